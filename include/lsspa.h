@@ -1,0 +1,119 @@
+/* lsspa.h -- C ABI of the MI355X-native LS-SPA engine (liblsspa_hip.so).
+ *
+ * The reference (cvxgrp/ls-spa @ v2) has no FFI layer: its boundary is the Python
+ * package surface of ls_spa/ls_spa.py.  Each entry point below names the reference
+ * function(s) it stands in for; the Python host package ls-spa_amd/ls_spa binds them
+ * with ctypes and re-creates the reference's own signatures on top.
+ *
+ * Conventions: extern "C"; plain pointers and sizes only; int status return
+ * (0 = LSSPA_OK); no C++ exception crosses the boundary; the caller owns every host
+ * buffer, the library owns every device buffer behind the opaque context; one context
+ * per GPU; a context is not thread-safe.  All matrices are row-major.  After a
+ * non-zero status lsspa_last_error() returns a description.
+ */
+#ifndef LSSPA_H
+#define LSSPA_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSSPA_ABI_VERSION 1
+
+#define LSSPA_OK 0
+#define LSSPA_ERR_ARG 1     /* bad argument / shape */
+#define LSSPA_ERR_HIP 2     /* a HIP runtime call failed */
+#define LSSPA_ERR_STATE 3   /* call sequence error (no problem loaded, ...) */
+#define LSSPA_ERR_NOMEM 4   /* device or host allocation failed */
+
+#define LSSPA_F64 0
+#define LSSPA_F32 1
+#define LSSPA_HOST 0
+#define LSSPA_DEVICE 1
+
+/* info bit flags (lsspa_get_info) */
+#define LSSPA_INFO_NOT_PD 1 /* a non-positive pivot was met in a Cholesky step */
+
+typedef struct lsspa_ctx lsspa_ctx;
+
+int lsspa_abi_version(void);
+/* NULL context: error of the last failed lsspa_create on this thread */
+const char* lsspa_last_error(const lsspa_ctx* ctx);
+
+int lsspa_create(int32_t device, lsspa_ctx** out);
+int lsspa_destroy(lsspa_ctx* ctx);
+/* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = library-owned */
+int lsspa_set_stream(lsspa_ctx* ctx, void* hip_stream);
+int lsspa_synchronize(lsspa_ctx* ctx);
+
+/* a1 -- replaces reduce_data (ls_spa/ls_spa.py:290-318) and the |y_test|^2 of :180.
+ * Forms G = X_tr^T X_tr / N + reg I, g = X_tr^T y_tr / N and, when M >= p, H = X_te^T X_te,
+ * h = X_te^T y_te by one MFMA Gram pass each; when M < p the test rows themselves are
+ * kept (transposed) as the test factor.  X pointers: row-major [rows][ld]; dtype applies to
+ * X and y alike; location says whether the four pointers are host or device memory. */
+int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const void* y_train, int64_t N,
+                 const void* X_test, int64_t ld_test, const void* y_test, int64_t M, int32_t p, double reg,
+                 int32_t dtype, int32_t location);
+
+/* Load an already reduced problem (host pointers) -- the inputs square_shapley takes
+ * (ls_spa/ls_spa.py:256-258) in Gram form.  G [p][p], g [p]; aug_train >= g^T G^-1 g.
+ * tri != 0: H [p][p], h [p] (test Gram);  tri == 0: Ft [p][m] (transposed test factor), ytil [m]. */
+int lsspa_set_reduced(lsspa_ctx* ctx, int32_t p, const double* G, const double* g, double aug_train,
+                      int32_t tri, const double* H, const double* h, int32_t m, const double* Ft,
+                      const double* ytil, double y_norm_sq);
+
+int lsspa_get_problem(const lsspa_ctx* ctx, int32_t* p, int32_t* m, int32_t* tri, double* y_norm_sq);
+/* device -> host copies of the reduced problem; any pointer may be NULL */
+int lsspa_get_gram(lsspa_ctx* ctx, double* G, double* g, double* H, double* h);
+
+/* a7 -- replaces theta = lstsq(...) and r_squared (ls_spa/ls_spa.py:240-243): factor the
+ * identity ordering, back-substitute, sum its lift vector.  info: LSSPA_INFO_* flags. */
+int lsspa_full_fit(lsspa_ctx* ctx, double* theta, double* r_squared, int32_t* info);
+/* the reduce_data outputs in the reference's layout: R_tr [p][p] upper triangular,
+ * q_tr [p], F_te [m][p], q_te [m]  (any pointer may be NULL) */
+int lsspa_get_factors(lsspa_ctx* ctx, double* R_tr, double* q_tr, double* F_te, double* q_te);
+
+/* a2 + a3 -- replaces square_shapley over a batch of orderings and the antithetical
+ * pairing (ls_spa/ls_spa.py:203-208, :256-287).  perms: host int32 [B][p].  With
+ * antithetical != 0 every ordering is also evaluated reversed and the two lift vectors are
+ * averaged (one sample).  lifts_out: host [B][p] or NULL.  accumulate != 0: add the batch's
+ * moments about the running mean to the pending-batch buffer (a4). */
+int lsspa_lift_batch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t antithetical,
+                     double* lifts_out, int32_t accumulate);
+int lsspa_get_info(lsspa_ctx* ctx, int32_t* info);
+
+/* a4 -- replaces merge_sample_mean / merge_sample_cov (ls_spa/ls_spa.py:103-119, :212-216).
+ * The pending-batch buffer is a device fp64 array [1 + p + p*p] = [n_b, sum(l - mu), sum (l - mu)(l - mu)^T];
+ * with several GPUs it is the (only) all-reduce target; lsspa_stats_merge folds it into the
+ * running (n, mean, M2) by Chan's pairwise update and clears it. */
+int lsspa_stats_reset(lsspa_ctx* ctx);
+int lsspa_stats_pending(lsspa_ctx* ctx, void** device_ptr, int64_t* count);
+int lsspa_stats_merge(lsspa_ctx* ctx);
+/* n samples, mean [p], biased covariance [p][p] (may be NULL) */
+int lsspa_stats_get(lsspa_ctx* ctx, int64_t* n, double* mean, double* cov_biased);
+
+/* per-kernel-class HIP-event timing on the context's stream */
+#define LSSPA_K_GATHER 0
+#define LSSPA_K_CHOL_DIAG 1
+#define LSSPA_K_CHOL_PANEL 2
+#define LSSPA_K_STRIP 3
+#define LSSPA_K_LIFT 4
+#define LSSPA_K_STATS 5
+#define LSSPA_K_GRAM 6
+#define LSSPA_K_COUNT 7
+int lsspa_profile_enable(lsspa_ctx* ctx, int32_t on);
+int lsspa_profile_get(lsspa_ctx* ctx, int32_t kernel_class, double* total_ms, int64_t* launches);
+int lsspa_profile_reset(lsspa_ctx* ctx);
+
+/* test hooks */
+int lsspa_mfma_probe(lsspa_ctx* ctx, const double* A16x4, const double* B4x16, double* D16x16);
+/* factor one ordering and copy the padded factor(s) out: L [p_pad][p_pad] (train),
+ * Lt [p_pad][p_pad] (test, tri mode only, else untouched), V [n_iblk*64][m_pad] */
+int lsspa_debug_factor(lsspa_ctx* ctx, const int32_t* perm, double* L, double* Lt, double* V,
+                       int32_t* p_pad, int32_t* m_pad, int32_t* v_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSSPA_H */

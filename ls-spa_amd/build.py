@@ -1,0 +1,72 @@
+"""Build liblsspa_hip.so (hand-written HIP for gfx950) in-tree.
+
+    python ls-spa_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  The shared library lands in
+``ls-spa_amd/lib/`` (git-ignored, but it travels to the GPU box with the tree).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build")
+LIBNAME = "liblsspa_hip.so"
+SOURCES = ["k_factor.hip", "k_lift.hip", "k_gram.hip", "lsspa_api.hip"]
+HEADERS = ["tiles.h", "kernels.h", os.path.join("..", "..", "include", "lsspa.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the LS-SPA engine needs the ROCm toolchain to build")
+    return exe
+
+
+def lib_path() -> str:
+    return os.path.join(LIBDIR, LIBNAME)
+
+
+def _newest_input() -> float:
+    paths = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def build_native(force: bool = False, verbose: bool = True) -> str:
+    out = lib_path()
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= _newest_input():
+        return out
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            sys.stderr.write(r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    if verbose:
+        print(f"built {out}")
+    return out
+
+
+if __name__ == "__main__":
+    build_native(force="--force" in sys.argv)

@@ -1,0 +1,489 @@
+// Per-ordering factorisation kernels: permuted gather, blocked left-looking Cholesky
+// (diagonal-block and panel steps) and the strip triangular solve.
+//
+// What they replace in the reference (cvxgrp/ls-spa, ls_spa/ls_spa.py):
+//   gather      -> X_train[:, perm], X_test[:, perm]                    (:275-276)
+//   chol_*      -> np.linalg.qr of the permuted train factor            (:275)
+//   strip       -> solve_triangular + the X @ T product                 (:279-283)
+// in the Gram form  G_pi = L L^T  (L = R^T of the reference's QR up to row signs).
+#include "kernels.h"
+#include "tiles.h"
+
+namespace lsspa {
+
+// =====================================================================================
+// gather:  A[mat][i][j] = S[perm[i]][perm[j]]  (j <= i),  row p = s[perm[.]] | aug,
+//          rows > p = identity.  One workgroup walks GROWS output rows; each source row
+//          is read once, coalesced, into LDS and the permuted columns are picked there,
+//          so both the global read and the global write are contiguous.
+// =====================================================================================
+constexpr int GROWS = 16;
+
+__global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* rowbuf = reinterpret_cast<double*>(smem_raw);                      // [p_pad]
+  int32_t* sperm = reinterpret_cast<int32_t*>(smem_raw + sizeof(double) * a.p_pad);  // [p_pad]
+
+  const int tid = threadIdx.x;
+  const int mat = blockIdx.y;
+  const int src = mat / a.n_ord;
+  const int ord = mat - src * a.n_ord;
+  const int i0 = blockIdx.x * GROWS;
+  const int p = a.p, p_pad = a.p_pad;
+  const int32_t* perm = a.perms + (int64_t)ord * p;
+  const double* S = a.S[src];
+  const double* svec = a.s[src];
+  double* out = a.A + (int64_t)mat * p_pad * p_pad;
+
+  const int jmax = min(i0 + GROWS, p);  // permutation entries this workgroup can touch
+  for (int j = tid; j < jmax; j += 256) sperm[j] = perm[j];
+  __syncthreads();
+
+  for (int ii = 0; ii < GROWS; ++ii) {
+    const int i = i0 + ii;
+    if (i >= p_pad) break;
+    const int jend = min(((i + 1 + NB - 1) / NB) * NB, p_pad);  // zero-fill to the block edge
+    double* orow = out + (int64_t)i * p_pad;
+    if (i < p) {
+      const double* srow = S + (int64_t)sperm[i] * a.ld_src;
+      __syncthreads();  // previous row's picks are done
+      for (int c = 2 * tid; c < p; c += 512) {
+        if (c + 1 < p) {
+          *reinterpret_cast<double2*>(rowbuf + c) = *reinterpret_cast<const double2*>(srow + c);
+        } else {
+          rowbuf[c] = srow[c];
+        }
+      }
+      __syncthreads();
+      for (int j = 2 * tid; j < jend; j += 512) {
+        double2 v;
+        v.x = (j <= i) ? rowbuf[sperm[j]] : 0.0;
+        v.y = (j + 1 <= i) ? rowbuf[sperm[j + 1]] : 0.0;
+        *reinterpret_cast<double2*>(orow + j) = v;
+      }
+    } else if (i == p) {
+      for (int j = tid; j < jend; j += 256)
+        orow[j] = (j < p) ? svec[sperm[j]] : (j == p ? a.aug[src] : 0.0);
+    } else {
+      for (int j = tid; j < jend; j += 256) orow[j] = (j == i) ? 1.0 : 0.0;
+    }
+  }
+}
+
+hipError_t launch_gather(const GatherArgs& a, hipStream_t st) {
+  if (a.p < 1 || a.p_pad % NB != 0 || a.p_pad <= a.p || a.n_ord < 1 || a.n_src < 1 || a.n_src > 2 ||
+      (a.ld_src & 1))
+    return hipErrorInvalidValue;
+  const size_t shmem = sizeof(double) * a.p_pad + sizeof(int32_t) * a.p_pad;
+  if (shmem > 160 * 1024) return hipErrorInvalidValue;
+  dim3 grid((a.p_pad + GROWS - 1) / GROWS, a.n_ord * a.n_src);
+  // aug row reads sperm[j] for all j < p: the workgroup holding row p must have them all
+  // (jmax = min(i0 + GROWS, p) = p there), so nothing else to arrange.
+  hipLaunchKernelGGL(gather_kernel, grid, dim3(256), shmem, st, a);
+  return hipGetLastError();
+}
+
+// =====================================================================================
+// chol_diag, step J:  T = A[J,J] - sum_{K<J} L[J,K] L[J,K]^T   (fp64 MFMA)
+//                     T = L_JJ L_JJ^T  by an in-LDS elimination that carries the
+//                     identity along, so L_JJ^-1 comes out of the same sweep.
+// One workgroup per matrix.
+// =====================================================================================
+__global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, double* __restrict__ Dinv,
+                                                        int32_t* __restrict__ info, int p_pad, int J,
+                                                        int nblk) {
+  __shared__ __attribute__((aligned(16))) double s_rk[64 * RK_LD];
+  __shared__ double s_T[64 * TT_LD];
+  __shared__ double s_Y[64 * TT_LD];
+  __shared__ double s_dd[64];
+  __shared__ int s_bad;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int mt = blockIdx.x;
+  double* M = A + (int64_t)mt * p_pad * p_pad;
+  const int J0 = J * NB;
+  const int tjq = w >> 1, tiq = w & 1;
+
+  d4 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = d4_zero();
+
+  const double* srcJ = M + (int64_t)J0 * p_pad;
+  const int nch = J0 / KCH;
+  RKRegs<64> rj = {};
+  if (nch > 0) rk_load<64>(rj, srcJ, p_pad, tid, 64);
+  for (int c = 0; c < nch; ++c) {
+    __syncthreads();
+    rk_store<64>(rj, s_rk, tid);
+    __syncthreads();
+    if (c + 1 < nch) rk_load<64>(rj, srcJ + (c + 1) * KCH, p_pad, tid, 64);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double av[2], bv[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) av[x] = s_rk[(16 * (2 * tjq + x) + l15) * RK_LD + 4 * kk + l4];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) bv[y] = s_rk[(16 * (2 * tiq + y) + l15) * RK_LD + 4 * kk + l4];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = mfma(av[x], bv[y], acc[x][y]);
+    }
+  }
+
+  // T <- A[J,J] (lower part is meaningful), Y <- I
+  if (tid == 0) s_bad = 0;
+  for (int idx = tid; idx < 64 * 64; idx += 256) {
+    const int row = idx >> 6, col = idx & 63;
+    s_T[row * TT_LD + col] = (col <= row) ? M[(int64_t)(J0 + row) * p_pad + J0 + col] : 0.0;
+    s_Y[row * TT_LD + col] = (row == col) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  // acc holds (sum L L^T)^T: element [j][i]; the matrix is symmetric, write it at T[i][j]
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * (2 * tjq + x) + acc_row(l4, r);
+        const int i = 16 * (2 * tiq + y) + l15;
+        if (j <= i) s_T[i * TT_LD + j] -= acc[x][y][r];
+      }
+  __syncthreads();
+
+  // elimination on [T | Y] without scaling: after step k column k of T is final
+  // (= L[:,k] * L[k][k]) and row k of Y is final (= (L^-1)[k,:] * L[k][k]).
+  const int ty = tid >> 4, tx = tid & 15;
+  for (int k = 0; k < 64; ++k) {
+    double d = s_T[k * TT_LD + k];
+    if (!(d > 0.0)) {  // not positive definite (or NaN): flag it and keep going finitely
+      d = 1.0;
+      if (tid == 0) s_bad = 1;
+    }
+    if (tid == 0) s_dd[k] = d;
+    const double invd = 1.0 / d;
+    const int a0 = (k + 1 > ty) ? (k + 1 - ty + 15) >> 4 : 0;  // first a with ty + 16 a > k
+    for (int a = a0; a < 4; ++a) {
+      const int i = ty + 16 * a;
+      const double f = s_T[i * TT_LD + k] * invd;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int j = tx + 16 * cc;
+        if (j > k && j <= i) s_T[i * TT_LD + j] -= f * s_T[j * TT_LD + k];
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = tx + 16 * cc;
+        if (c <= k) s_Y[i * TT_LD + c] -= f * s_Y[k * TT_LD + c];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < 64) s_dd[tid] = 1.0 / sqrt(s_dd[tid]);  // now holds 1 / L[k][k]
+  __syncthreads();
+
+  double* Dg = Dinv + ((int64_t)mt * nblk + J) * 4096;
+  for (int idx = tid; idx < 64 * 64; idx += 256) {
+    const int row = idx >> 6, col = idx & 63;
+    double lv = 0.0, xv = 0.0;
+    if (col < row) lv = s_T[row * TT_LD + col] * s_dd[col];
+    if (col == row) lv = 1.0 / s_dd[col];
+    if (col <= row) xv = s_Y[row * TT_LD + col] * s_dd[row];
+    M[(int64_t)(J0 + row) * p_pad + J0 + col] = lv;
+    Dg[idx] = xv;
+  }
+  if (tid == 0 && s_bad) atomicOr(&info[0], 1);
+}
+
+hipError_t launch_chol_diag(double* A, double* Dinv, int32_t* info, int p_pad, int J, int n_mats,
+                            hipStream_t st) {
+  if (p_pad % NB != 0 || J < 0 || J >= p_pad / NB || n_mats < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(chol_diag_kernel, dim3(n_mats), dim3(256), 0, st, A, Dinv, info, p_pad, J,
+                     p_pad / NB);
+  return hipGetLastError();
+}
+
+// =====================================================================================
+// chol_panel, step J:  for a 128-row tile I below the diagonal block,
+//     C = A[I,J] - sum_{K<J} L[I,K] L[J,K]^T ;  L[I,J] = C * L_JJ^-T
+// The accumulators hold C^T, which is exactly the B operand of  (L_JJ^-1) * C^T.
+// =====================================================================================
+__global__ __launch_bounds__(256, 2) void chol_panel_kernel(double* __restrict__ A,
+                                                            const double* __restrict__ Dinv, int p_pad,
+                                                            int J, int nblk) {
+  __shared__ __attribute__((aligned(16))) double s_rkj[64 * RK_LD];
+  __shared__ __attribute__((aligned(16))) double s_rki[128 * RK_LD];
+  __shared__ __attribute__((aligned(16))) double s_dinv[64 * DI_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int mt = blockIdx.y;
+  double* M = A + (int64_t)mt * p_pad * p_pad;
+  const int J0 = J * NB;
+  const int I0 = J0 + NB + blockIdx.x * 128;
+  const int rows_valid = min(128, p_pad - I0);
+
+  d4 acc[4][2];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = d4_zero();
+
+  const double* srcJ = M + (int64_t)J0 * p_pad;
+  const double* srcI = M + (int64_t)I0 * p_pad;
+  const int nch = J0 / KCH;
+  RKRegs<64> rj = {};
+  RKRegs<128> ri = {};
+  if (nch > 0) {
+    rk_load<64>(rj, srcJ, p_pad, tid, 64);
+    rk_load<128>(ri, srcI, p_pad, tid, rows_valid);
+  }
+  for (int c = 0; c < nch; ++c) {
+    __syncthreads();
+    rk_store<64>(rj, s_rkj, tid);
+    rk_store<128>(ri, s_rki, tid);
+    __syncthreads();
+    if (c + 1 < nch) {
+      rk_load<64>(rj, srcJ + (c + 1) * KCH, p_pad, tid, 64);
+      rk_load<128>(ri, srcI + (c + 1) * KCH, p_pad, tid, rows_valid);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double av[4], bv[2];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) av[x] = s_rkj[(16 * x + l15) * RK_LD + 4 * kk + l4];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) bv[y] = s_rki[(32 * w + 16 * y + l15) * RK_LD + 4 * kk + l4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = mfma(av[x], bv[y], acc[x][y]);
+    }
+  }
+
+  load_block64(s_dinv, Dinv + ((int64_t)mt * nblk + J) * 4096, tid);
+
+  // C^T = A[I,J]^T - acc, 16 columns of J at a time through the row-tile buffer
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    __syncthreads();
+    rk_load<128>(ri, srcI + J0 + 16 * x, p_pad, tid, rows_valid);
+    rk_store<128>(ri, s_rki, tid);
+    __syncthreads();
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[x][y][r] = s_rki[(32 * w + 16 * y + l15) * RK_LD + acc_row(l4, r)] - acc[x][y][r];
+  }
+
+  // out^T[j'][i] = sum_k Dinv[j'][k] C[i][k]   (Dinv lower triangular: k-blocks above j' vanish)
+  d4 outv[4][2];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) outv[x][y] = d4_zero();
+#pragma unroll
+  for (int xp = 0; xp < 4; ++xp)
+#pragma unroll
+    for (int x = 0; x <= xp; ++x)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double av = s_dinv[(16 * xp + l15) * DI_LD + 16 * x + acc_row(l4, r)];
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+          d4 t = outv[xp][y];
+          // B operand: element k = 4 r + l4 of the 16-wide k block x is acc[x][y][r]
+          outv[xp][y] = mfma(av, acc[x][y][r], t);
+        }
+      }
+
+  // store through the row-tile buffer so that the global writes are 128-B row segments
+#pragma unroll
+  for (int xp = 0; xp < 4; ++xp) {
+    __syncthreads();
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        s_rki[(32 * w + 16 * y + l15) * RK_LD + acc_row(l4, r)] = outv[xp][y][r];
+    __syncthreads();
+    const int c = tid & 7, row = tid >> 3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rr = row + 32 * q;
+      if (rr < rows_valid)
+        *reinterpret_cast<double2*>(M + (int64_t)(I0 + rr) * p_pad + J0 + 16 * xp + 2 * c) =
+            *reinterpret_cast<const double2*>(s_rki + rr * RK_LD + 2 * c);
+    }
+  }
+}
+
+hipError_t launch_chol_panel(double* A, const double* Dinv, int p_pad, int J, int n_mats, hipStream_t st) {
+  const int nblk = p_pad / NB;
+  if (p_pad % NB != 0 || J < 0 || J >= nblk - 1 || n_mats < 1) return hipErrorInvalidValue;
+  const int rows_below = p_pad - (J + 1) * NB;
+  dim3 grid((rows_below + 127) / 128, n_mats);
+  hipLaunchKernelGGL(chol_panel_kernel, grid, dim3(256), 0, st, A, Dinv, p_pad, J, nblk);
+  return hipGetLastError();
+}
+
+// =====================================================================================
+// strip:  V = L^-1 * RHS for one 128-column strip of the right-hand side, walking the
+// 64-row blocks top to bottom:  V[I] = L_II^-1 ( RHS[I] - sum_{K<I} L[I,K] V[K] ).
+//   tri  : RHS = L_t (Cholesky factor of the permuted test Gram), lower triangular, so a
+//          strip starts at its own diagonal block.
+//   rect : RHS = rows perm[i] of Ft (p x m), a plain row gather.
+// Strips are independent: no inter-workgroup traffic.
+// =====================================================================================
+__global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
+  __shared__ __attribute__((aligned(16))) double s_rk[64 * RK_LD];
+  __shared__ __attribute__((aligned(16))) double s_kc[16 * KC_LD];
+  __shared__ __attribute__((aligned(16))) double s_dinv[64 * DI_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int ord = blockIdx.y;
+  const int c0 = blockIdx.x * 128;
+  const int p = a.p, p_pad = a.p_pad, m_pad = a.m_pad;
+  const int nblk = p_pad / NB;
+  const int n_iblk = (p + NB - 1) / NB;
+  const double* L = a.A + (int64_t)ord * p_pad * p_pad;
+  const double* Lt = a.tri ? a.rhs + (int64_t)ord * p_pad * p_pad : nullptr;
+  const int32_t* perm = a.tri ? nullptr : a.perms + (int64_t)ord * p;
+  double* V = a.V + (int64_t)ord * n_iblk * NB * m_pad;
+
+  const int ib0 = a.tri ? c0 / NB : 0;
+  const int kstart = a.tri ? c0 : 0;
+  if (a.tri) {
+    // rows above the strip's first diagonal block are structurally zero; later kernels read them
+    for (int idx = tid; idx < ib0 * NB * 64; idx += 256) {
+      const int row = idx >> 6, c2 = idx & 63;
+      *reinterpret_cast<double2*>(V + (int64_t)row * m_pad + c0 + 2 * c2) = make_double2(0.0, 0.0);
+    }
+  }
+
+  for (int ib = ib0; ib < n_iblk; ++ib) {
+    const int I0 = ib * NB;
+    d4 acc[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) acc[x][y] = d4_zero();
+
+    const double* srcL = L + (int64_t)I0 * p_pad + kstart;
+    const double* srcV = V + (int64_t)kstart * m_pad + c0;
+    const int nch = (I0 - kstart) / KCH;
+    RKRegs<64> rl = {};
+    KCRegs rv = {};
+    if (nch > 0) {
+      rk_load<64>(rl, srcL, p_pad, tid, 64);
+      kc_load(rv, srcV, m_pad, tid);
+    }
+    for (int c = 0; c < nch; ++c) {
+      __syncthreads();
+      rk_store<64>(rl, s_rk, tid);
+      kc_store(rv, s_kc, tid);
+      __syncthreads();
+      if (c + 1 < nch) {
+        rk_load<64>(rl, srcL + (c + 1) * KCH, p_pad, tid, 64);
+        kc_load(rv, srcV + (int64_t)(c + 1) * KCH * m_pad, m_pad, tid);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        double av[4], bv[2];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) av[x] = s_rk[(16 * x + l15) * RK_LD + 4 * kk + l4];
+#pragma unroll
+        for (int y = 0; y < 2; ++y) bv[y] = s_kc[(4 * kk + l4) * KC_LD + 32 * w + 16 * y + l15];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y) acc[x][y] = mfma(av[x], bv[y], acc[x][y]);
+      }
+    }
+
+    __syncthreads();  // s_dinv is still being read by slower waves of the previous block
+    load_block64(s_dinv, a.Dinv + ((int64_t)ord * nblk + ib) * 4096, tid);
+
+    // C = RHS[I] - acc  (direct global reads: 16 lanes cover one 128-B row segment)
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = I0 + 16 * x + acc_row(l4, r);
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+          const int c = c0 + 32 * w + 16 * y + l15;
+          double rv0 = 0.0;
+          if (a.tri) {
+            if (c < I0 + NB) rv0 = Lt[(int64_t)i * p_pad + c];
+          } else {
+            if (i < p) rv0 = a.rhs[(int64_t)perm[i] * m_pad + c];
+          }
+          acc[x][y][r] = rv0 - acc[x][y][r];
+        }
+      }
+    __syncthreads();
+
+    d4 outv[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) outv[x][y] = d4_zero();
+#pragma unroll
+    for (int xp = 0; xp < 4; ++xp)
+#pragma unroll
+      for (int x = 0; x <= xp; ++x)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double av = s_dinv[(16 * xp + l15) * DI_LD + 16 * x + acc_row(l4, r)];
+#pragma unroll
+          for (int y = 0; y < 2; ++y) outv[xp][y] = mfma(av, acc[x][y][r], outv[xp][y]);
+        }
+
+#pragma unroll
+    for (int xp = 0; xp < 4; ++xp)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = I0 + 16 * xp + acc_row(l4, r);
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+          V[(int64_t)i * m_pad + c0 + 32 * w + 16 * y + l15] = outv[xp][y][r];
+      }
+    // the next block's k-loop reads these rows back (written by other waves of this workgroup)
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+hipError_t launch_strip(const StripArgs& a, hipStream_t st) {
+  if (a.p < 1 || a.p_pad % NB != 0 || a.m_pad % 128 != 0 || a.n_ord < 1) return hipErrorInvalidValue;
+  if (a.tri && a.m_pad > a.p_pad + 127) return hipErrorInvalidValue;
+  if (!a.tri && a.perms == nullptr) return hipErrorInvalidValue;
+  dim3 grid(a.m_pad / 128, a.n_ord);
+  hipLaunchKernelGGL(strip_kernel, grid, dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// =====================================================================================
+// probe: one MFMA, used by the unit test that pins the f64 operand / result lane maps
+// =====================================================================================
+__global__ void mfma_probe_kernel(const double* A, const double* B, double* D) {
+  const int l = threadIdx.x, l15 = l & 15, l4 = l >> 4;
+  d4 acc = d4_zero();
+  acc = mfma(A[l15 * 4 + l4], B[l4 * 16 + l15], acc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) D[acc_row(l4, r) * 16 + l15] = acc[r];
+}
+
+hipError_t launch_mfma_probe(const double* A, const double* B, double* D, hipStream_t st) {
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, st, A, B, D);
+  return hipGetLastError();
+}
+
+}  // namespace lsspa

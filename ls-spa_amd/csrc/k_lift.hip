@@ -1,0 +1,267 @@
+// Lift extraction, running statistics and the final back-substitution.
+//
+// Reference counterparts (cvxgrp/ls-spa, ls_spa/ls_spa.py):
+//   lift_partial / lift_finish -> costs, R_sq, ediff1d, argsort scatter   (:282-285)
+//                                 and the antithetical average            (:205-208)
+//   stats_batch / stats_merge  -> merge_sample_mean / merge_sample_cov    (:103-119, :212-216)
+//   backsolve                  -> theta = lstsq(R_tr, y_tr)               (:240)
+//
+// With V = L^-1 RHS (rows j in ordering position, columns c in "test space"),
+// z = L^-1 g_pi and y~ the reduced test target, the fitted values of the j-th nested
+// model are  N_j = sum_{k<=j} z_k V[k,:]  and its lift is
+//     ( |y~ - N_{j-1}|^2 - |y~ - N_j|^2 ) / |y_test|^2 = z_j V[j,:] . (2 y~ - N_j - N_{j-1}) / |y_test|^2
+#include "kernels.h"
+#include "tiles.h"
+
+namespace lsspa {
+
+// One wave per 64-column strip: lane = column, rows walked in order (the running N is a
+// scan down the rows); per 64-row tile the per-row dot products are reduced through LDS.
+__global__ __launch_bounds__(128) void lift_partial_kernel(LiftArgs a) {
+  __shared__ double s_E[2][64 * TT_LD];
+  __shared__ double s_z[2][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int ord = blockIdx.y;
+  const int strip = blockIdx.x * 2 + w;
+  const int nstrips = a.m_pad / 64;
+  const int cs = strip * 64;
+  const int p = a.p, p_pad = a.p_pad, m_pad = a.m_pad;
+  const int n_iblk = (p + NB - 1) / NB;
+  const double* L = a.A + (int64_t)ord * p_pad * p_pad;
+  const double* zrow = L + (int64_t)p * p_pad;
+  const double* V = a.V + (int64_t)ord * n_iblk * NB * m_pad;
+  double* Pp = a.Ppart + ((int64_t)ord * nstrips + strip) * p_pad;
+  const int c = cs + lane;
+  double yt;
+  if (a.tri)
+    yt = (c < p) ? a.At[(int64_t)ord * p_pad * p_pad + (int64_t)p * p_pad + c] : 0.0;
+  else
+    yt = a.ytil[c];
+  double* E = s_E[w];
+  double* zs = s_z[w];
+
+  double run = 0.0;
+  for (int jb = 0; jb < n_iblk; ++jb) {
+    const int j0 = jb * 64;
+    if (a.tri && j0 + 64 <= cs) {  // V is lower triangular: nothing in this strip yet
+      if (j0 + lane < p_pad) Pp[j0 + lane] = 0.0;
+      continue;
+    }
+    zs[lane] = (j0 + lane < p) ? zrow[j0 + lane] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    for (int jj = 0; jj < 64; ++jj) {
+      const int j = j0 + jj;
+      double e = 0.0;
+      if (j < p) {
+        const double v = V[(int64_t)j * m_pad + c];
+        const double t = zs[jj] * v;
+        e = v * (2.0 * (yt - run) - t);
+        run += t;
+      }
+      E[jj * TT_LD + lane] = e;
+    }
+    __builtin_amdgcn_wave_barrier();
+    double s = 0.0;
+#pragma unroll 8
+    for (int cc = 0; cc < 64; ++cc) s += E[lane * TT_LD + cc];
+    Pp[j0 + lane] = s;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// lifts[sample][perm[j]] = mean over the sample's orderings of z_j * sum_strips P_j / |y|^2
+__global__ __launch_bounds__(256) void lift_finish_kernel(LiftArgs a) {
+  const int sample = blockIdx.x;
+  const int nstrips = a.m_pad / 64;
+  const int p = a.p, p_pad = a.p_pad;
+  const double wgt = 1.0 / (a.per_sample * a.y_norm_sq);
+  double* out = a.lifts + (int64_t)sample * p;
+  for (int k = 0; k < a.per_sample; ++k) {
+    const int ord = sample * a.per_sample + k;
+    const int32_t* perm = a.perms + (int64_t)ord * p;
+    const double* zrow = a.A + (int64_t)ord * p_pad * p_pad + (int64_t)p * p_pad;
+    const double* Pp = a.Ppart + (int64_t)ord * nstrips * p_pad;
+    for (int j = threadIdx.x; j < p; j += 256) {
+      double s = 0.0;
+      for (int t = 0; t < nstrips; ++t) s += Pp[(int64_t)t * p_pad + j];
+      const double val = zrow[j] * s * wgt;
+      const int f = perm[j];
+      if (k == 0)
+        out[f] = val;
+      else
+        out[f] += val;
+    }
+    __syncthreads();  // a feature is written by different threads in different orderings
+  }
+}
+
+hipError_t launch_lift(const LiftArgs& a, hipStream_t st) {
+  if (a.p < 1 || a.p_pad % NB != 0 || a.m_pad % 128 != 0 || a.n_ord < 1 ||
+      (a.per_sample != 1 && a.per_sample != 2) || a.n_ord % a.per_sample != 0 || !(a.y_norm_sq > 0.0))
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(lift_partial_kernel, dim3(a.m_pad / 128, a.n_ord), dim3(128), 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lift_finish_kernel, dim3(a.n_ord / a.per_sample), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// pending-batch moments about the running mean mu:  D = lifts - mu,
+//   buf[0] (+)= n_s ;  buf[1+a] (+)= sum_s D[s][a] ;  buf[1+p+a*p+b] (+)= sum_s D[s][a] D[s][b]
+// 64 x 64 output tile per workgroup, 16 samples staged per step.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stats_batch_kernel(const double* __restrict__ lifts,
+                                                          const double* __restrict__ mean,
+                                                          double* __restrict__ buf, int n_samples, int p,
+                                                          int accumulate) {
+  __shared__ double sa[16][65];
+  __shared__ double sb[16][65];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int a0 = blockIdx.y * 64, b0 = blockIdx.x * 64;
+  double acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+  double colsum[4] = {0.0, 0.0, 0.0, 0.0};
+  const bool do_sum = (blockIdx.x == 0);  // column sums once per a-tile
+
+  for (int s0 = 0; s0 < n_samples; s0 += 16) {
+    __syncthreads();
+    for (int idx = tid; idx < 16 * 64; idx += 256) {
+      const int s = idx >> 6, c = idx & 63;
+      double va = 0.0, vb = 0.0;
+      if (s0 + s < n_samples) {
+        if (a0 + c < p) va = lifts[(int64_t)(s0 + s) * p + a0 + c] - mean[a0 + c];
+        if (b0 + c < p) vb = lifts[(int64_t)(s0 + s) * p + b0 + c] - mean[b0 + c];
+      }
+      sa[s][c] = va;
+      sb[s][c] = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) av[u] = sa[s][ty + 16 * u];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) bv[v] = sb[s][tx + 16 * v];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+      if (do_sum && tx == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) colsum[u] += av[u];
+      }
+    }
+  }
+  double* S = buf + 1;
+  double* Q = buf + 1 + p;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int ai = a0 + ty + 16 * u;
+    if (ai >= p) continue;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int bi = b0 + tx + 16 * v;
+      if (bi >= p) continue;
+      const int64_t o = (int64_t)ai * p + bi;
+      Q[o] = accumulate ? Q[o] + acc[u][v] : acc[u][v];
+    }
+    if (do_sum && tx == 0) S[ai] = accumulate ? S[ai] + colsum[u] : colsum[u];
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+    buf[0] = accumulate ? buf[0] + (double)n_samples : (double)n_samples;
+}
+
+hipError_t launch_stats_batch(const double* lifts, const double* mean, double* buf, int n_samples, int p,
+                              int accumulate, hipStream_t st) {
+  if (n_samples < 1 || p < 1) return hipErrorInvalidValue;
+  const int nt = (p + 63) / 64;
+  hipLaunchKernelGGL(stats_batch_kernel, dim3(nt, nt), dim3(256), 0, st, lifts, mean, buf, n_samples, p,
+                     accumulate);
+  return hipGetLastError();
+}
+
+// Chan et al. pairwise merge.  With delta = S / n_b (batch mean minus running mean):
+//   M2 += Q - n_b delta delta^T + (n n_b / (n + n_b)) delta delta^T ;  mean += (n_b / (n + n_b)) delta
+// M2 is updated by all workgroups first; mean and n by a second launch (stats_advance).
+__global__ __launch_bounds__(256) void stats_merge_m2_kernel(const double* __restrict__ buf,
+                                                             const double* __restrict__ state_n,
+                                                             double* __restrict__ M2, int p) {
+  const double nb = buf[0];
+  if (!(nb > 0.0)) return;
+  const double n = state_n[0];
+  const double coef = n * nb / (n + nb) - nb;
+  const double inv = 1.0 / nb;
+  const double* S = buf + 1;
+  const double* Q = buf + 1 + p;
+  const int64_t total = (int64_t)p * p;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+    const int ai = (int)(o / p), bi = (int)(o - (int64_t)ai * p);
+    M2[o] += Q[o] + coef * (S[ai] * inv) * (S[bi] * inv);
+  }
+}
+
+__global__ __launch_bounds__(256) void stats_advance_kernel(const double* __restrict__ buf,
+                                                            double* __restrict__ state_n,
+                                                            double* __restrict__ mean, int p) {
+  const double nb = buf[0];
+  if (!(nb > 0.0)) return;
+  const double n = state_n[0];
+  const double wgt = 1.0 / (n + nb);
+  for (int i = threadIdx.x; i < p; i += 256) mean[i] += buf[1 + i] * wgt;
+  __syncthreads();
+  if (threadIdx.x == 0) state_n[0] = n + nb;
+}
+
+hipError_t launch_stats_merge(const double* buf, double* state_n, double* mean, double* M2, int p,
+                              hipStream_t st) {
+  if (p < 1) return hipErrorInvalidValue;
+  const int64_t total = (int64_t)p * p;
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(stats_merge_m2_kernel, dim3(grid), dim3(256), 0, st, buf, state_n, M2, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(stats_advance_kernel, dim3(1), dim3(256), 0, st, buf, state_n, mean, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// theta = L^-T z, row-oriented so that every global read is a contiguous row of L:
+//   for j = p-1 .. 0 :  theta_j = w_j / L[j][j] ;  w[0:j] -= theta_j * L[j][0:j]
+// One workgroup; one-off cost per problem.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void backsolve_kernel(const double* __restrict__ L,
+                                                         double* __restrict__ theta, int p, int p_pad) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* wv = reinterpret_cast<double*>(smem_raw);
+  __shared__ double s_t;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < p; i += 1024) wv[i] = L[(int64_t)p * p_pad + i];
+  __syncthreads();
+  for (int j = p - 1; j >= 0; --j) {
+    const double* row = L + (int64_t)j * p_pad;
+    if (tid == 0) {
+      const double t = wv[j] / row[j];
+      s_t = t;
+      theta[j] = t;
+    }
+    __syncthreads();
+    const double t = s_t;
+    for (int i = tid; i < j; i += 1024) wv[i] -= t * row[i];
+    __syncthreads();
+  }
+}
+
+hipError_t launch_backsolve(const double* A, double* theta, int p, int p_pad, hipStream_t st) {
+  if (p < 1 || p_pad <= p) return hipErrorInvalidValue;
+  const size_t shmem = sizeof(double) * p;
+  if (shmem > 60 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(backsolve_kernel, dim3(1), dim3(1024), shmem, st, A, theta, p, p_pad);
+  return hipGetLastError();
+}
+
+}  // namespace lsspa

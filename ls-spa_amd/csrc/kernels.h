@@ -1,0 +1,79 @@
+// Host-side launchers of the LS-SPA HIP kernels.  Every launcher checks its shape
+// assumptions before launching (a faulting kernel can take the whole node down).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lsspa {
+
+struct GatherArgs {
+  const double* S[2];      // source Gram matrices (train, test), row-major, stride ld_src
+  const double* s[2];      // source right-hand sides (g, h)
+  double aug[2];           // diagonal value of the augmented row
+  int64_t ld_src;
+  const int32_t* perms;    // [n_ord][p]
+  int p, p_pad, n_ord, n_src;  // n_src = 1 (train only) or 2
+  double* A;               // [n_src * n_ord][p_pad][p_pad], lower triangles written
+};
+hipError_t launch_gather(const GatherArgs& a, hipStream_t st);
+
+// one left-looking block step J of the batched Cholesky factorisation
+hipError_t launch_chol_diag(double* A, double* Dinv, int32_t* info, int p_pad, int J, int n_mats,
+                            hipStream_t st);
+hipError_t launch_chol_panel(double* A, const double* Dinv, int p_pad, int J, int n_mats, hipStream_t st);
+
+struct StripArgs {
+  const double* A;         // factored train matrices, [n_ord][p_pad][p_pad]
+  const double* Dinv;      // [n_mats][nblk][64][64]; the first n_ord entries belong to A
+  const double* rhs;       // tri: factored test matrices (same layout as A); rect: Ft [p][m_pad]
+  const int32_t* perms;    // rect only
+  double* V;               // [n_ord][n_iblk*64][m_pad]
+  int p, p_pad, m_pad, n_ord, tri;
+};
+hipError_t launch_strip(const StripArgs& a, hipStream_t st);
+
+struct LiftArgs {
+  const double* A;         // factored train matrices (row p holds z)
+  const double* At;        // tri: factored test matrices (row p holds y-tilde); rect: null
+  const double* ytil;      // rect: [m_pad]
+  const double* V;
+  const int32_t* perms;    // [n_ord][p]
+  double* Ppart;           // [n_ord][m_pad/64][p_pad]
+  double* lifts;           // [n_samples][p]
+  double y_norm_sq;
+  int p, p_pad, m_pad, n_ord, per_sample, tri;  // per_sample = 1 or 2 orderings per sample
+};
+hipError_t launch_lift(const LiftArgs& a, hipStream_t st);
+
+// pending-batch moments about the current running mean: buf = [n_b, S (p), Q (p x p)]
+hipError_t launch_stats_batch(const double* lifts, const double* mean, double* buf, int n_samples, int p,
+                              int accumulate, hipStream_t st);
+// Chan merge of the pending batch into (n, mean, M2); n lives in state[0]
+hipError_t launch_stats_merge(const double* buf, double* state_n, double* mean, double* M2, int p,
+                              hipStream_t st);
+
+// theta = L^-T z for the factor stored in A (identity ordering), single workgroup
+hipError_t launch_backsolve(const double* A, double* theta, int p, int p_pad, hipStream_t st);
+
+// Gram contraction  C = Z^T Z, Z = [X | y]  (rows n, P1 = p + 1 columns), fp64 MFMA, split over rows
+struct GramArgs {
+  const void* X;           // [n][ld] row-major (device)
+  const void* y;           // [n]
+  int64_t n, ld;
+  int p;                   // features; Z has p + 1 columns
+  int is_f32;              // element type of X / y
+  double* slabs;           // workspace [n_split][n_pairs][128][128]
+  int n_split;
+  double* C;               // out: [P1pad][P1pad] full symmetric, P1pad = round_up(p + 1, 128)
+};
+size_t gram_workspace_bytes(int p, int n_split);
+int gram_default_split(int64_t n, int p);
+hipError_t launch_gram(const GramArgs& a, hipStream_t st);
+// G[a][b] = C[a][b] * scale + (a == b) * reg ; g[a] = C[p][a] * scale ; scalars[0] = C[p][p] * scale
+hipError_t launch_gram_finalize(const double* C, int p, double scale, double reg, double* G, int64_t ldg,
+                                double* g, double* scalar_out, hipStream_t st);
+
+// debugging / unit tests: D = A(16x4) * B(4x16) on one wave
+hipError_t launch_mfma_probe(const double* A, const double* B, double* D, hipStream_t st);
+
+}  // namespace lsspa

@@ -1,0 +1,873 @@
+// C ABI of the LS-SPA engine (include/lsspa.h): context, device memory and the
+// orchestration of the per-batch kernel sequence
+//     gather -> { chol_diag, chol_panel } x nblk -> strip -> lift -> stats
+#include "../../include/lsspa.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "tiles.h"
+
+using namespace lsspa;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ProfRec {
+  int cls;
+  hipEvent_t beg, end;
+};
+
+template <typename T>
+struct DevBuf {
+  T* ptr = nullptr;
+  size_t count = 0;
+};
+
+}  // namespace
+
+struct lsspa_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // reduced problem
+  bool have_problem = false;
+  int p = 0, p_pad = 0, m = 0, m_pad = 0, tri = 0;
+  double aug_train = 0.0, y_norm_sq = 0.0;
+  DevBuf<double> G, g, H, h, Ft, ytil, scal;
+
+  // per-batch workspace
+  int cap_ord = 0;      // orderings the workspace can hold
+  int cap_samples = 0;  // samples the lifts buffer can hold
+  DevBuf<double> A, V, Dinv, Ppart, lifts;
+  DevBuf<int32_t> perms_d, info_d;
+  int32_t* perms_h = nullptr;  // pinned staging
+  size_t perms_h_count = 0;
+
+  // running statistics
+  DevBuf<double> mean, M2, pend, state_n;
+  bool pend_dirty = false;
+
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof_recs;
+  double prof_ms[LSSPA_K_COUNT] = {0};
+  int64_t prof_n[LSSPA_K_COUNT] = {0};
+
+  int fail(int code, const char* what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess)
+      snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else
+      snprintf(buf, sizeof buf, "%s", what);
+    err = buf;
+    return code;
+  }
+};
+
+namespace {
+
+#define HIPCHK(expr)                                              \
+  do {                                                            \
+    hipError_t e_ = (expr);                                       \
+    if (e_ != hipSuccess) return ctx->fail(LSSPA_ERR_HIP, #expr, e_); \
+  } while (0)
+
+template <typename T>
+int dev_alloc(lsspa_ctx* ctx, DevBuf<T>& b, size_t count) {
+  if (b.count >= count && b.ptr) return LSSPA_OK;
+  if (b.ptr) (void)hipFree(b.ptr);
+  b.ptr = nullptr;
+  b.count = 0;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&b.ptr), count * sizeof(T));
+  if (e != hipSuccess) return ctx->fail(LSSPA_ERR_NOMEM, "hipMalloc", e);
+  b.count = count;
+  return LSSPA_OK;
+}
+
+template <typename T>
+void dev_free(DevBuf<T>& b) {
+  if (b.ptr) (void)hipFree(b.ptr);
+  b.ptr = nullptr;
+  b.count = 0;
+}
+
+#define TRY(expr)                     \
+  do {                                \
+    int rc_ = (expr);                 \
+    if (rc_ != LSSPA_OK) return rc_;  \
+  } while (0)
+
+inline int round_up(int x, int q) { return ((x + q - 1) / q) * q; }
+
+struct ProfScope {
+  lsspa_ctx* ctx;
+  ProfRec rec;
+  bool live;
+  ProfScope(lsspa_ctx* c, int cls) : ctx(c), live(false) {
+    if (!c->prof_on) return;
+    rec.cls = cls;
+    if (hipEventCreate(&rec.beg) != hipSuccess) return;
+    if (hipEventCreate(&rec.end) != hipSuccess) {
+      (void)hipEventDestroy(rec.beg);
+      return;
+    }
+    (void)hipEventRecord(rec.beg, c->stream);
+    live = true;
+  }
+  ~ProfScope() {
+    if (!live) return;
+    (void)hipEventRecord(rec.end, ctx->stream);
+    ctx->prof_recs.push_back(rec);
+  }
+};
+
+int prof_collect(lsspa_ctx* ctx) {
+  if (ctx->prof_recs.empty()) return LSSPA_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (auto& r : ctx->prof_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.beg, r.end) == hipSuccess) {
+      ctx->prof_ms[r.cls] += ms;
+      ctx->prof_n[r.cls] += 1;
+    }
+    (void)hipEventDestroy(r.beg);
+    (void)hipEventDestroy(r.end);
+  }
+  ctx->prof_recs.clear();
+  return LSSPA_OK;
+}
+
+// ---- small helper kernels that only the API layer needs ---------------------------------
+template <typename T>
+__global__ void transpose_test_kernel(const T* __restrict__ X, const T* __restrict__ y, int64_t M, int64_t ld,
+                                      int p, int m_pad, double* __restrict__ Ft, double* __restrict__ ytil) {
+  // Ft[f][r] = X[r][f]; tiny (M < p), clarity over speed
+  const int64_t total = (int64_t)p * m_pad;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+    const int f = (int)(o / m_pad), r = (int)(o - (int64_t)f * m_pad);
+    Ft[o] = (r < M) ? (double)X[(int64_t)r * ld + f] : 0.0;
+  }
+  if (blockIdx.x == 0)
+    for (int r = threadIdx.x; r < m_pad; r += 256) ytil[r] = (r < M) ? (double)y[r] : 0.0;
+}
+
+__global__ void sumsq_kernel(const double* __restrict__ v, int n, double* __restrict__ out) {
+  __shared__ double s[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += v[i] * v[i];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) s[threadIdx.x] += s[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = s[0];
+}
+
+// ---- problem set-up -----------------------------------------------------------------------
+int set_dims(lsspa_ctx* ctx, int p, int m, int tri) {
+  if (p < 1 || m < 1) return ctx->fail(LSSPA_ERR_ARG, "p and m must be positive");
+  if (tri && m != p) return ctx->fail(LSSPA_ERR_ARG, "tri mode needs m == p");
+  ctx->have_problem = false;
+  ctx->p = p;
+  ctx->m = m;
+  ctx->tri = tri;
+  ctx->p_pad = round_up(p + 1, NB);
+  ctx->m_pad = round_up(m, 128);
+  const size_t pp = (size_t)ctx->p_pad;
+  TRY(dev_alloc(ctx, ctx->G, (size_t)p * pp));
+  TRY(dev_alloc(ctx, ctx->g, pp));
+  TRY(dev_alloc(ctx, ctx->scal, 8));
+  if (tri) {
+    TRY(dev_alloc(ctx, ctx->H, (size_t)p * pp));
+    TRY(dev_alloc(ctx, ctx->h, pp));
+  } else {
+    TRY(dev_alloc(ctx, ctx->Ft, (size_t)p * ctx->m_pad));
+    TRY(dev_alloc(ctx, ctx->ytil, (size_t)ctx->m_pad));
+  }
+  TRY(dev_alloc(ctx, ctx->mean, (size_t)p));
+  TRY(dev_alloc(ctx, ctx->M2, (size_t)p * p));
+  TRY(dev_alloc(ctx, ctx->pend, (size_t)1 + p + (size_t)p * p));
+  TRY(dev_alloc(ctx, ctx->state_n, 8));
+  TRY(dev_alloc(ctx, ctx->info_d, 8));
+  // the workspace depends on p: drop it, it is re-created on demand
+  ctx->cap_ord = 0;
+  ctx->cap_samples = 0;
+  return LSSPA_OK;
+}
+
+int stats_reset(lsspa_ctx* ctx) {
+  const int p = ctx->p;
+  HIPCHK(hipMemsetAsync(ctx->mean.ptr, 0, sizeof(double) * p, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->M2.ptr, 0, sizeof(double) * (size_t)p * p, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->pend.ptr, 0, sizeof(double) * ((size_t)1 + p + (size_t)p * p), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->state_n.ptr, 0, sizeof(double) * 8, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->info_d.ptr, 0, sizeof(int32_t) * 8, ctx->stream));
+  ctx->pend_dirty = false;
+  return LSSPA_OK;
+}
+
+size_t bytes_per_ordering(const lsspa_ctx* ctx) {
+  const size_t pp = ctx->p_pad, nblk = pp / NB, n_iblk = (ctx->p + NB - 1) / NB;
+  const size_t nm = ctx->tri ? 2 : 1;
+  return nm * pp * pp * 8 + n_iblk * NB * (size_t)ctx->m_pad * 8 + nm * nblk * 4096 * 8 +
+         (size_t)(ctx->m_pad / 64) * pp * 8 + (size_t)ctx->p * 4;
+}
+
+int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
+  if (want_ord > ctx->cap_ord) {
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    // memory already held by the old workspace comes back when it is re-allocated
+    const size_t per = bytes_per_ordering(ctx);
+    size_t budget = (size_t)(0.85 * (double)free_b) + (size_t)ctx->cap_ord * per;
+    int cap = (int)std::min<size_t>((size_t)want_ord, budget / per);
+    cap = std::min(cap, 1024);
+    cap &= ~1;  // keep antithetical pairs together
+    if (cap < 2) return ctx->fail(LSSPA_ERR_NOMEM, "not enough device memory for two orderings");
+    if (cap > ctx->cap_ord) {
+      dev_free(ctx->A);
+      dev_free(ctx->V);
+      dev_free(ctx->Dinv);
+      dev_free(ctx->Ppart);
+      dev_free(ctx->perms_d);
+      const size_t pp = ctx->p_pad, nblk = pp / NB, n_iblk = (ctx->p + NB - 1) / NB;
+      const size_t nm = ctx->tri ? 2 : 1;
+      TRY(dev_alloc(ctx, ctx->A, nm * cap * pp * pp));
+      TRY(dev_alloc(ctx, ctx->V, (size_t)cap * n_iblk * NB * ctx->m_pad));
+      TRY(dev_alloc(ctx, ctx->Dinv, nm * cap * nblk * 4096));
+      TRY(dev_alloc(ctx, ctx->Ppart, (size_t)cap * (ctx->m_pad / 64) * pp));
+      TRY(dev_alloc(ctx, ctx->perms_d, (size_t)cap * ctx->p));
+      ctx->cap_ord = cap;
+    }
+  }
+  if (want_samples > ctx->cap_samples) {
+    TRY(dev_alloc(ctx, ctx->lifts, (size_t)want_samples * ctx->p));
+    ctx->cap_samples = want_samples;
+  }
+  return LSSPA_OK;
+}
+
+int ensure_pinned(lsspa_ctx* ctx, size_t count) {
+  if (ctx->perms_h_count >= count) return LSSPA_OK;
+  if (ctx->perms_h) (void)hipHostFree(ctx->perms_h);
+  ctx->perms_h = nullptr;
+  ctx->perms_h_count = 0;
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ctx->perms_h), count * sizeof(int32_t), 0);
+  if (e != hipSuccess) return ctx->fail(LSSPA_ERR_NOMEM, "hipHostMalloc", e);
+  ctx->perms_h_count = count;
+  return LSSPA_OK;
+}
+
+// Run gather -> factorisation -> strip -> lift for n_ord orderings already resident in perms_d.
+// lifts for sample s land in lifts_d[(s_off + s)][p].
+int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
+  const int p = ctx->p, p_pad = ctx->p_pad, m_pad = ctx->m_pad, nblk = p_pad / NB;
+  const int n_src = ctx->tri ? 2 : 1;
+  const int n_mats = n_ord * n_src;
+  {
+    ProfScope ps(ctx, LSSPA_K_GATHER);
+    GatherArgs ga;
+    ga.S[0] = ctx->G.ptr;
+    ga.s[0] = ctx->g.ptr;
+    ga.aug[0] = 2.0 * ctx->aug_train + 1.0;
+    ga.S[1] = ctx->tri ? ctx->H.ptr : nullptr;
+    ga.s[1] = ctx->tri ? ctx->h.ptr : nullptr;
+    ga.aug[1] = 2.0 * ctx->y_norm_sq + 1.0;
+    ga.ld_src = p_pad;
+    ga.perms = ctx->perms_d.ptr;
+    ga.p = p;
+    ga.p_pad = p_pad;
+    ga.n_ord = n_ord;
+    ga.n_src = n_src;
+    ga.A = ctx->A.ptr;
+    HIPCHK(launch_gather(ga, ctx->stream));
+  }
+  for (int J = 0; J < nblk; ++J) {
+    {
+      ProfScope ps(ctx, LSSPA_K_CHOL_DIAG);
+      HIPCHK(launch_chol_diag(ctx->A.ptr, ctx->Dinv.ptr, ctx->info_d.ptr, p_pad, J, n_mats, ctx->stream));
+    }
+    if (J + 1 < nblk) {
+      ProfScope ps(ctx, LSSPA_K_CHOL_PANEL);
+      HIPCHK(launch_chol_panel(ctx->A.ptr, ctx->Dinv.ptr, p_pad, J, n_mats, ctx->stream));
+    }
+  }
+  {
+    ProfScope ps(ctx, LSSPA_K_STRIP);
+    StripArgs sa;
+    sa.A = ctx->A.ptr;
+    sa.Dinv = ctx->Dinv.ptr;
+    sa.rhs = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * p_pad : ctx->Ft.ptr;
+    sa.perms = ctx->perms_d.ptr;
+    sa.V = ctx->V.ptr;
+    sa.p = p;
+    sa.p_pad = p_pad;
+    sa.m_pad = m_pad;
+    sa.n_ord = n_ord;
+    sa.tri = ctx->tri;
+    HIPCHK(launch_strip(sa, ctx->stream));
+  }
+  {
+    ProfScope ps(ctx, LSSPA_K_LIFT);
+    LiftArgs la;
+    la.A = ctx->A.ptr;
+    la.At = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * p_pad : nullptr;
+    la.ytil = ctx->tri ? nullptr : ctx->ytil.ptr;
+    la.V = ctx->V.ptr;
+    la.perms = ctx->perms_d.ptr;
+    la.Ppart = ctx->Ppart.ptr;
+    la.lifts = ctx->lifts.ptr + (size_t)s_off * p;
+    la.y_norm_sq = ctx->y_norm_sq;
+    la.p = p;
+    la.p_pad = p_pad;
+    la.m_pad = m_pad;
+    la.n_ord = n_ord;
+    la.per_sample = per_sample;
+    la.tri = ctx->tri;
+    HIPCHK(launch_lift(la, ctx->stream));
+  }
+  return LSSPA_OK;
+}
+
+// Stage `count` orderings (with their reverses when per_sample == 2) and run them.
+int stage_and_run(lsspa_ctx* ctx, const int32_t* perms, int n_samples, int per_sample, int s_off) {
+  const int p = ctx->p;
+  const int n_ord = n_samples * per_sample;
+  int32_t* hp = ctx->perms_h;
+  for (int s = 0; s < n_samples; ++s) {
+    const int32_t* src = perms + (size_t)s * p;
+    int32_t* d0 = hp + (size_t)s * per_sample * p;
+    for (int j = 0; j < p; ++j) {
+      const int32_t f = src[j];
+      if (f < 0 || f >= p) return ctx->fail(LSSPA_ERR_ARG, "ordering entry out of range");
+      d0[j] = f;
+    }
+    if (per_sample == 2) {
+      int32_t* d1 = d0 + p;
+      for (int j = 0; j < p; ++j) d1[j] = src[p - 1 - j];
+    }
+  }
+  HIPCHK(hipMemcpyAsync(ctx->perms_d.ptr, hp, sizeof(int32_t) * (size_t)n_ord * p, hipMemcpyHostToDevice,
+                        ctx->stream));
+  TRY(run_orderings(ctx, n_ord, per_sample, s_off));
+  // the pinned buffer is rewritten by the next sub-batch
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LSSPA_OK;
+}
+
+bool is_permutation(const int32_t* perm, int p, std::vector<char>& seen) {
+  seen.assign(p, 0);
+  for (int j = 0; j < p; ++j) {
+    const int32_t f = perm[j];
+    if (f < 0 || f >= p || seen[f]) return false;
+    seen[f] = 1;
+  }
+  return true;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int lsspa_abi_version(void) { return LSSPA_ABI_VERSION; }
+
+const char* lsspa_last_error(const lsspa_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int lsspa_create(int32_t device, lsspa_ctx** out) {
+  if (!out) {
+    g_create_error = "out pointer is NULL";
+    return LSSPA_ERR_ARG;
+  }
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n < 1) {
+    g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+    return LSSPA_ERR_HIP;
+  }
+  if (device < 0 || device >= n) {
+    g_create_error = "device index out of range";
+    return LSSPA_ERR_ARG;
+  }
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+    g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+    return LSSPA_ERR_HIP;
+  }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("this library is built for gfx950 only, device is ") + prop.gcnArchName;
+    return LSSPA_ERR_HIP;
+  }
+  lsspa_ctx* ctx = new (std::nothrow) lsspa_ctx();
+  if (!ctx) {
+    g_create_error = "out of host memory";
+    return LSSPA_ERR_NOMEM;
+  }
+  ctx->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+    g_create_error = std::string("stream creation: ") + hipGetErrorString(e);
+    delete ctx;
+    return LSSPA_ERR_HIP;
+  }
+  ctx->own_stream = true;
+  *out = ctx;
+  return LSSPA_OK;
+}
+
+int lsspa_destroy(lsspa_ctx* ctx) {
+  if (!ctx) return LSSPA_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& r : ctx->prof_recs) {
+    (void)hipEventDestroy(r.beg);
+    (void)hipEventDestroy(r.end);
+  }
+  dev_free(ctx->G); dev_free(ctx->g); dev_free(ctx->H); dev_free(ctx->h); dev_free(ctx->Ft);
+  dev_free(ctx->ytil); dev_free(ctx->scal); dev_free(ctx->A); dev_free(ctx->V); dev_free(ctx->Dinv);
+  dev_free(ctx->Ppart); dev_free(ctx->lifts); dev_free(ctx->perms_d); dev_free(ctx->info_d);
+  dev_free(ctx->mean); dev_free(ctx->M2); dev_free(ctx->pend); dev_free(ctx->state_n);
+  if (ctx->perms_h) (void)hipHostFree(ctx->perms_h);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return LSSPA_OK;
+}
+
+int lsspa_set_stream(lsspa_ctx* ctx, void* hip_stream) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (hip_stream) {
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    ctx->own_stream = false;
+  } else if (!ctx->own_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  return LSSPA_OK;
+}
+
+int lsspa_synchronize(lsspa_ctx* ctx) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LSSPA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int gram_side(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, int64_t ld, int p, int is_f32,
+                     double scale, double reg, double* G, double* g, double* scalar_out) {
+  const int n_split = gram_default_split(n, p);
+  const int P1pad = round_up(p + 1, 128);
+  DevBuf<double> slabs, C;
+  int rc = dev_alloc(ctx, slabs, gram_workspace_bytes(p, n_split) / sizeof(double));
+  if (rc == LSSPA_OK) rc = dev_alloc(ctx, C, (size_t)P1pad * P1pad);
+  if (rc == LSSPA_OK) {
+    ProfScope ps(ctx, LSSPA_K_GRAM);
+    GramArgs ga;
+    ga.X = X;
+    ga.y = y;
+    ga.n = n;
+    ga.ld = ld;
+    ga.p = p;
+    ga.is_f32 = is_f32;
+    ga.slabs = slabs.ptr;
+    ga.n_split = n_split;
+    ga.C = C.ptr;
+    hipError_t e = launch_gram(ga, ctx->stream);
+    if (e == hipSuccess) e = launch_gram_finalize(C.ptr, p, scale, reg, G, ctx->p_pad, g, scalar_out, ctx->stream);
+    if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "gram launch", e);
+  }
+  if (rc == LSSPA_OK) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "gram sync", e);
+  }
+  dev_free(slabs);
+  dev_free(C);
+  return rc;
+}
+
+int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const void* y_train, int64_t N,
+                 const void* X_test, int64_t ld_test, const void* y_test, int64_t M, int32_t p, double reg,
+                 int32_t dtype, int32_t location) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!X_train || !y_train || !X_test || !y_test) return ctx->fail(LSSPA_ERR_ARG, "NULL data pointer");
+  if (p < 1 || N < p || M < 1 || ld_train < p || ld_test < p)
+    return ctx->fail(LSSPA_ERR_ARG, "need 1 <= p <= N, M >= 1, ld >= p");
+  if (dtype != LSSPA_F64 && dtype != LSSPA_F32) return ctx->fail(LSSPA_ERR_ARG, "dtype");
+  if (location != LSSPA_HOST && location != LSSPA_DEVICE) return ctx->fail(LSSPA_ERR_ARG, "location");
+  if (!(reg >= 0.0)) return ctx->fail(LSSPA_ERR_ARG, "reg must be >= 0");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int tri = (M >= p) ? 1 : 0;
+  if (!tri && M > (1 << 20)) return ctx->fail(LSSPA_ERR_ARG, "M too large for rect mode");
+  TRY(set_dims(ctx, p, tri ? p : (int)M, tri));
+  const size_t es = dtype == LSSPA_F32 ? 4 : 8;
+
+  // host data: one side at a time through a temporary device copy
+  auto side = [&](const void* X, const void* y, int64_t n, int64_t ld, bool train) -> int {
+    const void *dX = X, *dy = y;
+    void *tX = nullptr, *ty = nullptr;
+    int64_t dld = ld;
+    int rc = LSSPA_OK;
+    if (location == LSSPA_HOST) {
+      hipError_t e = hipMalloc(&tX, (size_t)n * p * es);
+      if (e == hipSuccess) e = hipMalloc(&ty, (size_t)n * es);
+      if (e != hipSuccess) {
+        if (tX) (void)hipFree(tX);
+        return ctx->fail(LSSPA_ERR_NOMEM, "device copy of the data", e);
+      }
+      e = hipMemcpy2DAsync(tX, (size_t)p * es, X, (size_t)ld * es, (size_t)p * es, (size_t)n,
+                           hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(ty, y, (size_t)n * es, hipMemcpyHostToDevice, ctx->stream);
+      if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "H2D copy of the data", e);
+      dX = tX;
+      dy = ty;
+      dld = p;
+    }
+    if (rc == LSSPA_OK) {
+      if (train) {
+        rc = gram_side(ctx, dX, dy, n, dld, p, dtype == LSSPA_F32, 1.0 / (double)n, reg, ctx->G.ptr,
+                       ctx->g.ptr, ctx->scal.ptr + 0);
+      } else if (tri) {
+        rc = gram_side(ctx, dX, dy, n, dld, p, dtype == LSSPA_F32, 1.0, 0.0, ctx->H.ptr, ctx->h.ptr,
+                       ctx->scal.ptr + 1);
+      } else {
+        const int64_t total = (int64_t)p * ctx->m_pad;
+        const int grid = (int)std::min<int64_t>((total + 255) / 256, 2048);
+        if (dtype == LSSPA_F32)
+          hipLaunchKernelGGL(transpose_test_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream,
+                             (const float*)dX, (const float*)dy, n, dld, p, ctx->m_pad, ctx->Ft.ptr,
+                             ctx->ytil.ptr);
+        else
+          hipLaunchKernelGGL(transpose_test_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream,
+                             (const double*)dX, (const double*)dy, n, dld, p, ctx->m_pad, ctx->Ft.ptr,
+                             ctx->ytil.ptr);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->ytil.ptr, ctx->m_pad,
+                           ctx->scal.ptr + 1);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "test factor kernels", e);
+      }
+    }
+    if (tX) (void)hipFree(tX);
+    if (ty) (void)hipFree(ty);
+    return rc;
+  };
+  TRY(side(X_train, y_train, N, ld_train, true));
+  TRY(side(X_test, y_test, M, ld_test, false));
+  double sc[2];
+  HIPCHK(hipMemcpy(sc, ctx->scal.ptr, sizeof sc, hipMemcpyDeviceToHost));
+  ctx->aug_train = sc[0];
+  ctx->y_norm_sq = sc[1];
+  if (!(ctx->y_norm_sq > 0.0)) return ctx->fail(LSSPA_ERR_ARG, "y_test is identically zero (or NaN)");
+  TRY(stats_reset(ctx));
+  ctx->have_problem = true;
+  return LSSPA_OK;
+}
+
+int lsspa_set_reduced(lsspa_ctx* ctx, int32_t p, const double* G, const double* g, double aug_train,
+                      int32_t tri, const double* H, const double* h, int32_t m, const double* Ft,
+                      const double* ytil, double y_norm_sq) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!G || !g) return ctx->fail(LSSPA_ERR_ARG, "G and g are required");
+  if (tri ? (!H || !h) : (!Ft || !ytil)) return ctx->fail(LSSPA_ERR_ARG, "test side pointers missing");
+  if (!(y_norm_sq > 0.0) || !(aug_train >= 0.0)) return ctx->fail(LSSPA_ERR_ARG, "norms must be positive");
+  HIPCHK(hipSetDevice(ctx->device));
+  TRY(set_dims(ctx, p, tri ? p : m, tri ? 1 : 0));
+  const size_t pp = ctx->p_pad;
+  HIPCHK(hipMemcpy2D(ctx->G.ptr, pp * 8, G, (size_t)p * 8, (size_t)p * 8, p, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(ctx->g.ptr, 0, pp * 8));
+  HIPCHK(hipMemcpy(ctx->g.ptr, g, (size_t)p * 8, hipMemcpyHostToDevice));
+  if (tri) {
+    HIPCHK(hipMemcpy2D(ctx->H.ptr, pp * 8, H, (size_t)p * 8, (size_t)p * 8, p, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(ctx->h.ptr, 0, pp * 8));
+    HIPCHK(hipMemcpy(ctx->h.ptr, h, (size_t)p * 8, hipMemcpyHostToDevice));
+  } else {
+    const size_t mp = ctx->m_pad;
+    HIPCHK(hipMemset(ctx->Ft.ptr, 0, (size_t)p * mp * 8));
+    HIPCHK(hipMemcpy2D(ctx->Ft.ptr, mp * 8, Ft, (size_t)m * 8, (size_t)m * 8, p, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(ctx->ytil.ptr, 0, mp * 8));
+    HIPCHK(hipMemcpy(ctx->ytil.ptr, ytil, (size_t)m * 8, hipMemcpyHostToDevice));
+  }
+  ctx->aug_train = aug_train;
+  ctx->y_norm_sq = y_norm_sq;
+  TRY(stats_reset(ctx));
+  ctx->have_problem = true;
+  return LSSPA_OK;
+}
+
+int lsspa_get_problem(const lsspa_ctx* ctx, int32_t* p, int32_t* m, int32_t* tri, double* y_norm_sq) {
+  if (!ctx || !ctx->have_problem) return LSSPA_ERR_STATE;
+  if (p) *p = ctx->p;
+  if (m) *m = ctx->m;
+  if (tri) *tri = ctx->tri;
+  if (y_norm_sq) *y_norm_sq = ctx->y_norm_sq;
+  return LSSPA_OK;
+}
+
+int lsspa_get_gram(lsspa_ctx* ctx, double* G, double* g, double* H, double* h) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const size_t p = ctx->p, pp = ctx->p_pad;
+  if (G) HIPCHK(hipMemcpy2D(G, p * 8, ctx->G.ptr, pp * 8, p * 8, p, hipMemcpyDeviceToHost));
+  if (g) HIPCHK(hipMemcpy(g, ctx->g.ptr, p * 8, hipMemcpyDeviceToHost));
+  if ((H || h) && !ctx->tri) return ctx->fail(LSSPA_ERR_STATE, "no test Gram in rect mode");
+  if (H) HIPCHK(hipMemcpy2D(H, p * 8, ctx->H.ptr, pp * 8, p * 8, p, hipMemcpyDeviceToHost));
+  if (h) HIPCHK(hipMemcpy(h, ctx->h.ptr, p * 8, hipMemcpyDeviceToHost));
+  return LSSPA_OK;
+}
+
+// factor the identity ordering into workspace slot 0 (lifts into lifts_d row 0)
+static int factor_identity(lsspa_ctx* ctx, const int32_t* perm_or_null) {
+  const int p = ctx->p;
+  TRY(ensure_workspace(ctx, 2, 1));
+  TRY(ensure_pinned(ctx, (size_t)2 * p));
+  std::vector<int32_t> id(p);
+  for (int j = 0; j < p; ++j) id[j] = perm_or_null ? perm_or_null[j] : j;
+  return stage_and_run(ctx, id.data(), 1, 1, 0);
+}
+
+int lsspa_full_fit(lsspa_ctx* ctx, double* theta, double* r_squared, int32_t* info) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int p = ctx->p;
+  int32_t saved = 0, now = 0;
+  HIPCHK(hipMemcpy(&saved, ctx->info_d.ptr, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(ctx->info_d.ptr, 0, 4));
+  TRY(factor_identity(ctx, nullptr));
+  HIPCHK(hipMemcpy(&now, ctx->info_d.ptr, 4, hipMemcpyDeviceToHost));
+  saved |= now;
+  HIPCHK(hipMemcpy(ctx->info_d.ptr, &saved, 4, hipMemcpyHostToDevice));
+  if (info) *info = now;
+  if (theta) {
+    DevBuf<double> th;
+    TRY(dev_alloc(ctx, th, (size_t)p));
+    hipError_t e = launch_backsolve(ctx->A.ptr, th.ptr, p, ctx->p_pad, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(theta, th.ptr, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    dev_free(th);
+    if (e != hipSuccess) return ctx->fail(LSSPA_ERR_HIP, "backsolve", e);
+  }
+  if (r_squared) {
+    std::vector<double> l(p);
+    HIPCHK(hipMemcpy(l.data(), ctx->lifts.ptr, sizeof(double) * p, hipMemcpyDeviceToHost));
+    double s = 0.0;
+    for (int j = 0; j < p; ++j) s += l[j];
+    *r_squared = s;
+  }
+  return LSSPA_OK;
+}
+
+int lsspa_get_factors(lsspa_ctx* ctx, double* R_tr, double* q_tr, double* F_te, double* q_te) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int p = ctx->p, pp = ctx->p_pad, m = ctx->m;
+  TRY(factor_identity(ctx, nullptr));
+  std::vector<double> L((size_t)pp * pp);
+  HIPCHK(hipMemcpy(L.data(), ctx->A.ptr, L.size() * 8, hipMemcpyDeviceToHost));
+  if (R_tr)
+    for (int a = 0; a < p; ++a)
+      for (int b = 0; b < p; ++b) R_tr[(size_t)a * p + b] = (b >= a) ? L[(size_t)b * pp + a] : 0.0;
+  if (q_tr)
+    for (int a = 0; a < p; ++a) q_tr[a] = L[(size_t)p * pp + a];
+  if (ctx->tri) {
+    if (F_te || q_te) {
+      // slot layout of run_orderings: the test matrices follow the n_ord = 1 train matrices
+      HIPCHK(hipMemcpy(L.data(), ctx->A.ptr + (size_t)pp * pp, L.size() * 8, hipMemcpyDeviceToHost));
+      if (F_te)
+        for (int a = 0; a < p; ++a)
+          for (int b = 0; b < p; ++b) F_te[(size_t)a * p + b] = (b >= a) ? L[(size_t)b * pp + a] : 0.0;
+      if (q_te)
+        for (int a = 0; a < p; ++a) q_te[a] = L[(size_t)p * pp + a];
+    }
+  } else {
+    if (F_te) {
+      std::vector<double> Ft((size_t)p * ctx->m_pad);
+      HIPCHK(hipMemcpy(Ft.data(), ctx->Ft.ptr, Ft.size() * 8, hipMemcpyDeviceToHost));
+      for (int r = 0; r < m; ++r)
+        for (int f = 0; f < p; ++f) F_te[(size_t)r * p + f] = Ft[(size_t)f * ctx->m_pad + r];
+    }
+    if (q_te) HIPCHK(hipMemcpy(q_te, ctx->ytil.ptr, sizeof(double) * m, hipMemcpyDeviceToHost));
+  }
+  return LSSPA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int lsspa_lift_batch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t antithetical,
+                     double* lifts_out, int32_t accumulate) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  if (!perms || B < 1) return ctx->fail(LSSPA_ERR_ARG, "perms / B");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int p = ctx->p;
+  const int per = antithetical ? 2 : 1;
+  // validate before anything is launched: a repeated index would make a permuted Gram singular
+  {
+    std::vector<char> seen;
+    for (int s = 0; s < B; ++s)
+      if (!is_permutation(perms + (size_t)s * p, p, seen))
+        return ctx->fail(LSSPA_ERR_ARG, "perms: a row is not a permutation of 0..p-1");
+  }
+  TRY(ensure_workspace(ctx, std::min(B * per, 512), B));
+  const int sub = std::max(1, ctx->cap_ord / per);
+  TRY(ensure_pinned(ctx, (size_t)std::min(sub, (int)B) * per * p));
+  for (int s0 = 0; s0 < B; s0 += sub) {
+    const int ns = std::min(sub, B - s0);
+    TRY(stage_and_run(ctx, perms + (size_t)s0 * p, ns, per, s0));
+  }
+  if (accumulate) {
+    ProfScope ps(ctx, LSSPA_K_STATS);
+    HIPCHK(launch_stats_batch(ctx->lifts.ptr, ctx->mean.ptr, ctx->pend.ptr, B, p, ctx->pend_dirty ? 1 : 0,
+                              ctx->stream));
+    ctx->pend_dirty = true;
+  }
+  if (lifts_out) {
+    HIPCHK(hipMemcpyAsync(lifts_out, ctx->lifts.ptr, sizeof(double) * (size_t)B * p, hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return LSSPA_OK;
+}
+
+int lsspa_get_info(lsspa_ctx* ctx, int32_t* info) {
+  if (!ctx || !info) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(info, ctx->info_d.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LSSPA_OK;
+}
+
+int lsspa_stats_reset(lsspa_ctx* ctx) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  return stats_reset(ctx);
+}
+
+int lsspa_stats_pending(lsspa_ctx* ctx, void** device_ptr, int64_t* count) {
+  if (!ctx || !device_ptr || !count) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  *device_ptr = ctx->pend.ptr;
+  *count = (int64_t)1 + ctx->p + (int64_t)ctx->p * ctx->p;
+  return LSSPA_OK;
+}
+
+int lsspa_stats_merge(lsspa_ctx* ctx) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  {
+    ProfScope ps(ctx, LSSPA_K_STATS);
+    HIPCHK(launch_stats_merge(ctx->pend.ptr, ctx->state_n.ptr, ctx->mean.ptr, ctx->M2.ptr, ctx->p,
+                              ctx->stream));
+  }
+  // an empty pending buffer (n_b = 0) is what a rank with no samples contributes
+  HIPCHK(hipMemsetAsync(ctx->pend.ptr, 0, sizeof(double) * ((size_t)1 + ctx->p + (size_t)ctx->p * ctx->p),
+                        ctx->stream));
+  ctx->pend_dirty = false;
+  return LSSPA_OK;
+}
+
+int lsspa_stats_get(lsspa_ctx* ctx, int64_t* n, double* mean, double* cov_biased) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t p = ctx->p;
+  double nd = 0.0;
+  HIPCHK(hipMemcpyAsync(&nd, ctx->state_n.ptr, 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (mean) HIPCHK(hipMemcpyAsync(mean, ctx->mean.ptr, p * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (cov_biased) HIPCHK(hipMemcpyAsync(cov_biased, ctx->M2.ptr, p * p * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (n) *n = (int64_t)llround(nd);
+  if (cov_biased && nd > 0.0) {
+    const double inv = 1.0 / nd;
+    for (size_t i = 0; i < p * p; ++i) cov_biased[i] *= inv;
+  }
+  return LSSPA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int lsspa_profile_enable(lsspa_ctx* ctx, int32_t on) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  TRY(prof_collect(ctx));
+  ctx->prof_on = on != 0;
+  return LSSPA_OK;
+}
+
+int lsspa_profile_get(lsspa_ctx* ctx, int32_t k, double* total_ms, int64_t* launches) {
+  if (!ctx || k < 0 || k >= LSSPA_K_COUNT) return LSSPA_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  TRY(prof_collect(ctx));
+  if (total_ms) *total_ms = ctx->prof_ms[k];
+  if (launches) *launches = ctx->prof_n[k];
+  return LSSPA_OK;
+}
+
+int lsspa_profile_reset(lsspa_ctx* ctx) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  TRY(prof_collect(ctx));
+  for (int k = 0; k < LSSPA_K_COUNT; ++k) {
+    ctx->prof_ms[k] = 0.0;
+    ctx->prof_n[k] = 0;
+  }
+  return LSSPA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int lsspa_mfma_probe(lsspa_ctx* ctx, const double* A16x4, const double* B4x16, double* D16x16) {
+  if (!ctx || !A16x4 || !B4x16 || !D16x16) return LSSPA_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  DevBuf<double> buf;
+  TRY(dev_alloc(ctx, buf, 64 + 64 + 256));
+  hipError_t e = hipMemcpy(buf.ptr, A16x4, 64 * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(buf.ptr + 64, B4x16, 64 * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_mfma_probe(buf.ptr, buf.ptr + 64, buf.ptr + 128, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipMemcpy(D16x16, buf.ptr + 128, 256 * 8, hipMemcpyDeviceToHost);
+  dev_free(buf);
+  if (e != hipSuccess) return ctx->fail(LSSPA_ERR_HIP, "mfma probe", e);
+  return LSSPA_OK;
+}
+
+int lsspa_debug_factor(lsspa_ctx* ctx, const int32_t* perm, double* L, double* Lt, double* V, int32_t* p_pad,
+                       int32_t* m_pad, int32_t* v_rows) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t pp = ctx->p_pad, n_iblk = (ctx->p + NB - 1) / NB;
+  if (p_pad) *p_pad = ctx->p_pad;
+  if (m_pad) *m_pad = ctx->m_pad;
+  if (v_rows) *v_rows = (int32_t)(n_iblk * NB);
+  if (!perm) return LSSPA_OK;  // size query
+  std::vector<char> seen;
+  if (!is_permutation(perm, ctx->p, seen)) return ctx->fail(LSSPA_ERR_ARG, "perm is not a permutation");
+  TRY(factor_identity(ctx, perm));
+  if (L) HIPCHK(hipMemcpy(L, ctx->A.ptr, pp * pp * 8, hipMemcpyDeviceToHost));
+  if (Lt && ctx->tri) HIPCHK(hipMemcpy(Lt, ctx->A.ptr + pp * pp, pp * pp * 8, hipMemcpyDeviceToHost));
+  if (V) HIPCHK(hipMemcpy(V, ctx->V.ptr, n_iblk * NB * ctx->m_pad * 8, hipMemcpyDeviceToHost));
+  return LSSPA_OK;
+}
+
+}  // extern "C"

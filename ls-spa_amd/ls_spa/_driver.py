@@ -1,0 +1,258 @@
+"""The estimator driver: ``ls_spa(...)`` with the reference's signature and semantics,
+running every ordering on the HIP engine in batches.
+
+Reference: cvxgrp/ls-spa ``ls_spa/ls_spa.py:122-253``.  What is kept exactly:
+
+* the 12 positional parameters, their order and defaults (:122-133);
+* input coercion through ``np.array`` and ``validate_data`` (:158-162);
+* ordering source selection (:169-177): ``perms is None`` and p < 9 -> every ordering,
+  ``batch_size`` forced to 256, ``antithetical`` forced off; ``perms is None`` and p >= 9 ->
+  ``rng.permutation`` drawn lazily from the SAME generator the error estimator uses;
+  ``perms`` given -> consumed lazily, no sample cap;
+* the error-check trigger indices ``i % batch_size == 0 or i == max_samples - 1``, the
+  ``p >= 9`` guard, the tolerance break and the trailing estimate (:222-236).  Because the
+  generator is only touched by the sampler between two checks, drawing a whole chunk of
+  orderings up to the next check index and evaluating it as one GPU batch leaves the
+  generator's call sequence -- hence every later ordering -- unchanged;
+* results: running mean = attribution, biased covariance scaled as in :223-224.
+
+README-dialect keywords (README.md:96-106) are accepted on top: ``method``,
+``num_batches``, ``return_history``.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from . import _samplers as S
+from ._results import ShapleyResults, validate_data
+from ._stats import error_estimates, error_estimates_lowrank
+
+_NO_CAP = 2 ** 100
+
+
+def _next_check(i, batch_size, max_samples):
+    """Smallest index > i at which the reference evaluates the error estimate."""
+    nxt = (i // batch_size + 1) * batch_size
+    if i < max_samples - 1 < nxt:
+        nxt = max_samples - 1
+    return nxt
+
+
+class _Comm:
+    """Single-process communicator (world of one)."""
+    rank, world = 0, 1
+
+    def allreduce_pending(self, engine):
+        return None
+
+    def gather_lifts(self, local, counts):
+        return local
+
+
+def _min_norm_theta(G, g):
+    """theta of minimal norm for a numerically singular Gram matrix (the reference gets it
+    from lstsq on the triangular factor, ls_spa/ls_spa.py:240)."""
+    w, Q = np.linalg.eigh(G)
+    keep = w > w.max() * G.shape[0] * np.finfo(float).eps
+    coef = np.zeros_like(w)
+    coef[keep] = (Q.T @ g)[keep] / w[keep]
+    return Q @ coef
+
+
+def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms, antithetical,
+                  return_attribution_history, method, error_estimator, comm=None, chunk_cap=None):
+    """The sampling loop on an engine whose problem is already loaded.  Returns
+    (attribution, attribution_errors, overall_error, error_history, attribution_history, n)."""
+    comm = comm or _Comm()
+    rng = np.random.default_rng(seed)
+    never_stop = False
+    if perms is not None:
+        if method is not None:
+            raise ValueError("pass either perms= or method=, not both")
+        source, max_samples = S.IterableSource(perms, p), _NO_CAP
+    elif method is None:
+        if p < 9:
+            source, batch_size, antithetical = S.exact_source(p), 2 ** 8, False
+        else:
+            source = S.RandomSource(rng, p, max_samples)
+    elif method == "exact":
+        source, batch_size, antithetical, never_stop = S.exact_source(p), 2 ** 8, False, True
+        max_samples = _NO_CAP
+    elif method == "random":
+        source = S.RandomSource(rng, p, max_samples)
+    elif method == "argsort":
+        source = S.ArgsortSource(p, seed, max_samples)
+    elif method == "permutohedron":
+        source = S.PermutohedronSource(p, seed, max_samples)
+    else:
+        raise ValueError(f"method must be one of {S.METHODS} or None")
+    if batch_size < 1:
+        raise ValueError("batch_size must be positive")
+
+    estimate = p >= 9
+    keep_lifts = return_attribution_history or error_estimator == "lowrank"
+    engine.reset_stats()
+    feat_err, total_err = np.zeros(p), 0.0
+    err_hist, hist_parts, lift_parts = [], [], []
+    hist_sum = np.zeros(p)
+    i, pending, stop = 0, False, False
+    mean = np.zeros(p)
+    cov = None
+
+    def estimate_now(n):
+        nonlocal feat_err, total_err
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if error_estimator == "lowrank":
+                centred = np.concatenate(lift_parts) - mean
+                feat_err, total_err = error_estimates_lowrank(rng, centred, n)
+            else:
+                _, _, cov_b = engine.stats(want_cov=True)
+                feat_err, total_err = error_estimates(rng, cov_b * n / (n - 1) / n)
+        err_hist.append(total_err)
+
+    while not stop:
+        target = _next_check(i, batch_size, max_samples)
+        want = min(target, max_samples) - i
+        if chunk_cap:
+            want = min(want, chunk_cap)
+        chunk = source.take(want)
+        n_new = len(chunk)
+        if n_new == 0:
+            break
+        # deal the chunk round-robin over the ranks; every rank draws the same orderings
+        mine = chunk[comm.rank::comm.world]
+        local = None
+        if len(mine):
+            local = engine.run_batch(mine, antithetical, want_lifts=keep_lifts, accumulate=True)
+        comm.allreduce_pending(engine)
+        engine.merge()
+        if keep_lifts:
+            counts = [len(chunk[r::comm.world]) for r in range(comm.world)]
+            parts = comm.gather_lifts(local if local is not None else np.empty((0, p)), counts)
+            if comm.world > 1:
+                full = np.empty((n_new, p))
+                for r in range(comm.world):
+                    full[r::comm.world] = parts[r]
+            else:
+                full = parts
+            if return_attribution_history:
+                run = hist_sum + np.cumsum(full, axis=0)
+                hist_parts.append(run / np.arange(i + 1, i + n_new + 1)[:, None])
+                hist_sum = run[-1]
+            if error_estimator == "lowrank":
+                lift_parts.append(full)
+        i += n_new
+        pending = True
+        if n_new < want and not chunk_cap:
+            stop = True  # the source ran dry inside a chunk
+        if estimate and (i % batch_size == 0 or i == max_samples - 1):
+            _, mean, _ = engine.stats(want_cov=False)
+            estimate_now(i)
+            pending = False
+            if total_err < tolerance and not never_stop:
+                break
+        if i >= max_samples:
+            break
+
+    n, mean, _ = engine.stats(want_cov=False)
+    if estimate and pending and n > 0:
+        estimate_now(n)
+    history = None
+    if return_attribution_history:
+        history = np.concatenate(hist_parts) if hist_parts else np.zeros((0, p))
+    return mean, feat_err, total_err, np.array(err_hist), history, n
+
+
+def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_size=2 ** 8,
+           tolerance=1e-2, seed=42, perms=None, antithetical=True, return_attribution_history=False, *,
+           method=None, num_batches=None, return_history=None, device=0, error_estimator="reference",
+           _engine=None, _comm=None):
+    """Estimates the Shapley attribution of the out-of-sample R^2 of a least-squares fit.
+
+    Positional parameters, defaults and behaviour follow cvxgrp/ls-spa
+    (``ls_spa/ls_spa.py:122-253``).  Keyword-only additions:
+
+    method:  None (reference behaviour), 'exact', 'random', 'argsort' or 'permutohedron'.
+    num_batches:  if given, ``max_samples = batch_size * num_batches`` (README dialect).
+    return_history:  alias of ``return_attribution_history``.
+    device:  GPU index.
+    error_estimator:  'reference' (host, same generator call order as the reference) or
+        'lowrank' (same distribution, O(n p) instead of an O(p^3) factorisation).
+    """
+    X_train, X_test = np.array(X_train), np.array(X_test)
+    y_train, y_test = np.array(y_train), np.array(y_test)
+    validate_data(X_train, X_test, y_train, y_test)
+    if y_train.ndim != 1 or y_test.ndim != 1:
+        raise ValueError("y_train and y_test must be one-dimensional")  # reference: concatenate error, :312
+    p = X_train.shape[1]
+    if return_history is not None:
+        return_attribution_history = bool(return_history)
+    if num_batches is not None:
+        max_samples = int(batch_size) * int(num_batches)
+    if error_estimator not in ("reference", "lowrank"):
+        raise ValueError("error_estimator must be 'reference' or 'lowrank'")
+
+    engine = _engine
+    owns = engine is None
+    if owns:
+        from ._engine import HipEngine
+        engine = HipEngine(device)
+    try:
+        engine.load_data(X_train, X_test, y_train, y_test, reg)
+        attribution, feat_err, total_err, err_hist, history, _ = run_estimator(
+            engine, p, max_samples=max_samples, batch_size=batch_size, tolerance=tolerance, seed=seed,
+            perms=perms, antithetical=antithetical, return_attribution_history=return_attribution_history,
+            method=method, error_estimator=error_estimator, comm=_comm)
+        theta, r_squared, info = engine.full_fit()
+        if info or engine.info():
+            warnings.warn("a permuted Gram matrix was not numerically positive definite; the attribution "
+                          "of collinear features is not meaningful (the reference's is not either)",
+                          RuntimeWarning, stacklevel=2)
+        if info:
+            G, g, _, _ = engine.gram()
+            theta = _min_norm_theta(G, g)
+            yy = engine.y_norm_sq
+            pred = X_test.astype(np.float64) @ theta
+            r_squared = float((2.0 * (pred @ y_test) - pred @ pred) / yy)
+    finally:
+        if owns:
+            engine.close()
+    return ShapleyResults(attribution=attribution, theta=theta, overall_error=total_err,
+                          attribution_errors=feat_err, r_squared=r_squared, error_history=err_hist,
+                          attribution_history=history)
+
+
+# ------------------------------------------------------------------------------------------
+# helper-level surface of the reference (called by its notebooks and tests)
+# ------------------------------------------------------------------------------------------
+_helper_engine = None
+
+
+def _helper():
+    global _helper_engine
+    if _helper_engine is None:
+        from ._engine import HipEngine
+        _helper_engine = HipEngine(0)
+    return _helper_engine
+
+
+def reduce_data(X_train, X_test, y_train, y_test, reg):
+    """(R_tr, F_te, q_tr, q_te) with R_tr^T R_tr = X_tr^T X_tr / N + reg I, R_tr^T q_tr = X_tr^T y_tr / N,
+    F_te^T F_te = X_te^T X_te, F_te^T q_te = X_te^T y_te -- the contract of the reference's
+    ``reduce_data`` (ls_spa/ls_spa.py:290-318).  Here R_tr is the Cholesky factor of the MFMA Gram
+    matrix (positive diagonal), so it equals LAPACK's QR factor up to row signs."""
+    eng = _helper()
+    eng.load_data(np.array(X_train), np.array(X_test), np.array(y_train), np.array(y_test), reg)
+    return eng.factors()
+
+
+def square_shapley(X_train, X_test, y_train, y_test, y_norm_sq, perm):
+    """Lift vector of one ordering from reduced factors (ls_spa/ls_spa.py:256-287): arguments are
+    the four outputs of ``reduce_data``, ||y_test||^2 of the raw labels and the ordering."""
+    R, F = np.asarray(X_train, dtype=np.float64), np.asarray(X_test, dtype=np.float64)
+    q, qt = np.asarray(y_train, dtype=np.float64), np.asarray(y_test, dtype=np.float64)
+    eng = _helper()
+    eng.load_reduced(R.T @ R, R.T @ q, float(q @ q), float(y_norm_sq), Ft=F.T.copy(), ytil=qt)
+    return eng.run_batch(np.asarray(perm)[None, :], False, want_lifts=True, accumulate=False)[0]

@@ -1,0 +1,216 @@
+"""Device engine: a thin object wrapper over the C ABI (one context = one GPU).
+
+The driver (``_driver.py``) only talks to this interface:
+
+    load_data / load_reduced      one-time reduction (a1)
+    full_fit                      theta, r_squared (a7)
+    run_batch                     lift vectors of a batch of orderings (a2, a3) and the
+                                  batch's moments about the running mean (a4)
+    pending_buffer / merge        the all-reduce target and the Chan merge (a4, multi-GPU)
+    stats                         n, mean, biased covariance
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class DeviceArrayView:
+    """Zero-copy view of a device buffer for consumers of ``__cuda_array_interface__``
+    (torch.as_tensor on ROCm included): used to hand the pending-statistics buffer to
+    torch.distributed without going through the host."""
+
+    def __init__(self, ptr: int, count: int, owner):
+        self._owner = owner  # keeps the context alive
+        self.__cuda_array_interface__ = {
+            "shape": (int(count),),
+            "typestr": "<f8",
+            "data": (int(ptr), False),
+            "version": 2,
+            "strides": None,
+        }
+
+
+class HipEngine:
+    """One MI355X.  Raises LSSPANativeError when the HIP library or the GPU is missing."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._lib = N.load()
+        h = C.c_void_p()
+        rc = self._lib.lsspa_create(int(device), C.byref(h))
+        if rc != N.OK:
+            msg = self._lib.lsspa_last_error(None)
+            raise N.LSSPANativeError(f"lsspa_create(device={device}) failed: {msg.decode() if msg else rc}")
+        self._h = h
+        self.device = int(device)
+        self.p = 0
+        self.m = 0
+        self.tri = False
+        self.y_norm_sq = float("nan")
+        if stream is not None:
+            self._check(self._lib.lsspa_set_stream(self._h, C.c_void_p(int(stream))))
+
+    # ---- plumbing -------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != N.OK:
+            msg = self._lib.lsspa_last_error(self._h)
+            text = msg.decode() if msg else ""
+            if rc == 1:
+                raise ValueError(f"lsspa: {text}")
+            if rc == 4:
+                raise MemoryError(f"lsspa: {text}")
+            raise N.LSSPANativeError(f"lsspa call failed (status {rc}): {text}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lsspa_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(self._lib.lsspa_synchronize(self._h))
+
+    def _refresh_dims(self):
+        p, m, tri, yy = C.c_int32(), C.c_int32(), C.c_int32(), C.c_double()
+        self._check(self._lib.lsspa_get_problem(self._h, C.byref(p), C.byref(m), C.byref(tri), C.byref(yy)))
+        self.p, self.m, self.tri, self.y_norm_sq = p.value, m.value, bool(tri.value), yy.value
+
+    # ---- a1: reduction ---------------------------------------------------------------
+    def load_data(self, X_train, X_test, y_train, y_test, reg: float):
+        """Host ndarrays (float64 or float32, both sides alike) -> device Gram reduction."""
+        dt = np.float32 if (X_train.dtype == np.float32 and X_test.dtype == np.float32) else np.float64
+        Xa = np.ascontiguousarray(X_train, dtype=dt)
+        Xe = np.ascontiguousarray(X_test, dtype=dt)
+        ya = np.ascontiguousarray(y_train, dtype=dt)
+        ye = np.ascontiguousarray(y_test, dtype=dt)
+        n, p = Xa.shape
+        mrows = Xe.shape[0]
+        self._check(self._lib.lsspa_reduce(
+            self._h, Xa.ctypes.data, p, ya.ctypes.data, n, Xe.ctypes.data, p, ye.ctypes.data, mrows, p,
+            float(reg), N.F32 if dt == np.float32 else N.F64, N.HOST))
+        self._refresh_dims()
+
+    def load_device_data(self, X_train_ptr, ld_train, y_train_ptr, n, X_test_ptr, ld_test, y_test_ptr, m_rows,
+                         p, reg, f32=False):
+        """Same, from device pointers (e.g. torch tensors' data_ptr())."""
+        self._check(self._lib.lsspa_reduce(
+            self._h, C.c_void_p(X_train_ptr), ld_train, C.c_void_p(y_train_ptr), n, C.c_void_p(X_test_ptr),
+            ld_test, C.c_void_p(y_test_ptr), m_rows, p, float(reg), N.F32 if f32 else N.F64, N.DEVICE))
+        self._refresh_dims()
+
+    def load_reduced(self, G, g, aug_train, y_norm_sq, H=None, h=None, Ft=None, ytil=None):
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        p = G.shape[0]
+        if H is not None:
+            H = np.ascontiguousarray(H, dtype=np.float64)
+            h = np.ascontiguousarray(h, dtype=np.float64)
+            self._check(self._lib.lsspa_set_reduced(self._h, p, N.dptr(G), N.dptr(g), float(aug_train), 1,
+                                                    N.dptr(H), N.dptr(h), p, None, None, float(y_norm_sq)))
+        else:
+            Ft = np.ascontiguousarray(Ft, dtype=np.float64)
+            ytil = np.ascontiguousarray(ytil, dtype=np.float64)
+            self._check(self._lib.lsspa_set_reduced(self._h, p, N.dptr(G), N.dptr(g), float(aug_train), 0,
+                                                    None, None, Ft.shape[1], N.dptr(Ft), N.dptr(ytil),
+                                                    float(y_norm_sq)))
+        self._refresh_dims()
+
+    def gram(self):
+        p = self.p
+        G, g = np.empty((p, p)), np.empty(p)
+        if self.tri:
+            H, h = np.empty((p, p)), np.empty(p)
+            self._check(self._lib.lsspa_get_gram(self._h, N.dptr(G), N.dptr(g), N.dptr(H), N.dptr(h)))
+            return G, g, H, h
+        self._check(self._lib.lsspa_get_gram(self._h, N.dptr(G), N.dptr(g), None, None))
+        return G, g, None, None
+
+    # ---- a7 ----------------------------------------------------------------------------
+    def full_fit(self):
+        theta = np.empty(self.p)
+        r2, info = C.c_double(), C.c_int32()
+        self._check(self._lib.lsspa_full_fit(self._h, N.dptr(theta), C.byref(r2), C.byref(info)))
+        return theta, r2.value, info.value
+
+    def factors(self):
+        p, m = self.p, self.m
+        R, q = np.empty((p, p)), np.empty(p)
+        F, qt = np.empty((m, p)), np.empty(m)
+        self._check(self._lib.lsspa_get_factors(self._h, N.dptr(R), N.dptr(q), N.dptr(F), N.dptr(qt)))
+        return R, F, q, qt
+
+    # ---- a2 / a3 / a4 ------------------------------------------------------------------
+    def run_batch(self, perms, antithetical: bool, want_lifts: bool = False, accumulate: bool = True):
+        perms = np.ascontiguousarray(perms, dtype=np.int32)
+        if perms.ndim != 2 or perms.shape[1] != self.p:
+            raise ValueError(f"perms must have shape (B, {self.p})")
+        B = perms.shape[0]
+        out = np.empty((B, self.p)) if want_lifts else None
+        self._check(self._lib.lsspa_lift_batch(self._h, N.iptr(perms), B, int(bool(antithetical)),
+                                               N.dptr(out), int(bool(accumulate))))
+        return out
+
+    def info(self) -> int:
+        v = C.c_int32()
+        self._check(self._lib.lsspa_get_info(self._h, C.byref(v)))
+        return v.value
+
+    def reset_stats(self):
+        self._check(self._lib.lsspa_stats_reset(self._h))
+
+    def pending_buffer(self) -> DeviceArrayView:
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        self._check(self._lib.lsspa_stats_pending(self._h, C.byref(ptr), C.byref(cnt)))
+        return DeviceArrayView(ptr.value, cnt.value, self)
+
+    def merge(self):
+        self._check(self._lib.lsspa_stats_merge(self._h))
+
+    def stats(self, want_cov: bool = True):
+        n = C.c_int64()
+        mean = np.empty(self.p)
+        cov = np.empty((self.p, self.p)) if want_cov else None
+        self._check(self._lib.lsspa_stats_get(self._h, C.byref(n), N.dptr(mean), N.dptr(cov)))
+        return n.value, mean, cov
+
+    # ---- profiling / test hooks ---------------------------------------------------------
+    def profile(self, on: bool):
+        self._check(self._lib.lsspa_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._check(self._lib.lsspa_profile_reset(self._h))
+
+    def profile_read(self):
+        out = {}
+        for k, name in enumerate(N.KERNEL_CLASSES):
+            ms, cnt = C.c_double(), C.c_int64()
+            self._check(self._lib.lsspa_profile_get(self._h, k, C.byref(ms), C.byref(cnt)))
+            out[name] = (ms.value, cnt.value)
+        return out
+
+    def mfma_probe(self, A, B):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        D = np.empty((16, 16))
+        self._check(self._lib.lsspa_mfma_probe(self._h, N.dptr(A), N.dptr(B), N.dptr(D)))
+        return D
+
+    def debug_factor(self, perm):
+        pp, mp, vr = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._lib.lsspa_debug_factor(self._h, None, None, None, None, C.byref(pp), C.byref(mp),
+                                                 C.byref(vr)))
+        perm = np.ascontiguousarray(perm, dtype=np.int32)
+        L = np.empty((pp.value, pp.value))
+        Lt = np.empty((pp.value, pp.value)) if self.tri else None
+        V = np.empty((vr.value, mp.value))
+        self._check(self._lib.lsspa_debug_factor(self._h, N.iptr(perm), N.dptr(L), N.dptr(Lt), N.dptr(V),
+                                                 C.byref(pp), C.byref(mp), C.byref(vr)))
+        return L, Lt, V

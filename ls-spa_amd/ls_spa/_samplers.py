@@ -1,0 +1,106 @@
+"""Ordering sources.
+
+'exact' and 'random' are the two sources built into the reference driver
+(cvxgrp/ls-spa ``ls_spa/ls_spa.py:170-175``); 'argsort' and 'permutohedron' are the
+quasi-Monte-Carlo samplers of ``experiments/ground_truth_medium.py:56-71``, which the
+reference README names as ``method=`` values.  They stay on the host (SciPy QMC
+streams are part of the observable behaviour) and yield int orderings in chunks.
+"""
+from __future__ import annotations
+
+import itertools
+import warnings
+
+import numpy as np
+
+METHODS = ("exact", "random", "argsort", "permutohedron")
+
+
+def helmert_rows(p):
+    """(p-1) x p row-orthonormal basis of {x : sum x = 0}: row k = (1,..,1,-(k+1),0,..)/norm."""
+    U = np.tril(np.ones((p - 1, p)))
+    k = np.arange(p - 1)
+    U[k, k + 1] = -(k + 1.0)
+    return U / np.linalg.norm(U, axis=1, keepdims=True)
+
+
+class OrderingSource:
+    """Hands out up to ``count`` orderings at a time as an (n, p) integer array;
+    an empty array means exhausted."""
+
+    def take(self, count):  # pragma: no cover - interface
+        raise NotImplementedError
+
+
+class IterableSource(OrderingSource):
+    """Any iterable of length-p index sequences (generator, list, ndarray rows, an object
+    with ``__iter__`` such as a progress bar).  Pulled lazily, never exhausted eagerly."""
+
+    def __init__(self, iterable, p):
+        self._it = iter(iterable)
+        self._p = p
+
+    def take(self, count):
+        rows = list(itertools.islice(self._it, count))
+        if not rows:
+            return np.empty((0, self._p), dtype=np.int64)
+        out = np.asarray([np.asarray(r) for r in rows])
+        if out.ndim != 2 or out.shape[1] != self._p:
+            raise ValueError(f"every ordering must have length p = {self._p}")
+        return out
+
+
+class RandomSource(OrderingSource):
+    """rng.permutation(p), one call per ordering, drawn only when asked for -- the shared
+    generator is also consumed by the error estimator between batches."""
+
+    def __init__(self, rng, p, limit):
+        self._rng, self._p, self._left = rng, p, limit
+
+    def take(self, count):
+        n = int(min(count, self._left))
+        self._left -= n
+        if n <= 0:
+            return np.empty((0, self._p), dtype=np.int64)
+        return np.stack([self._rng.permutation(self._p) for _ in range(n)])
+
+
+class ArgsortSource(OrderingSource):
+    def __init__(self, p, seed, limit):
+        from scipy.stats.qmc import Sobol
+        self._qmc, self._p, self._left = Sobol(p, seed=seed), p, limit
+
+    def _points(self, n):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # Sobol balance warning for n not a power of two
+            return self._qmc.random(n)
+
+    def take(self, count):
+        n = int(min(count, self._left))
+        self._left -= n
+        if n <= 0:
+            return np.empty((0, self._p), dtype=np.int64)
+        return np.argsort(self._points(n), axis=1)
+
+
+class PermutohedronSource(ArgsortSource):
+    def __init__(self, p, seed, limit):
+        from scipy.stats.qmc import MultivariateNormalQMC
+        if p < 2:
+            raise ValueError("permutohedron sampling needs p >= 2")
+        self._qmc = MultivariateNormalQMC(np.zeros(p - 1), seed=seed, inv_transform=False)
+        self._p, self._left = p, limit
+        self._basis = helmert_rows(p)
+
+    def take(self, count):
+        n = int(min(count, self._left))
+        self._left -= n
+        if n <= 0:
+            return np.empty((0, self._p), dtype=np.int64)
+        pts = self._points(n)
+        pts = pts / np.linalg.norm(pts, axis=1, keepdims=True)
+        return np.argsort(pts @ self._basis, axis=1)
+
+
+def exact_source(p):
+    return IterableSource(itertools.permutations(range(p)), p)

@@ -1,0 +1,40 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for sub in ("ls-spa_amd", "oracle"):
+    path = os.path.join(ROOT, sub)
+    if path not in sys.path:
+        sys.path.insert(0, path)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return load
+
+
+def _gpu_available():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """One HIP engine for the whole GPU test session (fails loudly if it cannot be made)."""
+    from ls_spa._engine import HipEngine
+    eng = HipEngine(0)
+    yield eng
+    eng.close()

@@ -1,0 +1,96 @@
+"""GPU parity tests of the individual HIP kernels, through the C ABI (-m gpu)."""
+import numpy as np
+import pytest
+
+import lsspa_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def problem(seed, p, n, m):
+    rng = np.random.default_rng(seed)
+    Xa = rng.standard_normal((n, p))
+    Xe = rng.standard_normal((m, p))
+    w = rng.standard_normal(p)
+    return Xa, Xe, Xa @ w + rng.standard_normal(n), Xe @ w + rng.standard_normal(m)
+
+
+def test_mfma_f64_lane_maps(engine):
+    """Pins the operand / result lane maps of v_mfma_f64_16x16x4_f64 with asymmetric data."""
+    rng = np.random.default_rng(1)
+    A = rng.integers(-8, 9, (16, 4)).astype(np.float64)
+    B = rng.integers(-8, 9, (4, 16)).astype(np.float64)
+    D = engine.mfma_probe(A, B)
+    np.testing.assert_array_equal(D, A @ B)
+
+
+@pytest.mark.parametrize("p,n,m", [(12, 60, 50), (100, 400, 300), (200, 500, 260), (70, 300, 40)])
+def test_gram_reduction(engine, p, n, m):
+    Xa, Xe, ya, ye = problem(3, p, n, m)
+    engine.load_data(Xa, Xe, ya, ye, 0.25)
+    G, g, H, h = engine.gram()
+    np.testing.assert_allclose(G, Xa.T @ Xa / n + 0.25 * np.eye(p), rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(g, Xa.T @ ya / n, rtol=1e-13, atol=1e-13)
+    assert engine.tri == (m >= p)
+    if m >= p:
+        np.testing.assert_allclose(H, Xe.T @ Xe, rtol=1e-13, atol=1e-12)
+        np.testing.assert_allclose(h, Xe.T @ ye, rtol=1e-13, atol=1e-12)
+    assert abs(engine.y_norm_sq - ye @ ye) <= 1e-12 * (ye @ ye)
+
+
+@pytest.mark.parametrize("p,n,m", [(12, 60, 50), (100, 400, 300), (200, 500, 260)])
+def test_cholesky_factor(engine, p, n, m):
+    Xa, Xe, ya, ye = problem(4, p, n, m)
+    engine.load_data(Xa, Xe, ya, ye, 0.0)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(p)
+    L, Lt, V = engine.debug_factor(perm)
+    G = (Xa.T @ Xa / n)[np.ix_(perm, perm)]
+    g = (Xa.T @ ya / n)[perm]
+    Lref = np.linalg.cholesky(G)
+    np.testing.assert_allclose(np.tril(L[:p, :p]), Lref, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(L[p, :p], np.linalg.solve(Lref, g), rtol=1e-10, atol=1e-12)
+    H = (Xe.T @ Xe)[np.ix_(perm, perm)]
+    Ltref = np.linalg.cholesky(H)
+    np.testing.assert_allclose(np.tril(Lt[:p, :p]), Ltref, rtol=1e-11, atol=1e-11)
+    Vref = np.linalg.solve(Lref, Ltref)
+    np.testing.assert_allclose(V[:p, :p], Vref, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("p,n,m,anti", [(12, 60, 50, False), (12, 60, 50, True), (100, 400, 300, True),
+                                        (200, 500, 260, True), (70, 300, 40, True), (130, 300, 131, False)])
+def test_lift_batch_vs_oracle(engine, p, n, m, anti):
+    Xa, Xe, ya, ye = problem(5, p, n, m)
+    engine.load_data(Xa, Xe, ya, ye, 0.0)
+    red = O.reduce(Xa, Xe, ya, ye, 0.0)
+    yy = float(ye @ ye)
+    rng = np.random.default_rng(2)
+    perms = np.array([rng.permutation(p) for _ in range(9)])
+    got = engine.run_batch(perms, anti, want_lifts=True, accumulate=False)
+    want = np.array([O.sample_lift(*red, yy, o, anti) for o in perms])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-11)
+
+
+def test_full_fit_and_stats(engine):
+    p, n, m = 100, 400, 300
+    Xa, Xe, ya, ye = problem(6, p, n, m)
+    engine.load_data(Xa, Xe, ya, ye, 0.1)
+    theta, r2, info = engine.full_fit()
+    assert info == 0
+    G = Xa.T @ Xa / n + 0.1 * np.eye(p)
+    th = np.linalg.solve(G, Xa.T @ ya / n)
+    np.testing.assert_allclose(theta, th, rtol=1e-10, atol=1e-12)
+    r2_ref = 1 - np.sum((ye - Xe @ th) ** 2) / (ye @ ye)
+    assert abs(r2 - r2_ref) < 1e-11
+    rng = np.random.default_rng(3)
+    engine.reset_stats()
+    all_l = []
+    for b in range(3):
+        perms = np.array([rng.permutation(p) for _ in range(7 + b)])
+        all_l.append(engine.run_batch(perms, True, want_lifts=True, accumulate=True))
+        engine.merge()
+    all_l = np.concatenate(all_l)
+    cnt, mean, cov = engine.stats()
+    assert cnt == len(all_l)
+    np.testing.assert_allclose(mean, all_l.mean(0), rtol=0, atol=1e-14)
+    np.testing.assert_allclose(cov, np.cov(all_l, rowvar=False, bias=True), rtol=0, atol=1e-15)
