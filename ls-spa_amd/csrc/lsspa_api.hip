@@ -227,6 +227,7 @@ size_t bytes_per_ordering(const lsspa_ctx* ctx) {
 }
 
 int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
+  want_ord = (want_ord + 1) & ~1;  // antithetical pairs stay together
   if (want_ord > ctx->cap_ord) {
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));

@@ -1,0 +1,58 @@
+"""Multi-GPU sharding: one process per GPU, torch.distributed as the transport.
+
+Orderings are independent given the (replicated) reduced problem, so each global chunk of
+orderings is dealt round-robin over the ranks and the only data-path collective is ONE
+all-reduce (SUM, fp64) per chunk of the packed pending statistics
+[n_b, sum(l - mu), sum (l - mu)(l - mu)^T] -- the multi-device form of the reference's
+merge_sample_mean / merge_sample_cov (cvxgrp/ls-spa ls_spa/ls_spa.py:103-119, :212-216).
+With backend "nccl" (= RCCL on ROCm) the buffer is reduced in place in HBM over xGMI;
+with "gloo" (CPU tests) it is a host tensor.  After the collective every rank holds the
+same moments, merges them identically and therefore takes the same stop decision.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class TorchComm:
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self._torch, self._dist, self._group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self._on_gpu = dist.get_backend(group) == "nccl"
+
+    def _as_tensor(self, buf):
+        torch = self._torch
+        if isinstance(buf, np.ndarray):
+            return torch.from_numpy(buf)            # shares memory with the test double's buffer
+        return torch.as_tensor(buf, device="cuda")  # zero-copy view through __cuda_array_interface__
+
+    def allreduce_pending(self, engine):
+        if self.world == 1:
+            return
+        t = self._as_tensor(engine.pending_buffer())
+        if self._on_gpu:
+            engine.synchronize()                    # engine stream -> torch stream hand-off
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
+        if self._on_gpu:
+            self._torch.cuda.current_stream().synchronize()
+
+    def gather_lifts(self, local, counts):
+        """All ranks' per-sample lift vectors (only needed for attribution_history /
+        the low-rank error estimator)."""
+        if self.world == 1:
+            return local
+        torch = self._torch
+        p = local.shape[1]
+        dev = "cuda" if self._on_gpu else "cpu"
+        width = max(counts)
+        mine = torch.zeros((width, p), dtype=torch.float64, device=dev)
+        if len(local):
+            mine[: len(local)] = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self._dist.all_gather(parts, mine, group=self._group)
+        return [parts[r][: counts[r]].cpu().numpy() for r in range(self.world)]

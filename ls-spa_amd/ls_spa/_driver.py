@@ -74,7 +74,9 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
         source, max_samples = S.IterableSource(perms, p), _NO_CAP
     elif method is None:
         if p < 9:
-            source, batch_size, antithetical = S.exact_source(p), 2 ** 8, False
+            # the reference's loop runs over all p! orderings here; max_samples only ever enters
+            # the (p >= 9)-guarded error check (:222), so it does not cap this case
+            source, batch_size, antithetical, max_samples = S.exact_source(p), 2 ** 8, False, _NO_CAP
         else:
             source = S.RandomSource(rng, p, max_samples)
     elif method == "exact":

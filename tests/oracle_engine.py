@@ -1,0 +1,71 @@
+"""Test double with the HipEngine interface, backed by the CPU oracle.
+
+Lets the host logic (driver loop, trigger indices, generator interleave, multi-rank
+sharding) be tested without a GPU.  TESTS ONLY -- the product never imports this."""
+import numpy as np
+
+import lsspa_oracle as O
+
+
+class OracleEngine:
+    def __init__(self):
+        self.p = 0
+        self.calls = []
+
+    def load_data(self, Xa, Xe, ya, ye, reg):
+        Xa, Xe, ya, ye = (np.asarray(a, dtype=np.float64) for a in (Xa, Xe, ya, ye))
+        self._data = (Xa, Xe, ya, ye, reg)
+        self._red = O.reduce(Xa, Xe, ya, ye, reg)
+        self.p = Xa.shape[1]
+        self.m = self._red[1].shape[0]
+        self.tri = Xe.shape[0] >= self.p
+        self.y_norm_sq = float(np.linalg.norm(ye) ** 2)
+        self.reset_stats()
+
+    def reset_stats(self):
+        p = self.p
+        self._n, self._mean, self._M2 = 0, np.zeros(p), np.zeros((p, p))
+        self._pend = np.zeros(1 + p + p * p)
+
+    def run_batch(self, perms, antithetical, want_lifts=False, accumulate=True):
+        perms = np.asarray(perms)
+        self.calls.append(len(perms))
+        lifts = np.array([O.sample_lift(*self._red, self.y_norm_sq, o, antithetical) for o in perms])
+        if accumulate:
+            p = self.p
+            D = lifts - self._mean
+            self._pend[0] += len(D)
+            self._pend[1:1 + p] += D.sum(0)
+            self._pend[1 + p:] += (D.T @ D).ravel()
+        return lifts if want_lifts else None
+
+    def pending_buffer(self):
+        return self._pend
+
+    def merge(self):
+        p = self.p
+        nb = self._pend[0]
+        if nb > 0:
+            delta = self._pend[1:1 + p] / nb
+            Q = self._pend[1 + p:].reshape(p, p)
+            n = self._n
+            self._M2 += Q + (n * nb / (n + nb) - nb) * np.outer(delta, delta)
+            self._mean = self._mean + self._pend[1:1 + p] / (n + nb)
+            self._n = int(round(n + nb))
+        self._pend[:] = 0
+
+    def stats(self, want_cov=True):
+        cov = self._M2 / self._n if (want_cov and self._n) else (self._M2.copy() if want_cov else None)
+        return self._n, self._mean.copy(), cov
+
+    def full_fit(self):
+        R, F, q, qt = self._red
+        theta = np.linalg.lstsq(R, q, rcond=None)[0]
+        r2 = (np.linalg.norm(qt) ** 2 - np.linalg.norm(qt - F @ theta) ** 2) / self.y_norm_sq
+        return theta, float(r2), 0
+
+    def info(self):
+        return 0
+
+    def close(self):
+        pass

@@ -1,0 +1,254 @@
+"""Parity tests proper (-m gpu): the product path -- ls_spa.ls_spa() -> ctypes -> C ABI -> HIP kernels --
+against (i) golden fixtures produced by the real reference, (ii) the CPU oracle on the same seeded
+inputs, (iii) the reference's own unit tests re-expressed, (iv) size-independent properties at the
+BASELINE sizes.
+
+Stated fp64 tolerance: |lift_gpu - lift_ref| <= 1e-10 per ordering on benchmark-conditioned data
+(observed ~1e-15); theta to 1e-9 relative; the error-estimator outputs are statistical pins (the
+sample covariance is singular by construction, see test_oracle_golden.py).
+"""
+import numpy as np
+import pytest
+
+import lsspa_oracle as O
+from ls_spa import (ShapleyResults, ls_spa, reduce_data, square_shapley)
+
+pytestmark = pytest.mark.gpu
+LIFT_TOL = dict(rtol=0, atol=1e-10)
+
+
+def data_of(g):
+    return [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+
+
+# ------------------------------------------------------------------ golden fixtures (reference outputs)
+def test_toy_exact(golden):
+    g = golden("toy")
+    res = ls_spa(*data_of(g))
+    np.testing.assert_allclose(res.attribution, g["attribution"], **LIFT_TOL)
+    np.testing.assert_allclose(res.theta, g["theta"], rtol=1e-10)
+    assert abs(res.r_squared - float(g["r_squared"])) < 1e-12
+    assert res.overall_error == 0.0 and res.error_history.size == 0 and res.attribution_history is None
+    assert repr(res) == str(g["repr"])
+
+
+@pytest.mark.parametrize("p", [4, 8])
+def test_exact_small_p(golden, p):
+    g = golden(f"exact_p{p}")
+    res = ls_spa(*data_of(g))
+    np.testing.assert_allclose(res.attribution, g["attribution"], **LIFT_TOL)
+    np.testing.assert_allclose(res.theta, g["theta"], rtol=1e-10)
+    res2 = ls_spa(*data_of(g), method="exact")
+    np.testing.assert_allclose(res2.attribution, g["attribution"], **LIFT_TOL)
+
+
+@pytest.mark.parametrize("tag,reg", [("r0", 0.0), ("r1", 0.1)])
+def test_helpers_reduce_and_square_shapley(golden, tag, reg):
+    g = golden("p12")
+    d = data_of(g)
+    R, F, q, qt = reduce_data(*d, reg)
+    Rg, Fg = g[f"{tag}_R_tr"], g[f"{tag}_F_te"]
+    np.testing.assert_allclose(R.T @ R, Rg.T @ Rg, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(np.abs(R), np.abs(Rg), rtol=0, atol=1e-11)     # equal up to row signs
+    np.testing.assert_allclose(R.T @ q, Rg.T @ g[f"{tag}_q_tr"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(F.T @ F, Fg.T @ Fg, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(F.T @ qt, Fg.T @ g[f"{tag}_q_te"], rtol=0, atol=1e-10)
+    yy = np.linalg.norm(d[3]) ** 2
+    for o, want in zip(g["orders"], g[f"{tag}_lifts"]):
+        # the helper takes ANY valid factors: ours and the reference's (LAPACK signs) alike
+        np.testing.assert_allclose(square_shapley(R, F, q, qt, yy, o), want, **LIFT_TOL)
+        np.testing.assert_allclose(square_shapley(Rg, Fg, g[f"{tag}_q_tr"], g[f"{tag}_q_te"], yy, o), want,
+                                   **LIFT_TOL)
+
+
+@pytest.mark.parametrize("anti", [True, False])
+def test_driver_injected_perms(golden, anti):
+    g = golden("p12")
+    pre = f"drv_anti{int(anti)}_"
+    res = ls_spa(*data_of(g), perms=g["perms64"], batch_size=16, tolerance=0.0, antithetical=anti,
+                 return_attribution_history=True)
+    np.testing.assert_allclose(res.attribution, g[pre + "attribution"], **LIFT_TOL)
+    np.testing.assert_allclose(res.attribution_history, g[pre + "attribution_history"], **LIFT_TOL)
+    np.testing.assert_allclose(res.theta, g[pre + "theta"], rtol=1e-10)
+    assert abs(res.r_squared - float(g[pre + "r_squared"])) < 1e-12
+    assert len(res.error_history) == 4
+    np.testing.assert_allclose(res.error_history, g[pre + "error_history"], rtol=0.15)
+    np.testing.assert_allclose(res.attribution_errors, g[pre + "attribution_errors"], rtol=0.25)
+
+
+def test_seed_path_first_batch(golden):
+    g = golden("p12")
+    res = ls_spa(*data_of(g), max_samples=40, batch_size=16, tolerance=0.0, seed=3,
+                 return_attribution_history=True)
+    np.testing.assert_allclose(res.attribution_history[:16], g["seedpath_attribution_history"][:16], **LIFT_TOL)
+    assert len(res.error_history) == 4 and res.attribution_history.shape == (40, 12)
+
+
+def test_correlated_generator_ill_conditioned(golden, engine):
+    """The reference's own hard generator (cond ~ 1e3): pins the Gram/Cholesky route's accuracy."""
+    g = golden("corr_p100")
+    R, F, q, qt = g["R_tr"], g["F_te"], g["q_tr"], g["q_te"]
+    yy = float(g["y_norm_sq"])
+    # both device paths: rect (any factor) and tri (test Gram)
+    engine.load_reduced(R.T @ R, R.T @ q, float(q @ q), yy, Ft=F.T.copy(), ytil=qt)
+    rect = engine.run_batch(g["orders"], False, want_lifts=True, accumulate=False)
+    engine.load_reduced(R.T @ R, R.T @ q, float(q @ q), yy, H=F.T @ F, h=F.T @ qt)
+    tri = engine.run_batch(g["orders"], False, want_lifts=True, accumulate=False)
+    np.testing.assert_allclose(rect, g["lifts"], **LIFT_TOL)
+    np.testing.assert_allclose(tri, g["lifts"], **LIFT_TOL)
+    assert engine.info() == 0
+
+
+def test_m_less_than_p_and_float32(golden):
+    g = golden("edge")
+    res = ls_spa(*data_of(g), perms=g["perms"], batch_size=8, tolerance=0.0)
+    np.testing.assert_allclose(res.attribution, g["mltp_attribution"], **LIFT_TOL)
+    np.testing.assert_allclose(res.theta, g["mltp_theta"], rtol=1e-10)
+    d32 = [a.astype(np.float32) for a in data_of(golden("p12"))]
+    res = ls_spa(*d32, perms=g["perms"], batch_size=8, tolerance=0.0)
+    assert res.attribution.dtype == np.float64
+    np.testing.assert_allclose(res.attribution, g["f32_attribution"], rtol=0, atol=2e-5)
+
+
+# ------------------------------------------------------------------ reference unit tests, re-expressed
+@pytest.fixture(scope="module")
+def ref_data():
+    """setUp of the reference's TestLSSPA (test/test_ls_spa.py:48-72)."""
+    rng = np.random.default_rng(128)
+    n = 100
+    A = rng.standard_normal((n, n))
+    Qm, _ = np.linalg.qr(A)
+    easy_X = Qm @ np.sqrt(np.diag(np.arange(1, n + 1)))
+    easy_y = Qm[:, 0]
+    w = rng.standard_normal(n)
+    Xa = rng.multivariate_normal(np.zeros(n), A @ A.T, n)
+    Xa_c = Xa - Xa.mean(0, keepdims=True)
+    Xe = rng.multivariate_normal(np.zeros(n), A @ A.T, n)
+    Xe_c = Xe - Xa.mean(0, keepdims=True)
+    ya = Xa_c @ w + rng.standard_normal(n)
+    ya_c = ya - ya.mean()
+    ye = Xe_c @ w + rng.standard_normal(n)
+    ye_c = ye - ye.mean()
+    return dict(easy=(easy_X, easy_X.copy(), easy_y, easy_y.copy()), hard=(Xa_c, Xe_c, ya_c, ye_c))
+
+
+def test_ref_return_type(ref_data):                                   # test_ls_spa.py:75-79
+    assert isinstance(ls_spa(*ref_data["easy"]), ShapleyResults)
+
+
+def test_ref_linear_regression(ref_data):                            # :82-96
+    Xa, Xe, ya, ye = ref_data["easy"]
+    th = np.linalg.lstsq(Xa, ya, rcond=None)[0]
+    np.testing.assert_almost_equal(th, ls_spa(Xa, Xe, ya, ye, max_samples=4, batch_size=2).theta)
+    Xa, Xe, ya, ye = ref_data["hard"]                                 # N = p, centred: rank p - 1
+    th = np.linalg.lstsq(Xa, ya, rcond=None)[0]
+    with pytest.warns(RuntimeWarning):
+        got = ls_spa(Xa, Xe, ya, ye, max_samples=4, batch_size=2).theta
+    np.testing.assert_almost_equal(th, got, decimal=6)
+
+
+def test_ref_rsquared(ref_data):                                      # :99-109
+    Xa, Xe, ya, ye = ref_data["hard"]
+    th = np.linalg.lstsq(Xa, ya, rcond=None)[0]
+    r2 = 1 - np.sum((ye - Xe @ th) ** 2) / np.sum(ye ** 2)
+    with pytest.warns(RuntimeWarning):
+        got = ls_spa(Xa, Xe, ya, ye, max_samples=4, batch_size=2).r_squared
+    np.testing.assert_almost_equal(r2, got, decimal=6)
+
+
+def test_ref_regularization(ref_data):                                # :112-124
+    Xa, Xe, ya, ye = ref_data["hard"]
+    N, p = Xa.shape
+    Xr = np.vstack((Xa / np.sqrt(N), np.sqrt(0.1) * np.eye(p)))
+    yr = np.concatenate((ya / np.sqrt(N), np.zeros(p)))
+    th = np.linalg.lstsq(Xr, yr, rcond=None)[0]
+    np.testing.assert_almost_equal(th, ls_spa(Xa, Xe, ya, ye, reg=0.1, max_samples=4, batch_size=2).theta)
+
+
+def test_ref_seed_consistency(ref_data):                              # :127-135
+    Xa, Xe, ya, ye = ref_data["hard"]
+    a = ls_spa(Xa, Xe, ya, ye, reg=0.05, seed=42, max_samples=4, batch_size=2).attribution
+    b = ls_spa(Xa, Xe, ya, ye, reg=0.05, seed=42, max_samples=4, batch_size=2).attribution
+    np.testing.assert_array_equal(a, b)
+
+
+def test_ref_correctness_easy(ref_data):                              # :138-160
+    Xa, Xe, ya, ye = ref_data["easy"]
+    p = Xa.shape[1]
+    want = O.refit_lift(Xa, Xe, ya, ye, np.arange(p))    # orthogonal columns: any ordering gives the same lifts
+    res = ls_spa(Xa, Xe, ya, ye, max_samples=256 * 256, batch_size=256)
+    np.testing.assert_almost_equal(want, res.attribution)
+    assert len(res.error_history) == 1                 # covariance ~ 0: stops at the first check, i = 256
+
+
+# ------------------------------------------------------------------ seeded parity vs the oracle, mid sizes
+@pytest.mark.parametrize("p,n,m,reg", [(33, 200, 150, 0.0), (128, 600, 500, 1e-2), (257, 700, 300, 0.0),
+                                       (191, 500, 100, 0.0)])
+def test_lifts_vs_oracle_various_shapes(engine, p, n, m, reg):
+    Xa, Xe, ya, ye = O.gaussian_workload(p, n, m, seed=p)
+    engine.load_data(Xa, Xe, ya, ye, reg)
+    red = O.reduce(Xa, Xe, ya, ye, reg)
+    yy = float(ye @ ye)
+    rng = np.random.default_rng(p)
+    perms = np.array([np.arange(p), np.arange(p)[::-1]] + [rng.permutation(p) for _ in range(6)])
+    for anti in (False, True):
+        got = engine.run_batch(perms, anti, want_lifts=True, accumulate=False)
+        want = np.array([O.sample_lift(*red, yy, o, anti) for o in perms])
+        np.testing.assert_allclose(got, want, **LIFT_TOL)
+
+
+def test_bad_perms_rejected(engine):
+    Xa, Xe, ya, ye = O.gaussian_workload(12, 60, 50, seed=1)
+    engine.load_data(Xa, Xe, ya, ye, 0.0)
+    bad = np.arange(12)[None, :].copy()
+    bad[0, 3] = 4
+    with pytest.raises(ValueError):
+        engine.run_batch(bad, True)
+    with pytest.raises(ValueError):
+        engine.run_batch(np.arange(11)[None, :], True)
+
+
+# ------------------------------------------------------------------ BASELINE sizes: properties
+@pytest.mark.parametrize("p,N", [(100, 10000), (1000, 100000)])
+def test_full_size_properties(p, N):
+    """C2 / C3 shapes, data generated on the device.  Every ordering's lift vector sums to the
+    full-model R^2; reversing twice is the identity; antithetical = mean of the
+    two directions; a sampled sub-problem agrees with the oracle."""
+    import torch
+    from ls_spa._engine import HipEngine
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    Xa = torch.randn(N, p, dtype=torch.float64, device=dev)
+    Xe = torch.randn(N, p, dtype=torch.float64, device=dev)
+    w = torch.randn(p, dtype=torch.float64, device=dev)
+    ya = Xa @ w + torch.randn(N, dtype=torch.float64, device=dev)
+    ye = Xe @ w + torch.randn(N, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    eng = HipEngine(0)
+    try:
+        eng.load_device_data(Xa.data_ptr(), p, ya.data_ptr(), N, Xe.data_ptr(), p, ye.data_ptr(), N, p, 0.0)
+        G, g, H, h = eng.gram()
+        np.testing.assert_allclose(G, (Xa.T @ Xa / N).cpu().numpy(), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(h, (Xe.T @ ye).cpu().numpy(), rtol=1e-12)
+        theta, r2, info = eng.full_fit()
+        assert info == 0
+        th = torch.linalg.solve(Xa.T @ Xa, Xa.T @ ya)
+        np.testing.assert_allclose(theta, th.cpu().numpy(), rtol=1e-8, atol=1e-10)
+        r2_ref = 1 - float(((ye - Xe @ th) ** 2).sum() / (ye ** 2).sum())
+        assert abs(r2 - r2_ref) < 1e-10
+        from scipy.stats.qmc import Sobol
+        perms = np.argsort(Sobol(p, seed=42).random(16), axis=1)
+        fwd = eng.run_batch(perms, False, want_lifts=True, accumulate=False)
+        np.testing.assert_allclose(fwd.sum(1), r2, rtol=0, atol=1e-10)
+        rev = eng.run_batch(perms[:, ::-1].copy(), False, want_lifts=True, accumulate=False)
+        anti = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        np.testing.assert_allclose(anti, 0.5 * (fwd + rev), rtol=0, atol=1e-13)
+        # oracle on the reduced problem (Cholesky factors of the device Grams are valid factors)
+        R = np.linalg.cholesky(G).T
+        F = np.linalg.cholesky(H).T
+        q = np.linalg.solve(R.T, g)
+        qt = np.linalg.solve(F.T, h)
+        for o, got in zip(perms[:2], fwd[:2]):
+            np.testing.assert_allclose(got, O.ordering_lift(R, F, q, qt, eng.y_norm_sq, o), **LIFT_TOL)
+    finally:
+        eng.close()

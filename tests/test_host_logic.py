@@ -1,0 +1,289 @@
+"""CPU tests of the host side: public surface, driver loop (against fixtures made by the real
+reference), samplers, statistics helpers and the C-ABI export list.  The orderings are evaluated
+by a test double backed by the oracle (tests/oracle_engine.py); the GPU runs of the same cases
+live in test_gpu_parity.py."""
+import ctypes
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ls_spa as pkg
+from ls_spa import (ShapleyResults, SizeIncompatible, error_estimates, ls_spa, merge_sample_cov,
+                    merge_sample_mean, validate_data)
+from ls_spa import _samplers as S
+from oracle_engine import OracleEngine
+
+TOL = dict(rtol=0, atol=1e-12)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def data_of(g):
+    return [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+
+
+# ---------------------------------------------------------------- public surface
+def test_public_names_and_signature():
+    for name in ("ls_spa", "ShapleyResults", "SizeIncompatible", "validate_data", "merge_sample_mean",
+                 "merge_sample_cov", "square_shapley", "reduce_data", "error_estimates"):
+        assert hasattr(pkg, name), name
+    sig = inspect.signature(ls_spa)
+    names = list(sig.parameters)
+    assert names[:12] == ["X_train", "X_test", "y_train", "y_test", "reg", "max_samples", "batch_size",
+                          "tolerance", "seed", "perms", "antithetical", "return_attribution_history"]
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["reg"], d["max_samples"], d["batch_size"], d["tolerance"], d["seed"], d["perms"],
+            d["antithetical"], d["return_attribution_history"]) == (0., 2 ** 13, 2 ** 8, 1e-2, 42, None, True, False)
+    for extra in ("method", "num_batches", "return_history"):
+        assert sig.parameters[extra].kind is inspect.Parameter.KEYWORD_ONLY
+    fields = list(ShapleyResults.__dataclass_fields__)
+    assert fields == ["attribution", "theta", "overall_error", "attribution_errors", "r_squared",
+                      "error_history", "attribution_history"]
+
+
+def test_repr_matches_reference(golden):
+    g = golden("toy")
+    res = ls_spa(*data_of(g), _engine=OracleEngine())
+    assert repr(res) == str(g["repr"])
+    long = ShapleyResults(np.arange(7) / 3, np.arange(7) / 7, 1.5e-3, np.zeros(7), 0.5, np.zeros(0), None)
+    text = repr(long)
+    assert "(0.00, 0.33, 0.67, 1.00, 1.33, ...)" in text and "1.50E-03" in text and "p = 7" in text
+
+
+def test_validate_messages():
+    a, b = np.zeros((5, 3)), np.zeros((4, 3))
+    cases = [
+        ((a, np.zeros((4, 2)), np.zeros(5), np.zeros(4)), "same number of columns"),
+        ((a, b, np.zeros(4), np.zeros(4)), "rows as y_train"),
+        ((a, b, np.zeros(5), np.zeros(3)), "rows as y_test"),
+        ((np.zeros((2, 3)), b, np.zeros(2), np.zeros(4)), "at most the number of observations"),
+    ]
+    for args, frag in cases:
+        with pytest.raises(SizeIncompatible) as e:
+            validate_data(*args)
+        assert frag in e.value.message
+    validate_data(a, b, np.zeros(5), np.zeros(4))
+    with pytest.raises(SizeIncompatible):
+        ls_spa(a, np.zeros((4, 2)), np.zeros(5), np.zeros(4), _engine=OracleEngine())
+    with pytest.raises(ValueError):   # 2-D y, reference: ValueError from concatenate
+        ls_spa(np.ones((5, 3)), np.ones((4, 3)), np.ones((5, 1)), np.ones(4), _engine=OracleEngine())
+
+
+# ---------------------------------------------------------------- statistics helpers
+def test_merge_helpers(golden):
+    g = golden("merge")
+    X = g["X"]
+    a, b = X[:200], X[200:]
+    np.testing.assert_allclose(merge_sample_mean(a.mean(0), b.mean(0), 200, 300), g["merged_mean"], atol=1e-14)
+    got = merge_sample_cov(a.mean(0), b.mean(0), np.cov(a, rowvar=False, bias=True),
+                           np.cov(b, rowvar=False, bias=True), 200, 300)
+    np.testing.assert_allclose(got, g["merged_cov"], rtol=1e-13, atol=1e-12)
+    # the reference's own assertions (test/test_ls_spa.py:20-44), 7 decimals
+    np.testing.assert_almost_equal(X.mean(0), merge_sample_mean(a.mean(0), b.mean(0), 200, 300))
+    np.testing.assert_almost_equal(np.cov(X, rowvar=False, bias=True), got)
+
+
+def test_error_estimates_stream(golden):
+    g = golden("edge")
+    rng = np.random.default_rng(17)
+    feat, total = error_estimates(rng, g["ee_full_cov"])
+    np.testing.assert_allclose(feat, g["ee_full_feat"], rtol=1e-9)
+    np.testing.assert_allclose(total, float(g["ee_full_total"]), rtol=1e-9)
+    np.testing.assert_array_equal(rng.standard_normal(4), g["ee_full_next"])
+    feat, total = error_estimates(np.random.default_rng(17), g["ee_low_cov"])
+    np.testing.assert_allclose(total, float(g["ee_low_total"]), rtol=0.25)
+
+
+def test_lowrank_estimator_matches_distribution():
+    rng = np.random.default_rng(0)
+    lifts = rng.standard_normal((200, 15)) @ rng.standard_normal((15, 15)) * 1e-2
+    c = lifts - lifts.mean(0)
+    cov = np.cov(lifts, rowvar=False) / len(lifts)
+    f1, t1 = error_estimates(np.random.default_rng(1), cov)
+    f2, t2 = pkg.error_estimates_lowrank(np.random.default_rng(2), c)
+    assert abs(t1 - t2) / t1 < 0.1
+    np.testing.assert_allclose(f1, f2, rtol=0.2)
+
+
+# ---------------------------------------------------------------- samplers
+def test_samplers_match_fixtures(golden):
+    g = golden("samplers_p12")
+    np.testing.assert_allclose(S.helmert_rows(12), g["U"], atol=1e-15)
+    src = S.ArgsortSource(12, 5, 32)
+    got = np.concatenate([src.take(8), src.take(24), src.take(5)])   # chunked draws continue the sequence
+    np.testing.assert_array_equal(got, g["argsort"])
+    src = S.PermutohedronSource(12, 5, 32)
+    got = np.concatenate([src.take(16), src.take(16)])
+    np.testing.assert_array_equal(got, g["permutohedron"])
+    assert len(src.take(4)) == 0
+
+
+def test_iterable_source_is_lazy():
+    pulled = []
+
+    def gen():
+        for k in range(100):
+            pulled.append(k)
+            yield np.roll(np.arange(9), k)
+    src = S.IterableSource(gen(), 9)
+    assert src.take(4).shape == (4, 9) and len(pulled) == 4
+    with pytest.raises(ValueError):
+        S.IterableSource([[0, 1, 2]], 9).take(1)
+
+
+# ---------------------------------------------------------------- driver against reference outputs
+def test_toy_exact(golden):
+    g = golden("toy")
+    eng = OracleEngine()
+    res = ls_spa(*data_of(g), _engine=eng)
+    np.testing.assert_allclose(res.attribution, g["attribution"], **TOL)
+    np.testing.assert_allclose(res.theta, g["theta"], **TOL)
+    assert abs(res.r_squared - float(g["r_squared"])) < 1e-13
+    assert res.overall_error == 0.0 and res.error_history.shape == (0,) and res.attribution_history is None
+    np.testing.assert_array_equal(res.attribution_errors, np.zeros(3))
+    assert sum(eng.calls) == 6          # 3! orderings, antithetical forced off
+
+
+@pytest.mark.parametrize("p", [4, 8])
+def test_exact_small_p(golden, p):
+    g = golden(f"exact_p{p}")
+    res = ls_spa(*data_of(g), _engine=OracleEngine())
+    np.testing.assert_allclose(res.attribution, g["attribution"], **TOL)
+    assert abs(res.attribution.sum() - res.r_squared) < 1e-12
+
+
+@pytest.mark.parametrize("anti", [True, False])
+def test_injected_perms_history_and_triggers(golden, anti):
+    g = golden("p12")
+    pre = f"drv_anti{int(anti)}_"
+    eng = OracleEngine()
+    res = ls_spa(*data_of(g), perms=g["perms64"], batch_size=16, tolerance=0.0, antithetical=anti,
+                 return_attribution_history=True, _engine=eng)
+    np.testing.assert_allclose(res.attribution, g[pre + "attribution"], **TOL)
+    np.testing.assert_allclose(res.attribution_history, g[pre + "attribution_history"], **TOL)
+    np.testing.assert_allclose(res.theta, g[pre + "theta"], **TOL)
+    assert eng.calls == [16, 16, 16, 16]
+    assert len(res.error_history) == len(g[pre + "error_history"]) == 4
+    np.testing.assert_allclose(res.error_history, g[pre + "error_history"], rtol=0.15)
+    np.testing.assert_allclose(res.overall_error, float(g[pre + "overall_error"]), rtol=0.15)
+
+
+def test_perms_as_generator_and_progress_wrapper(golden):
+    g = golden("p12")
+
+    class Wrapper:            # stands in for marimo's progress bar: only __iter__ is used
+        def __init__(self, rows):
+            self.rows, self.n = rows, 0
+
+        def __iter__(self):
+            for r in self.rows:
+                self.n += 1
+                yield r
+    w = Wrapper(list(g["perms64"]))
+    res = ls_spa(*data_of(g), perms=w, batch_size=16, tolerance=0.0, _engine=OracleEngine())
+    np.testing.assert_allclose(res.attribution, g["drv_anti1_attribution"], **TOL)
+    assert w.n == 64
+
+
+def test_seed_path_trigger_indices_and_stream(golden):
+    """perms=None, p >= 9: checks at i = 16, 32, 39 (= max_samples - 1) and a trailing one at 40;
+    the first 16 orderings are drawn before the estimator touches the shared generator."""
+    g = golden("p12")
+    eng = OracleEngine()
+    res = ls_spa(*data_of(g), max_samples=40, batch_size=16, tolerance=0.0, seed=3,
+                 return_attribution_history=True, _engine=eng)
+    assert eng.calls == [16, 16, 7, 1]
+    assert len(res.error_history) == 4
+    np.testing.assert_allclose(res.attribution_history[:16], g["seedpath_attribution_history"][:16], **TOL)
+    assert res.attribution_history.shape == (40, 12)
+    if np.allclose(res.attribution_history[16:], g["seedpath_attribution_history"][16:], atol=1e-12):
+        np.testing.assert_allclose(res.attribution, g["seedpath_attribution"], **TOL)
+
+
+def test_tolerance_stops_at_batch_boundary(golden):
+    g = golden("p12")
+    eng = OracleEngine()
+    res = ls_spa(*data_of(g), perms=g["perms64"], batch_size=16, tolerance=1e9, _engine=eng)
+    assert eng.calls == [16] and len(res.error_history) == 1
+
+
+def test_single_sample_gives_nan_error(golden):
+    g = golden("p12")
+    with np.errstate(all="ignore"):
+        try:
+            res = ls_spa(*data_of(g), perms=g["perms64"][:1], _engine=OracleEngine())
+        except np.linalg.LinAlgError:
+            return           # numpy builds that refuse to factor a NaN matrix: same as the reference there
+    assert np.isnan(res.overall_error)
+
+
+def test_m_less_than_p_and_float32(golden):
+    g = golden("edge")
+    res = ls_spa(*data_of(g), perms=g["perms"], batch_size=8, tolerance=0.0, _engine=OracleEngine())
+    np.testing.assert_allclose(res.attribution, g["mltp_attribution"], **TOL)
+    np.testing.assert_allclose(res.theta, g["mltp_theta"], **TOL)
+    g12 = golden("p12")
+    d32 = [a.astype(np.float32) for a in data_of(g12)]
+    res = ls_spa(*d32, perms=g["perms"], batch_size=8, tolerance=0.0, _engine=OracleEngine())
+    assert res.attribution.dtype == np.float64
+    # the reference keeps the test side in float32; this build promotes both sides
+    np.testing.assert_allclose(res.attribution, g["f32_attribution"], rtol=0, atol=2e-5)
+
+
+def test_dataframe_inputs(golden):
+    import pandas as pd
+    g = golden("p12")
+    Xa, Xe, ya, ye = data_of(g)
+    res = ls_spa(pd.DataFrame(Xa), pd.DataFrame(Xe), pd.Series(ya), pd.Series(ye), perms=g["perms64"][:16],
+                 batch_size=16, tolerance=0.0, _engine=OracleEngine())
+    want = ls_spa(Xa, Xe, ya, ye, perms=g["perms64"][:16], batch_size=16, tolerance=0.0, _engine=OracleEngine())
+    np.testing.assert_array_equal(res.attribution, want.attribution)
+
+
+# ---------------------------------------------------------------- README dialect
+def test_readme_keywords(golden):
+    g = golden("p12")
+    d = data_of(g)
+    eng = OracleEngine()
+    res = ls_spa(*d, method="argsort", batch_size=8, num_batches=3, tolerance=0.0, seed=5,
+                 return_history=True, _engine=eng)
+    assert eng.calls == [8, 8, 7, 1] and res.attribution_history.shape == (24, 12)
+    from scipy.stats.qmc import Sobol
+    want = ls_spa(*d, perms=np.argsort(Sobol(12, seed=5).random(32), axis=1)[:24], batch_size=8,
+                  tolerance=0.0, _engine=OracleEngine())
+    np.testing.assert_allclose(res.attribution, want.attribution, **TOL)
+    res = ls_spa(*d, method="permutohedron", batch_size=8, num_batches=2, tolerance=0.0, seed=5,
+                 _engine=OracleEngine())
+    want = ls_spa(*d, perms=golden("samplers_p12")["permutohedron"][:16], batch_size=8, tolerance=0.0,
+                  _engine=OracleEngine())
+    np.testing.assert_allclose(res.attribution, want.attribution, **TOL)
+    g4 = golden("exact_p4")
+    res = ls_spa(*data_of(g4), method="exact", _engine=OracleEngine())
+    np.testing.assert_allclose(res.attribution, g4["attribution"], **TOL)
+    with pytest.raises(ValueError):
+        ls_spa(*d, method="sobol", _engine=OracleEngine())
+    with pytest.raises(ValueError):
+        ls_spa(*d, method="argsort", perms=g["perms64"], _engine=OracleEngine())
+
+
+# ---------------------------------------------------------------- C ABI export list
+def test_library_exports_every_declared_symbol():
+    from ls_spa import _native
+    header = open(os.path.join(ROOT, "include", "lsspa.h")).read()
+    declared = set(re.findall(r"\b(lsspa_[a-z0-9_]+)\s*\(", header)) - {"lsspa_ctx"}
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    lib = ctypes.CDLL(_native.library_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _native.load().lsspa_abi_version() == 1
+
+
+def test_product_never_imports_oracle():
+    pkg_dir = os.path.join(ROOT, "ls-spa_amd")
+    for base, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(base, f)).read()
+                assert "lsspa_oracle" not in text and "oracle_engine" not in text, f

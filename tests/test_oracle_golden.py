@@ -1,0 +1,143 @@
+"""Pins the CPU oracle (oracle/lsspa_oracle.py) against fixtures produced by the real
+reference (tests/golden/make_golden.py).  CPU only."""
+import itertools
+
+import numpy as np
+import pytest
+
+import lsspa_oracle as O
+
+TOL = dict(rtol=0, atol=1e-12)
+
+
+def test_toy_result_and_lifts(golden):
+    g = golden("toy")
+    d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+    res = O.estimate(*d)
+    np.testing.assert_allclose(res.attribution, g["attribution"], **TOL)
+    np.testing.assert_allclose(res.theta, g["theta"], **TOL)
+    assert abs(res.r_squared - float(g["r_squared"])) < 1e-13
+    assert res.overall_error == float(g["overall_error"]) == 0.0
+    assert res.error_history.size == 0 and g["error_history"].size == 0
+    red = O.reduce(*d, 0.0)
+    yy = np.linalg.norm(d[3]) ** 2
+    for o, want in zip(g["orders"], g["lifts"]):
+        np.testing.assert_allclose(O.ordering_lift(*red, yy, o), want, **TOL)
+    # published values
+    np.testing.assert_allclose(res.attribution, [0.59671319, 0.47096035, -0.14387332], atol=5e-9)
+    # third, independent definition: 2^p subset table
+    np.testing.assert_allclose(O.brute_force_shapley(*d), g["attribution"], atol=1e-12)
+
+
+@pytest.mark.parametrize("p", [4, 8])
+def test_exact_mode(golden, p):
+    g = golden(f"exact_p{p}")
+    d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+    res = O.estimate(*d)
+    np.testing.assert_allclose(res.attribution, g["attribution"], **TOL)
+    np.testing.assert_allclose(res.theta, g["theta"], **TOL)
+    assert abs(res.r_squared - float(g["r_squared"])) < 1e-13
+    if p == 4:
+        np.testing.assert_allclose(O.brute_force_shapley(*d), g["attribution"], atol=1e-12)
+
+
+@pytest.mark.parametrize("tag,reg", [("r0", 0.0), ("r1", 0.1)])
+def test_reduction_and_lifts_p12(golden, tag, reg):
+    g = golden("p12")
+    d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+    R, F, q, qt = O.reduce(*d, reg)
+    # LAPACK may flip row signs between builds: compare sign-invariant quantities
+    np.testing.assert_allclose(R.T @ R, g[f"{tag}_R_tr"].T @ g[f"{tag}_R_tr"], **TOL)
+    np.testing.assert_allclose(R.T @ q, g[f"{tag}_R_tr"].T @ g[f"{tag}_q_tr"], **TOL)
+    np.testing.assert_allclose(F.T @ F, g[f"{tag}_F_te"].T @ g[f"{tag}_F_te"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(F.T @ qt, g[f"{tag}_F_te"].T @ g[f"{tag}_q_te"], rtol=0, atol=1e-11)
+    yy = np.linalg.norm(d[3]) ** 2
+    for o, want in zip(g["orders"], g[f"{tag}_lifts"]):
+        np.testing.assert_allclose(O.ordering_lift(R, F, q, qt, yy, o), want, **TOL)
+    # second independent definition: refit every prefix on the raw data (reg = 0 only)
+    if reg == 0.0:
+        for o, want in zip(g["orders"][:3], g[f"{tag}_lifts"][:3]):
+            np.testing.assert_allclose(O.refit_lift(*d, o), want, atol=1e-11)
+
+
+@pytest.mark.parametrize("anti", [True, False])
+def test_driver_injected_perms(golden, anti):
+    g = golden("p12")
+    d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+    res = O.estimate(*d, perms=g["perms64"], batch_size=16, tolerance=0.0, antithetical=anti,
+                     return_attribution_history=True)
+    pre = f"drv_anti{int(anti)}_"
+    np.testing.assert_allclose(res.attribution, g[pre + "attribution"], **TOL)
+    np.testing.assert_allclose(res.attribution_history, g[pre + "attribution_history"], **TOL)
+    np.testing.assert_allclose(res.theta, g[pre + "theta"], **TOL)
+    # Lift vectors of every ordering sum to the same R^2, so the sample covariance is singular
+    # by construction and whether LAPACK's potrf "succeeds" on it is decided by round-off
+    # (SURVEY.md 3.3): the estimator's draws are pinned statistically, not bit for bit.
+    np.testing.assert_allclose(res.error_history, g[pre + "error_history"], rtol=0.15)
+    np.testing.assert_allclose(res.attribution_errors, g[pre + "attribution_errors"], rtol=0.25)
+    assert len(res.error_history) == 4
+
+
+def test_driver_seed_path_interleave(golden):
+    """perms=None, p >= 9: orderings and error draws come from ONE generator, lazily."""
+    g = golden("p12")
+    d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+    res = O.estimate(*d, max_samples=40, batch_size=16, tolerance=0.0, seed=3,
+                     return_attribution_history=True)
+    # up to the first error estimate the stream is only used for orderings: exact
+    np.testing.assert_allclose(res.attribution_history[:16], g["seedpath_attribution_history"][:16], **TOL)
+    assert len(res.error_history) == len(g["seedpath_error_history"]) == 4   # i = 16, 32, 39, 40
+    # afterwards the stream position depends on the Cholesky-or-SVD branch taken on a singular
+    # covariance (round-off decides): later orderings may differ, the estimate stays close
+    np.testing.assert_allclose(res.error_history, g["seedpath_error_history"], rtol=0.3)
+    if np.allclose(res.attribution_history[16:], g["seedpath_attribution_history"][16:], atol=1e-12):
+        np.testing.assert_allclose(res.attribution, g["seedpath_attribution"], **TOL)
+
+
+def test_correlated_generator_lifts(golden):
+    g = golden("corr_p100")
+    red = (g["R_tr"], g["F_te"], g["q_tr"], g["q_te"])
+    for o, want in zip(g["orders"], g["lifts"]):
+        np.testing.assert_allclose(O.ordering_lift(*red, float(g["y_norm_sq"]), o), want, rtol=0, atol=1e-11)
+    # the generator restatement reproduces the reduced problem the fixture was made from
+    d = O.correlated_workload(np.random.default_rng(int(g["seed"])), 100, int(g["N"]), int(g["M"]))
+    R = O.reduce(*d, 0.0)[0]
+    np.testing.assert_allclose(R.T @ R, g["R_tr"].T @ g["R_tr"], rtol=0, atol=1e-11)
+
+
+def test_samplers(golden):
+    from scipy.stats.qmc import MultivariateNormalQMC, Sobol
+    g = golden("samplers_p12")
+    np.testing.assert_allclose(O.permutohedron_basis(12), g["U"], atol=1e-15)
+    np.testing.assert_array_equal(O.orderings_argsort(Sobol(12, seed=5), 32), g["argsort"])
+    q = MultivariateNormalQMC(np.zeros(11), seed=5, inv_transform=False)
+    np.testing.assert_array_equal(O.orderings_permutohedron(q, 32, 12), g["permutohedron"])
+
+
+def test_merge_formulas(golden):
+    g = golden("merge")
+    X = g["X"]
+    a, b = X[:200], X[200:]
+    mm = O.pooled_mean(a.mean(0), b.mean(0), 200, 300)
+    mc = O.pooled_cov(a.mean(0), b.mean(0), np.cov(a, rowvar=False, bias=True),
+                      np.cov(b, rowvar=False, bias=True), 200, 300)
+    np.testing.assert_allclose(mm, g["merged_mean"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(mc, g["merged_cov"], rtol=1e-13, atol=1e-12)
+    np.testing.assert_allclose(mm, X.mean(0), atol=1e-12)
+    np.testing.assert_allclose(mc, np.cov(X, rowvar=False, bias=True), rtol=1e-10, atol=1e-10)
+
+
+def test_edge_cases(golden):
+    g = golden("edge")
+    d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]        # M = 8 < p = 12
+    res = O.estimate(*d, perms=g["perms"], batch_size=8, tolerance=0.0)
+    np.testing.assert_allclose(res.attribution, g["mltp_attribution"], **TOL)
+    np.testing.assert_allclose(res.theta, g["mltp_theta"], **TOL)
+    for tag in ("full", "low"):
+        rng = np.random.default_rng(17)
+        feat, total = O.error_quantiles(rng, g[f"ee_{tag}_cov"])
+        tol = 1e-9 if tag == "full" else 0.25   # singular covariance: branch decided by round-off
+        np.testing.assert_allclose(feat, g[f"ee_{tag}_feat"], rtol=tol)
+        np.testing.assert_allclose(total, float(g[f"ee_{tag}_total"]), rtol=tol)
+        if tag == "full":   # same stream position after a successful Cholesky draw
+            np.testing.assert_array_equal(rng.standard_normal(4), g[f"ee_{tag}_next"])
