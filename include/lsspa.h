@@ -106,6 +106,9 @@ int lsspa_profile_enable(lsspa_ctx* ctx, int32_t on);
 int lsspa_profile_get(lsspa_ctx* ctx, int32_t kernel_class, double* total_ms, int64_t* launches);
 int lsspa_profile_reset(lsspa_ctx* ctx);
 
+/* developer switch for in-process A/B timing of kernel variants (0 = shipped configuration) */
+int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);
+
 /* test hooks */
 int lsspa_mfma_probe(lsspa_ctx* ctx, const double* A16x4, const double* B4x16, double* D16x16);
 /* factor one ordering and copy the padded factor(s) out: L [p_pad][p_pad] (train),

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
   const int32_t* perm = a.perms + (int64_t)ord * p;
   const double* S = a.S[src];
   const double* svec = a.s[src];
-  double* out = a.A + (int64_t)mat * p_pad * p_pad;
+  const int64_t lda = lda_of(p_pad);
+  double* out = a.A + (int64_t)mat * p_pad * lda;
 
   const int jmax = min(i0 + GROWS, p);  // permutation entries this workgroup can touch
   for (int j = tid; j < jmax; j += 256) sperm[j] = perm[j];
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     const int i = i0 + ii;
     if (i >= p_pad) break;
     const int jend = min(((i + 1 + NB - 1) / NB) * NB, p_pad);  // zero-fill to the block edge
-    double* orow = out + (int64_t)i * p_pad;
+    double* orow = out + i * lda;
     if (i < p) {
       const double* srow = S + (int64_t)sperm[i] * a.ld_src;
       __syncthreads();  // previous row's picks are done
@@ -84,118 +85,107 @@ hipError_t launch_gather(const GatherArgs& a, hipStream_t st) {
 }
 
 // =====================================================================================
-// chol_diag, step J:  T = A[J,J] - sum_{K<J} L[J,K] L[J,K]^T   (fp64 MFMA)
-//                     T = L_JJ L_JJ^T  by an in-LDS elimination that carries the
-//                     identity along, so L_JJ^-1 comes out of the same sweep.
-// One workgroup per matrix.
+// Blocked Cholesky, left-looking for the off-diagonal tiles and right-looking for the
+// diagonal tiles:
+//   chol_diag,  step J : A[J,J] already carries every update  -sum_{K<J} L[J,K] L[J,K]^T
+//                        (applied by the panel steps below); factor it in place by an
+//                        elimination that carries the identity along, so L_JJ^-1 comes out
+//                        of the same sweep.  One workgroup per matrix, no GEMM.
+//   chol_panel, step J : for a 128-row tile I below the diagonal block,
+//                          C = A[I,J] - sum_{K<J} L[I,K] L[J,K]^T ;  L[I,J] = C * L_JJ^-T ;
+//                        then, while L[I,J] sits in LDS for its coalesced store, the two
+//                        diagonal tiles of the tile's own rows get  -= L[I',J] L[I',J]^T.
 // =====================================================================================
-__global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, double* __restrict__ Dinv,
-                                                        int32_t* __restrict__ info, int p_pad, int J,
-                                                        int nblk) {
-  __shared__ __attribute__((aligned(16))) double s_rk[64 * RK_LD];
-  __shared__ double s_T[64 * TT_LD];
-  __shared__ double s_Y[64 * TT_LD];
+__global__ __launch_bounds__(256, 2) void chol_diag_kernel(double* __restrict__ A, double* __restrict__ Dinv,
+                                                           int32_t* __restrict__ info, int p_pad, int J,
+                                                           int nblk) {
+  __shared__ double s_col[2][64];      // column k of T (unscaled), double-buffered by k parity
+  __shared__ double s_row[2][64];      // row k of Y
+  __shared__ double s_piv[2];
   __shared__ double s_dd[64];
   __shared__ int s_bad;
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int l15 = lane & 15, l4 = lane >> 4;
+  const int tid = threadIdx.x;
   const int mt = blockIdx.x;
-  double* M = A + (int64_t)mt * p_pad * p_pad;
+  const int64_t lda = lda_of(p_pad);
+  double* M = A + (int64_t)mt * p_pad * lda;
   const int J0 = J * NB;
-  const int tjq = w >> 1, tiq = w & 1;
 
-  d4 acc[2][2];
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int y = 0; y < 2; ++y) acc[x][y] = d4_zero();
-
-  const double* srcJ = M + (int64_t)J0 * p_pad;
-  const int nch = J0 / KCH;
-  RKRegs<64> rj = {};
-  if (nch > 0) rk_load<64>(rj, srcJ, p_pad, tid, 64);
-  for (int c = 0; c < nch; ++c) {
-    __syncthreads();
-    rk_store<64>(rj, s_rk, tid);
-    __syncthreads();
-    if (c + 1 < nch) rk_load<64>(rj, srcJ + (c + 1) * KCH, p_pad, tid, 64);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      double av[2], bv[2];
-#pragma unroll
-      for (int x = 0; x < 2; ++x) av[x] = s_rk[(16 * (2 * tjq + x) + l15) * RK_LD + 4 * kk + l4];
-#pragma unroll
-      for (int y = 0; y < 2; ++y) bv[y] = s_rk[(16 * (2 * tiq + y) + l15) * RK_LD + 4 * kk + l4];
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = mfma(av[x], bv[y], acc[x][y]);
-    }
-  }
-
-  // T <- A[J,J] (lower part is meaningful), Y <- I
-  if (tid == 0) s_bad = 0;
-  for (int idx = tid; idx < 64 * 64; idx += 256) {
-    const int row = idx >> 6, col = idx & 63;
-    s_T[row * TT_LD + col] = (col <= row) ? M[(int64_t)(J0 + row) * p_pad + J0 + col] : 0.0;
-    s_Y[row * TT_LD + col] = (row == col) ? 1.0 : 0.0;
-  }
-  __syncthreads();
-  // acc holds (sum L L^T)^T: element [j][i]; the matrix is symmetric, write it at T[i][j]
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int y = 0; y < 2; ++y)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = 16 * (2 * tjq + x) + acc_row(l4, r);
-        const int i = 16 * (2 * tiq + y) + l15;
-        if (j <= i) s_T[i * TT_LD + j] -= acc[x][y][r];
-      }
-  __syncthreads();
-
-  // elimination on [T | Y] without scaling: after step k column k of T is final
-  // (= L[:,k] * L[k][k]) and row k of Y is final (= (L^-1)[k,:] * L[k][k]).
+  // Owner layout: thread (ty, tx) keeps T(ty + 16 a, tx + 16 c) and Y(ty + 16 a, tx + 16 c) in
+  // registers.  Elimination on [T | Y] without scaling: after step k column k of T is final
+  // (= L[:,k] * L[k][k]) and row k of Y is final (= (L^-1)[k,:] * L[k][k]).  Per step only
+  // column k of T, row k of Y and the pivot travel through LDS (one barrier per step).
   const int ty = tid >> 4, tx = tid & 15;
-  for (int k = 0; k < 64; ++k) {
-    double d = s_T[k * TT_LD + k];
-    if (!(d > 0.0)) {  // not positive definite (or NaN): flag it and keep going finitely
-      d = 1.0;
-      if (tid == 0) s_bad = 1;
-    }
-    if (tid == 0) s_dd[k] = d;
-    const double invd = 1.0 / d;
-    const int a0 = (k + 1 > ty) ? (k + 1 - ty + 15) >> 4 : 0;  // first a with ty + 16 a > k
-    for (int a = a0; a < 4; ++a) {
-      const int i = ty + 16 * a;
-      const double f = s_T[i * TT_LD + k] * invd;
+  double T[4][4], Y[4][4];
+  if (tid == 0) s_bad = 0;
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int j = tx + 16 * cc;
-        if (j > k && j <= i) s_T[i * TT_LD + j] -= f * s_T[j * TT_LD + k];
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int row = ty + 16 * a, col = tx + 16 * c;
+      T[a][c] = (col <= row) ? M[(J0 + row) * lda + J0 + col] : 0.0;
+      Y[a][c] = (row == col) ? 1.0 : 0.0;
+    }
+
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) {
+#pragma unroll 1
+    for (int kk = 0; kk < 16; ++kk) {
+      const int k = 16 * kc + kk;
+      const int buf = k & 1;
+      if (tx == kk) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s_col[buf][ty + 16 * a] = T[a][kc];
+      }
+      if (ty == kk) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_row[buf][tx + 16 * c] = Y[kc][c];
+        if (tx == kk) s_piv[buf] = T[kc][kc];
+      }
+      __syncthreads();
+      double d = s_piv[buf];
+      if (!(d > 0.0)) {  // not positive definite (or NaN): flag it and keep going finitely
+        d = 1.0;
+        if (tid == 0) s_bad = 1;
+      }
+      if (tid == 0) s_dd[k] = d;
+      const double invd = 1.0 / d;
+      double cj[4], rc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        cj[c] = s_col[buf][tx + 16 * c];
+        rc[c] = s_row[buf][tx + 16 * c];
       }
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int c = tx + 16 * cc;
-        if (c <= k) s_Y[i * TT_LD + c] -= f * s_Y[k * TT_LD + c];
+      for (int a = 0; a < 4; ++a) {
+        const int i = ty + 16 * a;
+        const double f = (i > k) ? s_col[buf][i] * invd : 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int j = tx + 16 * c;
+          if (j > k && j <= i) T[a][c] -= f * cj[c];
+          if (j <= k) Y[a][c] -= f * rc[c];
+        }
       }
     }
-    __syncthreads();
   }
+  __syncthreads();
   if (tid < 64) s_dd[tid] = 1.0 / sqrt(s_dd[tid]);  // now holds 1 / L[k][k]
   __syncthreads();
 
   double* Dg = Dinv + ((int64_t)mt * nblk + J) * 4096;
-  for (int idx = tid; idx < 64 * 64; idx += 256) {
-    const int row = idx >> 6, col = idx & 63;
-    double lv = 0.0, xv = 0.0;
-    if (col < row) lv = s_T[row * TT_LD + col] * s_dd[col];
-    if (col == row) lv = 1.0 / s_dd[col];
-    if (col <= row) xv = s_Y[row * TT_LD + col] * s_dd[row];
-    M[(int64_t)(J0 + row) * p_pad + J0 + col] = lv;
-    Dg[idx] = xv;
-  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int row = ty + 16 * a, col = tx + 16 * c;
+      double lv = 0.0, xv = 0.0;
+      if (col < row) lv = T[a][c] * s_dd[col];
+      if (col == row) lv = 1.0 / s_dd[col];
+      if (col <= row) xv = Y[a][c] * s_dd[row];
+      M[(J0 + row) * lda + J0 + col] = lv;
+      Dg[row * 64 + col] = xv;
+    }
   if (tid == 0 && s_bad) atomicOr(&info[0], 1);
 }
 
@@ -207,50 +197,80 @@ hipError_t launch_chol_diag(double* A, double* Dinv, int32_t* info, int p_pad, i
   return hipGetLastError();
 }
 
-// =====================================================================================
-// chol_panel, step J:  for a 128-row tile I below the diagonal block,
-//     C = A[I,J] - sum_{K<J} L[I,K] L[J,K]^T ;  L[I,J] = C * L_JJ^-T
-// The accumulators hold C^T, which is exactly the B operand of  (L_JJ^-1) * C^T.
-// =====================================================================================
-__global__ __launch_bounds__(256, 2) void chol_panel_kernel(double* __restrict__ A,
+// The accumulators hold -C^T: they start at -A[I,J]^T (each wave stages its own 32 rows through
+// its slice of the output buffer, coalesced, no workgroup barrier) and collect +L[J,K] L[I,K]^T.
+// -C^T is exactly the B operand of (L_JJ^-1) * C^T: no LDS round trip between the two products.
+__global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__ A,
                                                             const double* __restrict__ Dinv, int p_pad,
-                                                            int J, int nblk) {
-  __shared__ __attribute__((aligned(16))) double s_rkj[64 * RK_LD];
-  __shared__ __attribute__((aligned(16))) double s_rki[128 * RK_LD];
-  __shared__ __attribute__((aligned(16))) double s_dinv[64 * DI_LD];
+                                                            int J, int nblk, int flags) {
+  // LDS: 52,224 B, so that three workgroups fit one CU.  Region A holds the two operand tiles
+  // of the main loop and, after it, L_JJ^-1; region B is the output / update staging tile.
+  __shared__ __attribute__((aligned(16))) double s_a[64 * DI_LD];
+  __shared__ __attribute__((aligned(16))) double s_b[128 * RK_LD];
+  static_assert(64 * DI_LD >= 64 * RK_LD + 128 * RK_LD, "operand tiles must fit region A");
+  double* const s_rkj = s_a;
+  double* const s_rki = s_a + 64 * RK_LD;
+  double* const s_dinv = s_a;
+  double* const s_out = s_b;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int mt = blockIdx.y;
-  double* M = A + (int64_t)mt * p_pad * p_pad;
+  const int64_t lda = lda_of(p_pad);
+  double* M = A + (int64_t)mt * p_pad * lda;
   const int J0 = J * NB;
   const int I0 = J0 + NB + blockIdx.x * 128;
   const int rows_valid = min(128, p_pad - I0);
 
-  d4 acc[4][2];
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 2; ++y) acc[x][y] = d4_zero();
+  const double* srcJ = M + J0 * lda;
+  const double* srcI = M + I0 * lda;
 
-  const double* srcJ = M + (int64_t)J0 * p_pad;
-  const double* srcI = M + (int64_t)I0 * p_pad;
   const int nch = J0 / KCH;
   RKRegs<64> rj = {};
   RKRegs<128> ri = {};
   if (nch > 0) {
-    rk_load<64>(rj, srcJ, p_pad, tid, 64);
-    rk_load<128>(ri, srcI, p_pad, tid, rows_valid);
+    rk_load<64>(rj, srcJ, lda, tid, 64);
+    rk_load<128>(ri, srcI, lda, tid, rows_valid);
   }
+
+  // acc[x][y][r] <-> (column j = 16 x + l4 + 4 r of block J, row i = 32 w + 16 y + l15 of the tile)
+  d4 acc[4][2];
+  {
+    const int rr = lane >> 3, ch = lane & 7;  // 8 rows x 8 16-byte chunks per wave instruction
+    v2d t[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 32 * w + rr + 8 * q;
+        t[x][q] = (i < rows_valid) ? *reinterpret_cast<const v2d*>(srcI + i * lda + J0 + 16 * x + 2 * ch)
+                                   : v2d{0.0, 0.0};
+      }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<v2d*>(s_out + (32 * w + rr + 8 * q) * RK_LD + 2 * ch) = t[x][q];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[x][y][r] = -s_out[(32 * w + 16 * y + l15) * RK_LD + acc_row(l4, r)];
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
   for (int c = 0; c < nch; ++c) {
     __syncthreads();
     rk_store<64>(rj, s_rkj, tid);
     rk_store<128>(ri, s_rki, tid);
     __syncthreads();
     if (c + 1 < nch) {
-      rk_load<64>(rj, srcJ + (c + 1) * KCH, p_pad, tid, 64);
-      rk_load<128>(ri, srcI + (c + 1) * KCH, p_pad, tid, rows_valid);
+      rk_load<64>(rj, srcJ + (c + 1) * KCH, lda, tid, 64);
+      rk_load<128>(ri, srcI + (c + 1) * KCH, lda, tid, rows_valid);
     }
+    if (32 * w >= rows_valid) continue;  // half tile at the bottom: this wave's rows do not exist
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       double av[4], bv[2];
@@ -265,44 +285,41 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(double* __restrict__
     }
   }
 
+  __syncthreads();  // every wave is done with the operand tiles that L_JJ^-1 now overwrites
   load_block64(s_dinv, Dinv + ((int64_t)mt * nblk + J) * 4096, tid);
+  __syncthreads();
 
-  // C^T = A[I,J]^T - acc, 16 columns of J at a time through the row-tile buffer
-#pragma unroll
-  for (int x = 0; x < 4; ++x) {
-    __syncthreads();
-    rk_load<128>(ri, srcI + J0 + 16 * x, p_pad, tid, rows_valid);
-    rk_store<128>(ri, s_rki, tid);
-    __syncthreads();
-#pragma unroll
-    for (int y = 0; y < 2; ++y)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[x][y][r] = s_rki[(32 * w + 16 * y + l15) * RK_LD + acc_row(l4, r)] - acc[x][y][r];
-  }
-
-  // out^T[j'][i] = sum_k Dinv[j'][k] C[i][k]   (Dinv lower triangular: k-blocks above j' vanish)
+  // out^T[j'][i] = sum_k Dinv[j'][k] C[i][k] = sum_k (-Dinv[j'][k]) acc[k][i]
+  // (Dinv lower triangular: k-blocks above j' vanish)
   d4 outv[4][2];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
     for (int y = 0; y < 2; ++y) outv[x][y] = d4_zero();
+  if (32 * w < rows_valid) {
 #pragma unroll
-  for (int xp = 0; xp < 4; ++xp)
+    for (int xp = 0; xp < 4; ++xp)
 #pragma unroll
-    for (int x = 0; x <= xp; ++x)
+      for (int x = 0; x <= xp; ++x)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double av = s_dinv[(16 * xp + l15) * DI_LD + 16 * x + acc_row(l4, r)];
+        for (int r = 0; r < 4; ++r) {
+          const double av = -s_dinv[(16 * xp + l15) * DI_LD + 16 * x + acc_row(l4, r)];
 #pragma unroll
-        for (int y = 0; y < 2; ++y) {
-          d4 t = outv[xp][y];
-          // B operand: element k = 4 r + l4 of the 16-wide k block x is acc[x][y][r]
-          outv[xp][y] = mfma(av, acc[x][y][r], t);
+          for (int y = 0; y < 2; ++y) outv[xp][y] = mfma(av, acc[x][y][r], outv[xp][y]);
         }
-      }
+  }
 
-  // store through the row-tile buffer so that the global writes are 128-B row segments
+  // Store through the output buffer (128-B row segments) and, while each 16-column chunk of
+  // L[I,J] is in LDS in operand layout, accumulate the symmetric updates of the tile's own two
+  // diagonal blocks (lower tiles only).  Wave w -> sub-block sb = w >> 1; the 10 lower tiles of a
+  // sub-block are split 5 / 5: tile rows {0, 3} for even waves, {1, 2} for odd ones.
+  d4 upd[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) upd[a][b] = d4_zero();
+  const int sb = w >> 1;
+  const int t1[2] = {(w & 1) ? 1 : 0, (w & 1) ? 2 : 3};
 #pragma unroll
   for (int xp = 0; xp < 4; ++xp) {
     __syncthreads();
@@ -310,25 +327,55 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(double* __restrict__
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        s_rki[(32 * w + 16 * y + l15) * RK_LD + acc_row(l4, r)] = outv[xp][y][r];
+        s_out[(32 * w + 16 * y + l15) * RK_LD + acc_row(l4, r)] = outv[xp][y][r];
     __syncthreads();
     const int c = tid & 7, row = tid >> 3;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int rr = row + 32 * q;
       if (rr < rows_valid)
-        *reinterpret_cast<double2*>(M + (int64_t)(I0 + rr) * p_pad + J0 + 16 * xp + 2 * c) =
-            *reinterpret_cast<const double2*>(s_rki + rr * RK_LD + 2 * c);
+        *reinterpret_cast<v2d*>(M + (I0 + rr) * lda + J0 + 16 * xp + 2 * c) =
+            *reinterpret_cast<const v2d*>(s_out + rr * RK_LD + 2 * c);
     }
+    if (64 * sb >= rows_valid) continue;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double av[2], bv[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) av[a] = s_out[(64 * sb + 16 * t1[a] + l15) * RK_LD + 4 * kk + l4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = s_out[(64 * sb + 16 * b + l15) * RK_LD + 4 * kk + l4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (b <= t1[a]) upd[a][b] = mfma(av[a], bv[b], upd[a][b]);  // wave-uniform condition
+    }
+  }
+  // A[I',I'] -= L[I',J] L[I',J]^T on the sub-block's diagonal tile (owned by this workgroup alone)
+  if (64 * sb < rows_valid) {
+    double* D = M + (I0 + 64 * sb) * lda + I0 + 64 * sb;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (b > t1[a]) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * t1[a] + acc_row(l4, r), col = 16 * b + l15;
+          if (col <= row) D[row * lda + col] -= upd[a][b][r];
+        }
+      }
   }
 }
 
-hipError_t launch_chol_panel(double* A, const double* Dinv, int p_pad, int J, int n_mats, hipStream_t st) {
+hipError_t launch_chol_panel(double* A, const double* Dinv, int p_pad, int J, int n_mats, int flags,
+                             hipStream_t st) {
   const int nblk = p_pad / NB;
   if (p_pad % NB != 0 || J < 0 || J >= nblk - 1 || n_mats < 1) return hipErrorInvalidValue;
   const int rows_below = p_pad - (J + 1) * NB;
   dim3 grid((rows_below + 127) / 128, n_mats);
-  hipLaunchKernelGGL(chol_panel_kernel, grid, dim3(256), 0, st, A, Dinv, p_pad, J, nblk);
+  hipLaunchKernelGGL(chol_panel_kernel, grid, dim3(256), 0, st, A, Dinv, p_pad, J, nblk, flags);
   return hipGetLastError();
 }
 
@@ -347,15 +394,18 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int ord = blockIdx.y;
-  const int c0 = blockIdx.x * 128;
+  // x = ordering (fastest in dispatch order), y = strip: in tri mode strip 0 is the longest, so
+  // the long workgroups start first and the short ones fill the tail
+  const int ord = blockIdx.x;
+  const int c0 = blockIdx.y * 128;
   const int p = a.p, p_pad = a.p_pad, m_pad = a.m_pad;
   const int nblk = p_pad / NB;
   const int n_iblk = (p + NB - 1) / NB;
-  const double* L = a.A + (int64_t)ord * p_pad * p_pad;
-  const double* Lt = a.tri ? a.rhs + (int64_t)ord * p_pad * p_pad : nullptr;
+  const int64_t lda = lda_of(p_pad), ldv = ldv_of(m_pad);
+  const double* L = a.A + (int64_t)ord * p_pad * lda;
+  const double* Lt = a.tri ? a.rhs + (int64_t)ord * p_pad * lda : nullptr;
   const int32_t* perm = a.tri ? nullptr : a.perms + (int64_t)ord * p;
-  double* V = a.V + (int64_t)ord * n_iblk * NB * m_pad;
+  double* V = a.V + (int64_t)ord * n_iblk * NB * ldv;
 
   const int ib0 = a.tri ? c0 / NB : 0;
   const int kstart = a.tri ? c0 : 0;
@@ -363,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
     // rows above the strip's first diagonal block are structurally zero; later kernels read them
     for (int idx = tid; idx < ib0 * NB * 64; idx += 256) {
       const int row = idx >> 6, c2 = idx & 63;
-      *reinterpret_cast<double2*>(V + (int64_t)row * m_pad + c0 + 2 * c2) = make_double2(0.0, 0.0);
+      *reinterpret_cast<v2d*>(V + row * ldv + c0 + 2 * c2) = v2d{0.0, 0.0};
     }
   }
 
@@ -375,14 +425,14 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
 #pragma unroll
       for (int y = 0; y < 2; ++y) acc[x][y] = d4_zero();
 
-    const double* srcL = L + (int64_t)I0 * p_pad + kstart;
-    const double* srcV = V + (int64_t)kstart * m_pad + c0;
+    const double* srcL = L + I0 * lda + kstart;
+    const double* srcV = V + kstart * ldv + c0;
     const int nch = (I0 - kstart) / KCH;
     RKRegs<64> rl = {};
     KCRegs rv = {};
     if (nch > 0) {
-      rk_load<64>(rl, srcL, p_pad, tid, 64);
-      kc_load(rv, srcV, m_pad, tid);
+      rk_load<64>(rl, srcL, lda, tid, 64);
+      kc_load(rv, srcV, ldv, tid);
     }
     for (int c = 0; c < nch; ++c) {
       __syncthreads();
@@ -390,9 +440,11 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
       kc_store(rv, s_kc, tid);
       __syncthreads();
       if (c + 1 < nch) {
-        rk_load<64>(rl, srcL + (c + 1) * KCH, p_pad, tid, 64);
-        kc_load(rv, srcV + (int64_t)(c + 1) * KCH * m_pad, m_pad, tid);
+        rk_load<64>(rl, srcL + (c + 1) * KCH, lda, tid, 64);
+        kc_load(rv, srcV + (c + 1) * KCH * ldv, ldv, tid);
       }
+      // tri: V[k][c] = 0 for c > k, so columns c0+64.. (waves 2, 3) see only zeros while k < c0+64
+      if (a.tri && w >= 2 && c < 4 && !(a.flags & 1)) continue;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         double av[4], bv[2];
@@ -421,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
           const int c = c0 + 32 * w + 16 * y + l15;
           double rv0 = 0.0;
           if (a.tri) {
-            if (c < I0 + NB) rv0 = Lt[(int64_t)i * p_pad + c];
+            if (c < I0 + NB) rv0 = Lt[i * lda + c];
           } else {
             if (i < p) rv0 = a.rhs[(int64_t)perm[i] * m_pad + c];
           }
@@ -453,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
         const int i = I0 + 16 * xp + acc_row(l4, r);
 #pragma unroll
         for (int y = 0; y < 2; ++y)
-          V[(int64_t)i * m_pad + c0 + 32 * w + 16 * y + l15] = outv[xp][y][r];
+          V[i * ldv + c0 + 32 * w + 16 * y + l15] = outv[xp][y][r];
       }
     // the next block's k-loop reads these rows back (written by other waves of this workgroup)
     __threadfence_block();
@@ -465,7 +517,7 @@ hipError_t launch_strip(const StripArgs& a, hipStream_t st) {
   if (a.p < 1 || a.p_pad % NB != 0 || a.m_pad % 128 != 0 || a.n_ord < 1) return hipErrorInvalidValue;
   if (a.tri && a.m_pad > a.p_pad + 127) return hipErrorInvalidValue;
   if (!a.tri && a.perms == nullptr) return hipErrorInvalidValue;
-  dim3 grid(a.m_pad / 128, a.n_ord);
+  dim3 grid(a.n_ord, a.m_pad / 128);
   hipLaunchKernelGGL(strip_kernel, grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }

@@ -15,56 +15,59 @@
 
 namespace lsspa {
 
-// One wave per 64-column strip: lane = column, rows walked in order (the running N is a
-// scan down the rows); per 64-row tile the per-row dot products are reduced through LDS.
-__global__ __launch_bounds__(128) void lift_partial_kernel(LiftArgs a) {
-  __shared__ double s_E[2][64 * TT_LD];
-  __shared__ double s_z[2][64];
+// One wave per 64-column strip: lane = column, rows walked in order (the running N is a scan
+// down the rows).  Rows are taken 16 at a time: 16 independent coalesced loads, the scan in
+// registers, then the 16 per-row dot products are reduced through a small LDS tile.
+__global__ __launch_bounds__(256) void lift_partial_kernel(LiftArgs a) {
+  __shared__ double s_E[4][16 * TT_LD];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int ord = blockIdx.y;
-  const int strip = blockIdx.x * 2 + w;
+  const int ord = blockIdx.x;
+  const int strip = blockIdx.y * 4 + w;
   const int nstrips = a.m_pad / 64;
+  if (strip >= nstrips) return;  // whole wave leaves; no workgroup barrier below
   const int cs = strip * 64;
   const int p = a.p, p_pad = a.p_pad, m_pad = a.m_pad;
   const int n_iblk = (p + NB - 1) / NB;
-  const double* L = a.A + (int64_t)ord * p_pad * p_pad;
-  const double* zrow = L + (int64_t)p * p_pad;
-  const double* V = a.V + (int64_t)ord * n_iblk * NB * m_pad;
+  const int64_t lda = lda_of(p_pad), ldv = ldv_of(m_pad);
+  const double* L = a.A + (int64_t)ord * p_pad * lda;
+  const double* zrow = L + p * lda;
+  const double* V = a.V + (int64_t)ord * n_iblk * NB * ldv;
   double* Pp = a.Ppart + ((int64_t)ord * nstrips + strip) * p_pad;
   const int c = cs + lane;
   double yt;
   if (a.tri)
-    yt = (c < p) ? a.At[(int64_t)ord * p_pad * p_pad + (int64_t)p * p_pad + c] : 0.0;
+    yt = (c < p) ? a.At[(int64_t)ord * p_pad * lda + p * lda + c] : 0.0;
   else
     yt = a.ytil[c];
   double* E = s_E[w];
-  double* zs = s_z[w];
+  const int r16 = lane & 15, q4 = lane >> 4;
 
   double run = 0.0;
-  for (int jb = 0; jb < n_iblk; ++jb) {
-    const int j0 = jb * 64;
-    if (a.tri && j0 + 64 <= cs) {  // V is lower triangular: nothing in this strip yet
-      if (j0 + lane < p_pad) Pp[j0 + lane] = 0.0;
+  const int n_rows = n_iblk * 64;
+  for (int j0 = 0; j0 < n_rows; j0 += 16) {
+    if (a.tri && j0 + 16 <= cs) {  // V is lower triangular: nothing in this strip yet
+      if (lane < 16) Pp[j0 + lane] = 0.0;
       continue;
     }
-    zs[lane] = (j0 + lane < p) ? zrow[j0 + lane] : 0.0;
-    __builtin_amdgcn_wave_barrier();
-    for (int jj = 0; jj < 64; ++jj) {
-      const int j = j0 + jj;
-      double e = 0.0;
-      if (j < p) {
-        const double v = V[(int64_t)j * m_pad + c];
-        const double t = zs[jj] * v;
-        e = v * (2.0 * (yt - run) - t);
-        run += t;
-      }
-      E[jj * TT_LD + lane] = e;
+    double v[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) v[jj] = (j0 + jj < p) ? V[(j0 + jj) * ldv + c] : 0.0;
+    const double zl = (j0 + r16 < p) ? zrow[j0 + r16] : 0.0;  // lane r16 holds z[j0 + r16]
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const double zj = __shfl(zl, jj, 64);
+      const double t = zj * v[jj];
+      E[jj * TT_LD + lane] = v[jj] * (2.0 * (yt - run) - t);
+      run += t;
     }
     __builtin_amdgcn_wave_barrier();
+    // lane (r16, q4) sums columns 16 q4 .. 16 q4 + 15 of row r16, then the four quarters meet
     double s = 0.0;
-#pragma unroll 8
-    for (int cc = 0; cc < 64; ++cc) s += E[lane * TT_LD + cc];
-    Pp[j0 + lane] = s;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) s += E[r16 * TT_LD + 16 * q4 + cc];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 16) Pp[j0 + lane] = s;
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void lift_finish_kernel(LiftArgs a) {
   for (int k = 0; k < a.per_sample; ++k) {
     const int ord = sample * a.per_sample + k;
     const int32_t* perm = a.perms + (int64_t)ord * p;
-    const double* zrow = a.A + (int64_t)ord * p_pad * p_pad + (int64_t)p * p_pad;
+    const double* zrow = a.A + (int64_t)ord * p_pad * lda_of(p_pad) + p * lda_of(p_pad);
     const double* Pp = a.Ppart + (int64_t)ord * nstrips * p_pad;
     for (int j = threadIdx.x; j < p; j += 256) {
       double s = 0.0;
@@ -99,7 +102,7 @@ hipError_t launch_lift(const LiftArgs& a, hipStream_t st) {
   if (a.p < 1 || a.p_pad % NB != 0 || a.m_pad % 128 != 0 || a.n_ord < 1 ||
       (a.per_sample != 1 && a.per_sample != 2) || a.n_ord % a.per_sample != 0 || !(a.y_norm_sq > 0.0))
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL(lift_partial_kernel, dim3(a.m_pad / 128, a.n_ord), dim3(128), 0, st, a);
+  hipLaunchKernelGGL(lift_partial_kernel, dim3(a.n_ord, (a.m_pad / 64 + 3) / 4), dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(lift_finish_kernel, dim3(a.n_ord / a.per_sample), dim3(256), 0, st, a);
@@ -240,10 +243,11 @@ __global__ __launch_bounds__(1024) void backsolve_kernel(const double* __restric
   double* wv = reinterpret_cast<double*>(smem_raw);
   __shared__ double s_t;
   const int tid = threadIdx.x;
-  for (int i = tid; i < p; i += 1024) wv[i] = L[(int64_t)p * p_pad + i];
+  const int64_t lda = lda_of(p_pad);
+  for (int i = tid; i < p; i += 1024) wv[i] = L[p * lda + i];
   __syncthreads();
   for (int j = p - 1; j >= 0; --j) {
-    const double* row = L + (int64_t)j * p_pad;
+    const double* row = L + j * lda;
     if (tid == 0) {
       const double t = wv[j] / row[j];
       s_t = t;

@@ -20,7 +20,8 @@ hipError_t launch_gather(const GatherArgs& a, hipStream_t st);
 // one left-looking block step J of the batched Cholesky factorisation
 hipError_t launch_chol_diag(double* A, double* Dinv, int32_t* info, int p_pad, int J, int n_mats,
                             hipStream_t st);
-hipError_t launch_chol_panel(double* A, const double* Dinv, int p_pad, int J, int n_mats, hipStream_t st);
+hipError_t launch_chol_panel(double* A, const double* Dinv, int p_pad, int J, int n_mats, int flags,
+                             hipStream_t st);
 
 struct StripArgs {
   const double* A;         // factored train matrices, [n_ord][p_pad][p_pad]
@@ -29,6 +30,7 @@ struct StripArgs {
   const int32_t* perms;    // rect only
   double* V;               // [n_ord][n_iblk*64][m_pad]
   int p, p_pad, m_pad, n_ord, tri;
+  int flags;               // developer A/B switches
 };
 hipError_t launch_strip(const StripArgs& a, hipStream_t st);
 

@@ -58,6 +58,7 @@ struct lsspa_ctx {
   // running statistics
   DevBuf<double> mean, M2, pend, state_n;
   bool pend_dirty = false;
+  int flags = 0;
 
   // profiling
   bool prof_on = false;
@@ -222,7 +223,7 @@ int stats_reset(lsspa_ctx* ctx) {
 size_t bytes_per_ordering(const lsspa_ctx* ctx) {
   const size_t pp = ctx->p_pad, nblk = pp / NB, n_iblk = (ctx->p + NB - 1) / NB;
   const size_t nm = ctx->tri ? 2 : 1;
-  return nm * pp * pp * 8 + n_iblk * NB * (size_t)ctx->m_pad * 8 + nm * nblk * 4096 * 8 +
+  return nm * pp * (size_t)lda_of(ctx->p_pad) * 8 + n_iblk * NB * (size_t)ldv_of(ctx->m_pad) * 8 + nm * nblk * 4096 * 8 +
          (size_t)(ctx->m_pad / 64) * pp * 8 + (size_t)ctx->p * 4;
 }
 
@@ -246,8 +247,8 @@ int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
       dev_free(ctx->perms_d);
       const size_t pp = ctx->p_pad, nblk = pp / NB, n_iblk = (ctx->p + NB - 1) / NB;
       const size_t nm = ctx->tri ? 2 : 1;
-      TRY(dev_alloc(ctx, ctx->A, nm * cap * pp * pp));
-      TRY(dev_alloc(ctx, ctx->V, (size_t)cap * n_iblk * NB * ctx->m_pad));
+      TRY(dev_alloc(ctx, ctx->A, nm * cap * pp * (size_t)lda_of(ctx->p_pad)));
+      TRY(dev_alloc(ctx, ctx->V, (size_t)cap * n_iblk * NB * (size_t)ldv_of(ctx->m_pad)));
       TRY(dev_alloc(ctx, ctx->Dinv, nm * cap * nblk * 4096));
       TRY(dev_alloc(ctx, ctx->Ppart, (size_t)cap * (ctx->m_pad / 64) * pp));
       TRY(dev_alloc(ctx, ctx->perms_d, (size_t)cap * ctx->p));
@@ -303,7 +304,7 @@ int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
     }
     if (J + 1 < nblk) {
       ProfScope ps(ctx, LSSPA_K_CHOL_PANEL);
-      HIPCHK(launch_chol_panel(ctx->A.ptr, ctx->Dinv.ptr, p_pad, J, n_mats, ctx->stream));
+      HIPCHK(launch_chol_panel(ctx->A.ptr, ctx->Dinv.ptr, p_pad, J, n_mats, ctx->flags, ctx->stream));
     }
   }
   {
@@ -311,7 +312,7 @@ int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
     StripArgs sa;
     sa.A = ctx->A.ptr;
     sa.Dinv = ctx->Dinv.ptr;
-    sa.rhs = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * p_pad : ctx->Ft.ptr;
+    sa.rhs = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * (size_t)lda_of(p_pad) : ctx->Ft.ptr;
     sa.perms = ctx->perms_d.ptr;
     sa.V = ctx->V.ptr;
     sa.p = p;
@@ -319,13 +320,14 @@ int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
     sa.m_pad = m_pad;
     sa.n_ord = n_ord;
     sa.tri = ctx->tri;
+    sa.flags = ctx->flags;
     HIPCHK(launch_strip(sa, ctx->stream));
   }
   {
     ProfScope ps(ctx, LSSPA_K_LIFT);
     LiftArgs la;
     la.A = ctx->A.ptr;
-    la.At = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * p_pad : nullptr;
+    la.At = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * (size_t)lda_of(p_pad) : nullptr;
     la.ytil = ctx->tri ? nullptr : ctx->ytil.ptr;
     la.V = ctx->V.ptr;
     la.perms = ctx->perms_d.ptr;
@@ -681,9 +683,11 @@ int lsspa_get_factors(lsspa_ctx* ctx, double* R_tr, double* q_tr, double* F_te, 
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
-  const int p = ctx->p, pp = ctx->p_pad, m = ctx->m;
+  const int p = ctx->p, m = ctx->m;
+  const size_t pp = (size_t)lda_of(ctx->p_pad);   // row stride of the factor matrices
+  const size_t mat = (size_t)ctx->p_pad * pp;
   TRY(factor_identity(ctx, nullptr));
-  std::vector<double> L((size_t)pp * pp);
+  std::vector<double> L(mat);
   HIPCHK(hipMemcpy(L.data(), ctx->A.ptr, L.size() * 8, hipMemcpyDeviceToHost));
   if (R_tr)
     for (int a = 0; a < p; ++a)
@@ -693,7 +697,7 @@ int lsspa_get_factors(lsspa_ctx* ctx, double* R_tr, double* q_tr, double* F_te, 
   if (ctx->tri) {
     if (F_te || q_te) {
       // slot layout of run_orderings: the test matrices follow the n_ord = 1 train matrices
-      HIPCHK(hipMemcpy(L.data(), ctx->A.ptr + (size_t)pp * pp, L.size() * 8, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(L.data(), ctx->A.ptr + mat, L.size() * 8, hipMemcpyDeviceToHost));
       if (F_te)
         for (int a = 0; a < p; ++a)
           for (int b = 0; b < p; ++b) F_te[(size_t)a * p + b] = (b >= a) ? L[(size_t)b * pp + a] : 0.0;
@@ -837,6 +841,12 @@ int lsspa_profile_reset(lsspa_ctx* ctx) {
 }
 
 // ---------------------------------------------------------------------------------------------
+int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  ctx->flags = flags;
+  return LSSPA_OK;
+}
+
 int lsspa_mfma_probe(lsspa_ctx* ctx, const double* A16x4, const double* B4x16, double* D16x16) {
   if (!ctx || !A16x4 || !B4x16 || !D16x16) return LSSPA_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
@@ -865,9 +875,11 @@ int lsspa_debug_factor(lsspa_ctx* ctx, const int32_t* perm, double* L, double* L
   std::vector<char> seen;
   if (!is_permutation(perm, ctx->p, seen)) return ctx->fail(LSSPA_ERR_ARG, "perm is not a permutation");
   TRY(factor_identity(ctx, perm));
-  if (L) HIPCHK(hipMemcpy(L, ctx->A.ptr, pp * pp * 8, hipMemcpyDeviceToHost));
-  if (Lt && ctx->tri) HIPCHK(hipMemcpy(Lt, ctx->A.ptr + pp * pp, pp * pp * 8, hipMemcpyDeviceToHost));
-  if (V) HIPCHK(hipMemcpy(V, ctx->V.ptr, n_iblk * NB * ctx->m_pad * 8, hipMemcpyDeviceToHost));
+  const size_t lda = (size_t)lda_of(ctx->p_pad), ldv = (size_t)ldv_of(ctx->m_pad), mp = ctx->m_pad;
+  if (L) HIPCHK(hipMemcpy2D(L, pp * 8, ctx->A.ptr, lda * 8, pp * 8, pp, hipMemcpyDeviceToHost));
+  if (Lt && ctx->tri)
+    HIPCHK(hipMemcpy2D(Lt, pp * 8, ctx->A.ptr + pp * lda, lda * 8, pp * 8, pp, hipMemcpyDeviceToHost));
+  if (V) HIPCHK(hipMemcpy2D(V, mp * 8, ctx->V.ptr, ldv * 8, mp * 8, n_iblk * NB, hipMemcpyDeviceToHost));
   return LSSPA_OK;
 }
 

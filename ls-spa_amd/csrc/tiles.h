@@ -29,6 +29,12 @@ constexpr int KC_LD = 144;    // LDS row stride (doubles) of a [16 k][128 cols] 
                               // the two k rows of a 32-lane group on disjoint bank halves
 constexpr int DI_LD = 66;     // LDS row stride of a 64 x 64 block read as an A operand
 constexpr int TT_LD = 65;     // LDS row stride of the in-LDS elimination tiles (column walks)
+// Row strides of the per-ordering matrices in HBM.  p_pad and m_pad are multiples of 64 / 128, and
+// a power-of-two row stride sends every row of a tile to the same few memory channels; 32 extra
+// doubles (256 B, one channel-interleave granule) per row spread a tile's rows over the channels.
+constexpr int LD_PAD = 32;
+__host__ __device__ inline int64_t lda_of(int p_pad) { return (int64_t)p_pad + LD_PAD; }
+__host__ __device__ inline int64_t ldv_of(int m_pad) { return (int64_t)m_pad + LD_PAD; }
 
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);

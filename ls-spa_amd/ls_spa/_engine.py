@@ -196,6 +196,9 @@ class HipEngine:
             out[name] = (ms.value, cnt.value)
         return out
 
+    def set_flags(self, flags: int):
+        self._check(self._lib.lsspa_set_flags(self._h, int(flags)))
+
     def mfma_probe(self, A, B):
         A = np.ascontiguousarray(A, dtype=np.float64)
         B = np.ascontiguousarray(B, dtype=np.float64)

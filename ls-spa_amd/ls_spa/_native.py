@@ -54,6 +54,7 @@ SIGNATURES = {
     "lsspa_profile_enable": (C.c_int, [_vp, _i32]),
     "lsspa_profile_get": (C.c_int, [_vp, _i32, _pd, _pi64]),
     "lsspa_profile_reset": (C.c_int, [_vp]),
+    "lsspa_set_flags": (C.c_int, [_vp, _i32]),
     "lsspa_mfma_probe": (C.c_int, [_vp, _pd, _pd, _pd]),
     "lsspa_debug_factor": (C.c_int, [_vp, _pi32, _pd, _pd, _pd, _pi32, _pi32, _pi32]),
 }
@@ -61,6 +62,31 @@ SIGNATURES = {
 
 def library_path() -> str:
     return _LIB_PATH
+
+
+def _preload_hip_runtime():
+    """One process must not hold two HIP runtimes.  PyTorch-ROCm wheels bundle their own
+    libamdhip64; if that PyTorch is installed, bind to ITS runtime (without importing torch), so
+    that a later ``import torch`` -- bench.py and the torch.distributed layer do that -- finds the
+    runtime it expects already loaded instead of a second, system-wide one ("No HIP GPUs are
+    available").  Without PyTorch the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    cand = os.path.join(libdir, "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load():
@@ -72,6 +98,7 @@ def load():
         raise LSSPANativeError(
             f"{_LIB_PATH} is missing: build it with `python ls-spa_amd/build.py` "
             "(needs hipcc; there is no CPU fallback)")
+    _preload_hip_runtime()
     try:
         lib = C.CDLL(_LIB_PATH)
     except OSError as exc:  # e.g. libamdhip64 not found

@@ -31,15 +31,38 @@ rng = np.random.default_rng(0)
 perms = np.stack([rng.permutation(p) for _ in range(B)]).astype(np.int32)
 eng.run_batch(perms, True)  # warm-up (allocations)
 eng.merge(); eng.synchronize()
-eng.profile_reset()
+eng.profile(False)
 t0 = time.perf_counter()
 for s in range(steps):
     eng.run_batch(perms, True)
     eng.merge()
 eng.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print(f"batch of {B} antithetical samples: {1e3*dt:.2f} ms -> {2*B/dt:.0f} orderings/s")
+print(f"batch of {B} antithetical samples: {1e3*dt:.2f} ms -> {2*B/dt:.0f} orderings/s (no events)")
+eng.profile(True)
+eng.profile_reset()
+for s in range(steps):
+    eng.run_batch(perms, True)
+    eng.merge()
+eng.synchronize()
 for k, (ms, cnt) in eng.profile_read().items():
     if cnt: print(f"  {k:11s} {ms/steps:9.3f} ms/batch  ({cnt//steps} launches)")
+if len(sys.argv) > 5:
+    # in-process A/B of developer flag sets, interleaved rounds, per kernel class
+    sets = [int(x) for x in sys.argv[5].split(",")]
+    res = {f: [] for f in sets}
+    for rnd in range(4):
+        for f in sets:
+            eng.set_flags(f)
+            eng.profile_reset()
+            for s in range(3):
+                eng.run_batch(perms, True); eng.merge()
+            eng.synchronize()
+            pr = eng.profile_read()
+            res[f].append({k: v[0] / 3 for k, v in pr.items() if v[1]})
+    for f in sets:
+        keys = res[f][0].keys()
+        print("flags", f, {k: round(min(r[k] for r in res[f]), 3) for k in keys})
+    eng.set_flags(0)
 n, mean, cov = eng.stats()
 print("n", n, "sum(mean)", mean.sum(), "r2", r2)
