@@ -96,34 +96,31 @@ hipError_t launch_gather(const GatherArgs& a, hipStream_t st) {
 //                        then, while L[I,J] sits in LDS for its coalesced store, the two
 //                        diagonal tiles of the tile's own rows get  -= L[I',J] L[I',J]^T.
 // =====================================================================================
-__global__ __launch_bounds__(256, 2) void chol_diag_kernel(double* __restrict__ A, double* __restrict__ Dinv,
-                                                           int32_t* __restrict__ info, int p_pad, int J,
-                                                           int nblk) {
-  __shared__ double s_col[2][64];      // column k of T (unscaled), double-buffered by k parity
-  __shared__ double s_row[2][64];      // row k of Y
-  __shared__ double s_piv[2];
-  __shared__ double s_dd[64];
-  __shared__ int s_bad;
+// LDS scratch of the 64 x 64 elimination (2,600 B)
+struct ElimScratch {
+  double col[2][64];  // column k of T (unscaled), double-buffered by k parity
+  double row[2][64];  // row k of Y
+  double piv[2];
+  double dd[64];
+  int bad;
+};
 
-  const int tid = threadIdx.x;
-  const int mt = blockIdx.x;
-  const int64_t lda = lda_of(p_pad);
-  double* M = A + (int64_t)mt * p_pad * lda;
-  const int J0 = J * NB;
-
-  // Owner layout: thread (ty, tx) keeps T(ty + 16 a, tx + 16 c) and Y(ty + 16 a, tx + 16 c) in
-  // registers.  Elimination on [T | Y] without scaling: after step k column k of T is final
-  // (= L[:,k] * L[k][k]) and row k of Y is final (= (L^-1)[k,:] * L[k][k]).  Per step only
-  // column k of T, row k of Y and the pivot travel through LDS (one barrier per step).
+// Factor the 64 x 64 diagonal block at Mt (row stride lda, lower part meaningful) in place and
+// write its inverse to Dg.  256 threads.  Owner layout: thread (ty, tx) keeps T(ty + 16 a, tx + 16 c)
+// and Y(ty + 16 a, tx + 16 c) in registers.  Elimination on [T | Y] without scaling: after step k
+// column k of T is final (= L[:,k] * L[k][k]) and row k of Y is final (= (L^-1)[k,:] * L[k][k]).
+// Per step only column k of T, row k of Y and the pivot travel through LDS (one barrier per step).
+__device__ __forceinline__ void eliminate_block64(double* __restrict__ Mt, int64_t lda, double* __restrict__ Dg,
+                                                  int32_t* __restrict__ info, ElimScratch* sc, int tid) {
   const int ty = tid >> 4, tx = tid & 15;
   double T[4][4], Y[4][4];
-  if (tid == 0) s_bad = 0;
+  if (tid == 0) sc->bad = 0;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int row = ty + 16 * a, col = tx + 16 * c;
-      T[a][c] = (col <= row) ? M[(J0 + row) * lda + J0 + col] : 0.0;
+      T[a][c] = (col <= row) ? Mt[row * lda + col] : 0.0;
       Y[a][c] = (row == col) ? 1.0 : 0.0;
     }
 
@@ -135,58 +132,79 @@ __global__ __launch_bounds__(256, 2) void chol_diag_kernel(double* __restrict__ 
       const int buf = k & 1;
       if (tx == kk) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) s_col[buf][ty + 16 * a] = T[a][kc];
+        for (int a = 0; a < 4; ++a) sc->col[buf][ty + 16 * a] = T[a][kc];
       }
       if (ty == kk) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s_row[buf][tx + 16 * c] = Y[kc][c];
-        if (tx == kk) s_piv[buf] = T[kc][kc];
+        for (int c = 0; c < 4; ++c) sc->row[buf][tx + 16 * c] = Y[kc][c];
+        if (tx == kk) sc->piv[buf] = T[kc][kc];
       }
       __syncthreads();
-      double d = s_piv[buf];
+      double d = sc->piv[buf];
       if (!(d > 0.0)) {  // not positive definite (or NaN): flag it and keep going finitely
         d = 1.0;
-        if (tid == 0) s_bad = 1;
+        if (tid == 0) sc->bad = 1;
       }
-      if (tid == 0) s_dd[k] = d;
+      if (tid == 0) sc->dd[k] = d;
       const double invd = 1.0 / d;
       double cj[4], rc[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        cj[c] = s_col[buf][tx + 16 * c];
-        rc[c] = s_row[buf][tx + 16 * c];
+        cj[c] = sc->col[buf][tx + 16 * c];
+        rc[c] = sc->row[buf][tx + 16 * c];
       }
+      // kc is a compile-time constant here: row groups a < kc are finished (i <= k), column
+      // groups c < kc only carry Y updates (j <= k), column groups c > kc only T updates (j > k)
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
+        if (a < kc) continue;
         const int i = ty + 16 * a;
-        const double f = (i > k) ? s_col[buf][i] * invd : 0.0;
+        const double f = (i > k) ? sc->col[buf][i] * invd : 0.0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int j = tx + 16 * c;
-          if (j > k && j <= i) T[a][c] -= f * cj[c];
-          if (j <= k) Y[a][c] -= f * rc[c];
+          if (c < kc) {
+            Y[a][c] -= f * rc[c];
+          } else if (c > kc) {
+            if (c <= a && j <= i) T[a][c] -= f * cj[c];
+          } else {
+            if (j > k && j <= i) T[a][c] -= f * cj[c];
+            if (j <= k) Y[a][c] -= f * rc[c];
+          }
         }
       }
     }
   }
   __syncthreads();
-  if (tid < 64) s_dd[tid] = 1.0 / sqrt(s_dd[tid]);  // now holds 1 / L[k][k]
+  if (tid < 64) sc->dd[tid] = 1.0 / sqrt(sc->dd[tid]);  // now holds 1 / L[k][k]
   __syncthreads();
 
-  double* Dg = Dinv + ((int64_t)mt * nblk + J) * 4096;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int row = ty + 16 * a, col = tx + 16 * c;
       double lv = 0.0, xv = 0.0;
-      if (col < row) lv = T[a][c] * s_dd[col];
-      if (col == row) lv = 1.0 / s_dd[col];
-      if (col <= row) xv = Y[a][c] * s_dd[row];
-      M[(J0 + row) * lda + J0 + col] = lv;
+      if (col < row) lv = T[a][c] * sc->dd[col];
+      if (col == row) lv = 1.0 / sc->dd[col];
+      if (col <= row) xv = Y[a][c] * sc->dd[row];
+      Mt[row * lda + col] = lv;
       Dg[row * 64 + col] = xv;
     }
-  if (tid == 0 && s_bad) atomicOr(&info[0], 1);
+  if (tid == 0 && sc->bad) atomicOr(&info[0], 1);
+}
+
+// Stand-alone launch: only block 0 needs it (later diagonal blocks are factored by the panel
+// workgroup that applied their last update).
+__global__ __launch_bounds__(256, 2) void chol_diag_kernel(double* __restrict__ A, double* __restrict__ Dinv,
+                                                           int32_t* __restrict__ info, int p_pad, int J,
+                                                           int nblk) {
+  __shared__ ElimScratch sc;
+  const int mt = blockIdx.x;
+  const int64_t lda = lda_of(p_pad);
+  double* M = A + (int64_t)mt * p_pad * lda;
+  const int J0 = J * NB;
+  eliminate_block64(M + J0 * lda + J0, lda, Dinv + ((int64_t)mt * nblk + J) * 4096, info, &sc, threadIdx.x);
 }
 
 hipError_t launch_chol_diag(double* A, double* Dinv, int32_t* info, int p_pad, int J, int n_mats,
@@ -200,14 +218,15 @@ hipError_t launch_chol_diag(double* A, double* Dinv, int32_t* info, int p_pad, i
 // The accumulators hold -C^T: they start at -A[I,J]^T (each wave stages its own 32 rows through
 // its slice of the output buffer, coalesced, no workgroup barrier) and collect +L[J,K] L[I,K]^T.
 // -C^T is exactly the B operand of (L_JJ^-1) * C^T: no LDS round trip between the two products.
-__global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__ A,
-                                                            const double* __restrict__ Dinv, int p_pad,
-                                                            int J, int nblk, int flags) {
+__global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__ A, double* __restrict__ Dinv,
+                                                            int32_t* __restrict__ info, int p_pad, int J,
+                                                            int nblk, int flags) {
   // LDS: 52,224 B, so that three workgroups fit one CU.  Region A holds the two operand tiles
   // of the main loop and, after it, L_JJ^-1; region B is the output / update staging tile.
   __shared__ __attribute__((aligned(16))) double s_a[64 * DI_LD];
   __shared__ __attribute__((aligned(16))) double s_b[128 * RK_LD];
   static_assert(64 * DI_LD >= 64 * RK_LD + 128 * RK_LD, "operand tiles must fit region A");
+  static_assert(sizeof(ElimScratch) <= sizeof(double) * 64 * DI_LD, "elimination scratch must fit region A");
   double* const s_rkj = s_a;
   double* const s_rki = s_a + 64 * RK_LD;
   double* const s_dinv = s_a;
@@ -215,11 +234,14 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int mt = blockIdx.y;
+  // x = matrix (fastest in dispatch order), y = row tile: the tile-0 workgroups, which also factor
+  // the next diagonal block, start first
+  const int mt = blockIdx.x;
+  const int tile = blockIdx.y;
   const int64_t lda = lda_of(p_pad);
   double* M = A + (int64_t)mt * p_pad * lda;
   const int J0 = J * NB;
-  const int I0 = J0 + NB + blockIdx.x * 128;
+  const int I0 = J0 + NB + tile * 128;
   const int rows_valid = min(128, p_pad - I0);
 
   const double* srcJ = M + J0 * lda;
@@ -367,15 +389,25 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
         }
       }
   }
+
+  // Tile 0 starts at block row J + 1: its first diagonal block has just received its last update,
+  // so this workgroup factors it right away (no separate launch, and the latency-bound sweep
+  // overlaps with the other workgroups' MFMA work).
+  if (tile == 0 && !(flags & 2)) {
+    __threadfence_block();
+    __syncthreads();  // the update above was written by waves 0 and 1; region A is free again
+    eliminate_block64(M + I0 * lda + I0, lda, Dinv + ((int64_t)mt * nblk + J + 1) * 4096, info,
+                      reinterpret_cast<ElimScratch*>(s_a), tid);
+  }
 }
 
-hipError_t launch_chol_panel(double* A, const double* Dinv, int p_pad, int J, int n_mats, int flags,
+hipError_t launch_chol_panel(double* A, double* Dinv, int32_t* info, int p_pad, int J, int n_mats, int flags,
                              hipStream_t st) {
   const int nblk = p_pad / NB;
   if (p_pad % NB != 0 || J < 0 || J >= nblk - 1 || n_mats < 1) return hipErrorInvalidValue;
   const int rows_below = p_pad - (J + 1) * NB;
-  dim3 grid((rows_below + 127) / 128, n_mats);
-  hipLaunchKernelGGL(chol_panel_kernel, grid, dim3(256), 0, st, A, Dinv, p_pad, J, nblk, flags);
+  dim3 grid(n_mats, (rows_below + 127) / 128);
+  hipLaunchKernelGGL(chol_panel_kernel, grid, dim3(256), 0, st, A, Dinv, info, p_pad, J, nblk, flags);
   return hipGetLastError();
 }
 

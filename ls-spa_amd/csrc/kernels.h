@@ -20,7 +20,8 @@ hipError_t launch_gather(const GatherArgs& a, hipStream_t st);
 // one left-looking block step J of the batched Cholesky factorisation
 hipError_t launch_chol_diag(double* A, double* Dinv, int32_t* info, int p_pad, int J, int n_mats,
                             hipStream_t st);
-hipError_t launch_chol_panel(double* A, const double* Dinv, int p_pad, int J, int n_mats, int flags,
+// panel step J; unless flags & 2, its tile-0 workgroups also factor diagonal block J + 1
+hipError_t launch_chol_panel(double* A, double* Dinv, int32_t* info, int p_pad, int J, int n_mats, int flags,
                              hipStream_t st);
 
 struct StripArgs {

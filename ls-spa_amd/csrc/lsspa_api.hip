@@ -52,7 +52,12 @@ struct lsspa_ctx {
   int cap_samples = 0;  // samples the lifts buffer can hold
   DevBuf<double> A, V, Dinv, Ppart, lifts;
   DevBuf<int32_t> perms_d, info_d;
-  int32_t* perms_h = nullptr;  // pinned staging
+  // pinned staging of the orderings: two buffers in turn, each guarded by the event of its last
+  // H2D copy, so the host can prepare batch k+1 while the GPU still runs batch k (no stream sync)
+  int32_t* perms_h[2] = {nullptr, nullptr};
+  hipEvent_t perms_ev[2] = {nullptr, nullptr};
+  bool perms_busy[2] = {false, false};
+  int perms_turn = 0;
   size_t perms_h_count = 0;
 
   // running statistics
@@ -181,6 +186,7 @@ __global__ void sumsq_kernel(const double* __restrict__ v, int n, double* __rest
 int set_dims(lsspa_ctx* ctx, int p, int m, int tri) {
   if (p < 1 || m < 1) return ctx->fail(LSSPA_ERR_ARG, "p and m must be positive");
   if (tri && m != p) return ctx->fail(LSSPA_ERR_ARG, "tri mode needs m == p");
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // buffers below may be re-allocated
   ctx->have_problem = false;
   ctx->p = p;
   ctx->m = m;
@@ -229,6 +235,8 @@ size_t bytes_per_ordering(const lsspa_ctx* ctx) {
 
 int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
   want_ord = (want_ord + 1) & ~1;  // antithetical pairs stay together
+  if (want_ord > ctx->cap_ord || want_samples > ctx->cap_samples)
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // work in flight still uses the old buffers
   if (want_ord > ctx->cap_ord) {
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -236,7 +244,7 @@ int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
     const size_t per = bytes_per_ordering(ctx);
     size_t budget = (size_t)(0.85 * (double)free_b) + (size_t)ctx->cap_ord * per;
     int cap = (int)std::min<size_t>((size_t)want_ord, budget / per);
-    cap = std::min(cap, 1024);
+    cap = std::min(cap, 4096);
     cap &= ~1;  // keep antithetical pairs together
     if (cap < 2) return ctx->fail(LSSPA_ERR_NOMEM, "not enough device memory for two orderings");
     if (cap > ctx->cap_ord) {
@@ -264,11 +272,16 @@ int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
 
 int ensure_pinned(lsspa_ctx* ctx, size_t count) {
   if (ctx->perms_h_count >= count) return LSSPA_OK;
-  if (ctx->perms_h) (void)hipHostFree(ctx->perms_h);
-  ctx->perms_h = nullptr;
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // pending copies still read the old buffers
   ctx->perms_h_count = 0;
-  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ctx->perms_h), count * sizeof(int32_t), 0);
-  if (e != hipSuccess) return ctx->fail(LSSPA_ERR_NOMEM, "hipHostMalloc", e);
+  for (int b = 0; b < 2; ++b) {
+    if (ctx->perms_h[b]) (void)hipHostFree(ctx->perms_h[b]);
+    ctx->perms_h[b] = nullptr;
+    ctx->perms_busy[b] = false;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ctx->perms_h[b]), count * sizeof(int32_t), 0);
+    if (e != hipSuccess) return ctx->fail(LSSPA_ERR_NOMEM, "hipHostMalloc", e);
+    if (!ctx->perms_ev[b]) HIPCHK(hipEventCreateWithFlags(&ctx->perms_ev[b], hipEventDisableTiming));
+  }
   ctx->perms_h_count = count;
   return LSSPA_OK;
 }
@@ -297,14 +310,16 @@ int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
     ga.A = ctx->A.ptr;
     HIPCHK(launch_gather(ga, ctx->stream));
   }
+  const bool fused = !(ctx->flags & 2);  // panel step J also factors diagonal block J + 1
   for (int J = 0; J < nblk; ++J) {
-    {
+    if (J == 0 || !fused) {
       ProfScope ps(ctx, LSSPA_K_CHOL_DIAG);
       HIPCHK(launch_chol_diag(ctx->A.ptr, ctx->Dinv.ptr, ctx->info_d.ptr, p_pad, J, n_mats, ctx->stream));
     }
     if (J + 1 < nblk) {
       ProfScope ps(ctx, LSSPA_K_CHOL_PANEL);
-      HIPCHK(launch_chol_panel(ctx->A.ptr, ctx->Dinv.ptr, p_pad, J, n_mats, ctx->flags, ctx->stream));
+      HIPCHK(launch_chol_panel(ctx->A.ptr, ctx->Dinv.ptr, ctx->info_d.ptr, p_pad, J, n_mats, ctx->flags,
+                               ctx->stream));
     }
   }
   {
@@ -349,7 +364,13 @@ int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
 int stage_and_run(lsspa_ctx* ctx, const int32_t* perms, int n_samples, int per_sample, int s_off) {
   const int p = ctx->p;
   const int n_ord = n_samples * per_sample;
-  int32_t* hp = ctx->perms_h;
+  const int turn = ctx->perms_turn;
+  ctx->perms_turn ^= 1;
+  if (ctx->perms_busy[turn]) {  // the copy that last read this buffer must have run
+    HIPCHK(hipEventSynchronize(ctx->perms_ev[turn]));
+    ctx->perms_busy[turn] = false;
+  }
+  int32_t* hp = ctx->perms_h[turn];
   for (int s = 0; s < n_samples; ++s) {
     const int32_t* src = perms + (size_t)s * p;
     int32_t* d0 = hp + (size_t)s * per_sample * p;
@@ -365,10 +386,9 @@ int stage_and_run(lsspa_ctx* ctx, const int32_t* perms, int n_samples, int per_s
   }
   HIPCHK(hipMemcpyAsync(ctx->perms_d.ptr, hp, sizeof(int32_t) * (size_t)n_ord * p, hipMemcpyHostToDevice,
                         ctx->stream));
-  TRY(run_orderings(ctx, n_ord, per_sample, s_off));
-  // the pinned buffer is rewritten by the next sub-batch
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  return LSSPA_OK;
+  HIPCHK(hipEventRecord(ctx->perms_ev[turn], ctx->stream));
+  ctx->perms_busy[turn] = true;
+  return run_orderings(ctx, n_ord, per_sample, s_off);
 }
 
 bool is_permutation(const int32_t* perm, int p, std::vector<char>& seen) {
@@ -444,7 +464,10 @@ int lsspa_destroy(lsspa_ctx* ctx) {
   dev_free(ctx->ytil); dev_free(ctx->scal); dev_free(ctx->A); dev_free(ctx->V); dev_free(ctx->Dinv);
   dev_free(ctx->Ppart); dev_free(ctx->lifts); dev_free(ctx->perms_d); dev_free(ctx->info_d);
   dev_free(ctx->mean); dev_free(ctx->M2); dev_free(ctx->pend); dev_free(ctx->state_n);
-  if (ctx->perms_h) (void)hipHostFree(ctx->perms_h);
+  for (int b = 0; b < 2; ++b) {
+    if (ctx->perms_h[b]) (void)hipHostFree(ctx->perms_h[b]);
+    if (ctx->perms_ev[b]) (void)hipEventDestroy(ctx->perms_ev[b]);
+  }
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return LSSPA_OK;
@@ -644,7 +667,9 @@ static int factor_identity(lsspa_ctx* ctx, const int32_t* perm_or_null) {
   TRY(ensure_pinned(ctx, (size_t)2 * p));
   std::vector<int32_t> id(p);
   for (int j = 0; j < p; ++j) id[j] = perm_or_null ? perm_or_null[j] : j;
-  return stage_and_run(ctx, id.data(), 1, 1, 0);
+  TRY(stage_and_run(ctx, id.data(), 1, 1, 0));
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // callers read results with blocking copies
+  return LSSPA_OK;
 }
 
 int lsspa_full_fit(lsspa_ctx* ctx, double* theta, double* r_squared, int32_t* info) {
@@ -732,7 +757,10 @@ int lsspa_lift_batch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t an
       if (!is_permutation(perms + (size_t)s * p, p, seen))
         return ctx->fail(LSSPA_ERR_ARG, "perms: a row is not a permutation of 0..p-1");
   }
-  TRY(ensure_workspace(ctx, std::min(B * per, 512), B));
+  // orderings per launch sequence: everything at once up to ~8 GB of workspace or 4096 orderings
+  const size_t per_ord = bytes_per_ordering(ctx);
+  const int want = (int)std::max<size_t>(2, std::min<size_t>(4096, ((size_t)8 << 30) / per_ord));
+  TRY(ensure_workspace(ctx, std::min(B * per, std::max(want, 512)), B));
   const int sub = std::max(1, ctx->cap_ord / per);
   TRY(ensure_pinned(ctx, (size_t)std::min(sub, (int)B) * per * p));
   for (int s0 = 0; s0 < B; s0 += sub) {
