@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void lift_partial_kernel(LiftArgs a) {
   const int64_t lda = lda_of(p_pad), ldv = ldv_of(m_pad);
   const double* L = a.A + (int64_t)ord * p_pad * lda;
   const double* zrow = L + p * lda;
-  const double* V = a.V + (int64_t)ord * n_iblk * NB * ldv;
+  const double* V = a.V + (int64_t)ord * v_rows_of(p) * ldv;
   double* Pp = a.Ppart + ((int64_t)ord * nstrips + strip) * p_pad;
   const int c = cs + lane;
   double yt;

@@ -229,7 +229,9 @@ int stats_reset(lsspa_ctx* ctx) {
 size_t bytes_per_ordering(const lsspa_ctx* ctx) {
   const size_t pp = ctx->p_pad, nblk = pp / NB, n_iblk = (ctx->p + NB - 1) / NB;
   const size_t nm = ctx->tri ? 2 : 1;
-  return nm * pp * (size_t)lda_of(ctx->p_pad) * 8 + n_iblk * NB * (size_t)ldv_of(ctx->m_pad) * 8 + nm * nblk * 4096 * 8 +
+  (void)n_iblk;
+  return nm * pp * (size_t)lda_of(ctx->p_pad) * 8 + (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad) * 8 +
+         nm * nblk * 4096 * 8 +
          (size_t)(ctx->m_pad / 64) * pp * 8 + (size_t)ctx->p * 4;
 }
 
@@ -256,7 +258,8 @@ int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
       const size_t pp = ctx->p_pad, nblk = pp / NB, n_iblk = (ctx->p + NB - 1) / NB;
       const size_t nm = ctx->tri ? 2 : 1;
       TRY(dev_alloc(ctx, ctx->A, nm * cap * pp * (size_t)lda_of(ctx->p_pad)));
-      TRY(dev_alloc(ctx, ctx->V, (size_t)cap * n_iblk * NB * (size_t)ldv_of(ctx->m_pad)));
+      (void)n_iblk;
+      TRY(dev_alloc(ctx, ctx->V, (size_t)cap * (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad)));
       TRY(dev_alloc(ctx, ctx->Dinv, nm * cap * nblk * 4096));
       TRY(dev_alloc(ctx, ctx->Ppart, (size_t)cap * (ctx->m_pad / 64) * pp));
       TRY(dev_alloc(ctx, ctx->perms_d, (size_t)cap * ctx->p));

@@ -35,12 +35,35 @@ constexpr int TT_LD = 65;     // LDS row stride of the in-LDS elimination tiles 
 constexpr int LD_PAD = 32;
 __host__ __device__ inline int64_t lda_of(int p_pad) { return (int64_t)p_pad + LD_PAD; }
 __host__ __device__ inline int64_t ldv_of(int m_pad) { return (int64_t)m_pad + LD_PAD; }
+// rows of a V matrix: the ordering's row blocks rounded up to the 128-row strip step
+__host__ __device__ inline int64_t v_rows_of(int p) { return (int64_t)((p + 127) / 128) * 128; }
 
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 // row of an accumulator element inside its 16 x 16 tile
 __device__ __forceinline__ int acc_row(int l4, int r) { return l4 + 4 * r; }
+
+// ---- v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction ------------------
+// Measured on gfx950 (tools/mfma_bench3.hip): 16.5 cycles per instruction = 32 flop/clk/SIMD
+// (the vendor fp64 rate, 70-76 TFLOP/s sustained), against ~99 cycles per 2048-flop 16x16x4
+// instruction (47 TFLOP/s).  Lane maps, probed with one-hot operands (tools/mfma_probe4.hip), with
+// lane l = 16 q + 4 g + t:   A_g[i = t][k = q],  B_g[k = q][j = t],  D_g[i = q][j = t]   (block = g);
+// CBSZ / ABID broadcast has no effect for f64.
+//
+// A 16x16x4 step is done as four of them ("rotations" s = 0..3): with
+//   a   (lane) = A16[4 g + t][q]                       -- the same register the 16x16x4 form takes
+//   b_s (lane) = B16[q][4 ((g + s) & 3) + t]
+// acc_s (lane) accumulates D16[4 g + q][4 ((g + s) & 3) + t].
+__device__ __forceinline__ double mfma4(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc4_row(int lane) { return 4 * ((lane >> 2) & 3) + (lane >> 4); }
+__device__ __forceinline__ int acc4_col(int lane, int s) { return 4 * ((((lane >> 2) & 3) + s) & 3) + (lane & 3); }
+// value of v held by the lane whose block index is (g + u) & 3 (same q, t)
+__device__ __forceinline__ double rot_blocks(double v, int lane, int u) {
+  return __shfl(v, (lane & 48) | ((lane + 4 * u) & 15), 64);
+}
 
 __device__ __forceinline__ d4 d4_zero() {
   d4 z = {0.0, 0.0, 0.0, 0.0};
@@ -99,10 +122,11 @@ __device__ __forceinline__ void kc_store(const KCRegs& r, double* lds, int tid) 
 }
 
 // copy a dense 64 x 64 block (row-major, ld 64) from global into LDS with stride DI_LD
+template <int NT = 256>
 __device__ __forceinline__ void load_block64(double* lds, const double* __restrict__ g, int tid) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int idx = tid + 256 * q;  // double2 index, 2048 in all
+  for (int q = 0; q < 2048 / NT; ++q) {
+    const int idx = tid + NT * q;  // 16-byte piece index, 2048 in all
     const int row = idx >> 5, c2 = idx & 31;
     *reinterpret_cast<v2d*>(lds + row * DI_LD + 2 * c2) =
         *reinterpret_cast<const v2d*>(g + row * 64 + 2 * c2);
