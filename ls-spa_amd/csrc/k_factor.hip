@@ -401,230 +401,13 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
   }
 }
 
-// Production form of the panel step on the 4x4x4 fp64 MFMA (tiles.h; the 16x16x4 form above is kept
-// as the A/B reference).  Accumulator rotation s of tile (x, y) holds element
-// (j = 16 x + acc4_row, i = 32 w + 16 y + acc4_col(s)) of -C^T.
-// The accumulators hold -C^T: they start at -A[I,J]^T (each wave stages its own 32 rows through
-// its slice of the output buffer, coalesced, no workgroup barrier) and collect +L[J,K] L[I,K]^T.
-// -C^T is exactly the B operand of (L_JJ^-1) * C^T: no LDS round trip between the two products.
-__global__ __launch_bounds__(256, 2) void chol_panel4_kernel(double* __restrict__ A, double* __restrict__ Dinv,
-                                                            int32_t* __restrict__ info, int p_pad, int J,
-                                                            int nblk, int flags) {
-  // LDS: 52,224 B, so that three workgroups fit one CU.  Region A holds the two operand tiles
-  // of the main loop and, after it, L_JJ^-1; region B is the output / update staging tile.
-  __shared__ __attribute__((aligned(16))) double s_a[64 * DI_LD];
-  __shared__ __attribute__((aligned(16))) double s_b[128 * RK_LD];
-  static_assert(64 * DI_LD >= 64 * RK_LD + 128 * RK_LD, "operand tiles must fit region A");
-  static_assert(sizeof(ElimScratch) <= sizeof(double) * 64 * DI_LD, "elimination scratch must fit region A");
-  double* const s_rkj = s_a;
-  double* const s_rki = s_a + 64 * RK_LD;
-  double* const s_dinv = s_a;
-  double* const s_out = s_b;
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int l15 = lane & 15, q = lane >> 4, g = (lane >> 2) & 3;
-  const int arow = acc4_row(lane);
-  int acol[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) acol[s] = acc4_col(lane, s);
-  // x = matrix (fastest in dispatch order), y = row tile: the tile-0 workgroups, which also factor
-  // the next diagonal block, start first
-  const int mt = blockIdx.x;
-  const int tile = blockIdx.y;
-  const int64_t lda = lda_of(p_pad);
-  double* M = A + (int64_t)mt * p_pad * lda;
-  const int J0 = J * NB;
-  const int I0 = J0 + NB + tile * 128;
-  const int rows_valid = min(128, p_pad - I0);
-
-  const double* srcJ = M + J0 * lda;
-  const double* srcI = M + I0 * lda;
-
-  const int nch = J0 / KCH;
-  RKRegs<64> rj = {};
-  RKRegs<128> ri = {};
-  if (nch > 0) {
-    rk_load<64>(rj, srcJ, lda, tid, 64);
-    rk_load<128>(ri, srcI, lda, tid, rows_valid);
-  }
-
-  double acc[4][2][4];
-  {
-    const int rr = lane >> 3, ch = lane & 7;  // 8 rows x 8 16-byte chunks per wave instruction
-    v2d t[4][4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = 32 * w + rr + 8 * q;
-        t[x][q] = (i < rows_valid) ? *reinterpret_cast<const v2d*>(srcI + i * lda + J0 + 16 * x + 2 * ch)
-                                   : v2d{0.0, 0.0};
-      }
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<v2d*>(s_out + (32 * w + rr + 8 * q) * RK_LD + 2 * ch) = t[x][q];
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[x][y][s] = -s_out[(32 * w + 16 * y + acol[s]) * RK_LD + arow];
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-
-  for (int c = 0; c < nch; ++c) {
-    __syncthreads();
-    rk_store<64>(rj, s_rkj, tid);
-    rk_store<128>(ri, s_rki, tid);
-    __syncthreads();
-    if (c + 1 < nch) {
-      rk_load<64>(rj, srcJ + (c + 1) * KCH, lda, tid, 64);
-      rk_load<128>(ri, srcI + (c + 1) * KCH, lda, tid, rows_valid);
-    }
-    if (32 * w >= rows_valid) continue;  // half tile at the bottom: this wave's rows do not exist
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      double av[4], bv[2][4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) av[x] = s_rkj[(16 * x + l15) * RK_LD + 4 * kk + q];
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) bv[y][s] = s_rki[(32 * w + 16 * y + acol[s]) * RK_LD + 4 * kk + q];
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) acc[x][y][s] = mfma4(av[x], bv[y][s], acc[x][y][s]);
-    }
-  }
-
-  __syncthreads();  // every wave is done with the operand tiles that L_JJ^-1 now overwrites
-  load_block64(s_dinv, Dinv + ((int64_t)mt * nblk + J) * 4096, tid);
-  __syncthreads();
-
-  // out^T[j'][i] = sum_k Dinv[j'][k] C[i][k] = sum_k (-Dinv[j'][k]) acc[k][i]
-  // (Dinv lower triangular: k-blocks above j' vanish)
-  // block g of an accumulator register only holds 4 of the tile's 16 j-rows; the other three row
-  // groups come from the neighbouring blocks by a lane rotation (u = 1..3)
-  double outv[4][2][4];
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 2; ++y)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) outv[x][y][s] = 0.0;
-  if (32 * w < rows_valid) {
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        double am[4];
-#pragma unroll
-        for (int xp = x; xp < 4; ++xp)
-          am[xp] = -s_dinv[(16 * xp + l15) * DI_LD + 16 * x + 4 * ((g + u) & 3) + q];
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const double r = (u == 0) ? acc[x][y][s] : rot_blocks(acc[x][y][s], lane, u);
-#pragma unroll
-            for (int xp = x; xp < 4; ++xp)
-              outv[xp][y][(s + u) & 3] = mfma4(am[xp], r, outv[xp][y][(s + u) & 3]);
-          }
-      }
-  }
-
-  // Store through the output buffer (128-B row segments) and, while each 16-column chunk of
-  // L[I,J] is in LDS in operand layout, accumulate the symmetric updates of the tile's own two
-  // diagonal blocks (lower tiles only).  Wave w -> sub-block sb = w >> 1; the 10 lower tiles of a
-  // sub-block are split 5 / 5: tile rows {0, 3} for even waves, {1, 2} for odd ones.
-  double upd[2][4][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) upd[a][b][s] = 0.0;
-  const int sb = w >> 1;
-  const int t1[2] = {(w & 1) ? 1 : 0, (w & 1) ? 2 : 3};
-#pragma unroll
-  for (int xp = 0; xp < 4; ++xp) {
-    __syncthreads();
-#pragma unroll
-    for (int y = 0; y < 2; ++y)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) s_out[(32 * w + 16 * y + acol[s]) * RK_LD + arow] = outv[xp][y][s];
-    __syncthreads();
-    const int c = tid & 7, row = tid >> 3;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int rr = row + 32 * q;
-      if (rr < rows_valid)
-        *reinterpret_cast<v2d*>(M + (I0 + rr) * lda + J0 + 16 * xp + 2 * c) =
-            *reinterpret_cast<const v2d*>(s_out + rr * RK_LD + 2 * c);
-    }
-    if (64 * sb >= rows_valid) continue;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      double av[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) av[a] = s_out[(64 * sb + 16 * t1[a] + l15) * RK_LD + 4 * kk + q];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (b > t1[1]) continue;  // wave-uniform: no tile row of this wave reaches column tile b
-        double bv[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) bv[s] = s_out[(64 * sb + 16 * b + acol[s]) * RK_LD + 4 * kk + q];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          if (b > t1[a]) continue;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) upd[a][b][s] = mfma4(av[a], bv[s], upd[a][b][s]);
-        }
-      }
-    }
-  }
-  // A[I',I'] -= L[I',J] L[I',J]^T on the sub-block's diagonal tile (owned by this workgroup alone)
-  if (64 * sb < rows_valid) {
-    double* D = M + (I0 + 64 * sb) * lda + I0 + 64 * sb;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (b > t1[a]) continue;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int row = 16 * t1[a] + arow, col = 16 * b + acol[s];
-          if (col <= row) D[row * lda + col] -= upd[a][b][s];
-        }
-      }
-  }
-
-  // Tile 0 starts at block row J + 1: its first diagonal block has just received its last update,
-  // so this workgroup factors it right away (no separate launch, and the latency-bound sweep
-  // overlaps with the other workgroups' MFMA work).
-  if (tile == 0 && !(flags & 2)) {
-    __threadfence_block();
-    __syncthreads();  // the update above was written by waves 0 and 1; region A is free again
-    eliminate_block64(M + I0 * lda + I0, lda, Dinv + ((int64_t)mt * nblk + J + 1) * 4096, info,
-                      reinterpret_cast<ElimScratch*>(s_a), tid);
-  }
-}
-
 hipError_t launch_chol_panel(double* A, double* Dinv, int32_t* info, int p_pad, int J, int n_mats, int flags,
                              hipStream_t st) {
   const int nblk = p_pad / NB;
   if (p_pad % NB != 0 || J < 0 || J >= nblk - 1 || n_mats < 1) return hipErrorInvalidValue;
   const int rows_below = p_pad - (J + 1) * NB;
   dim3 grid(n_mats, (rows_below + 127) / 128);
-  if (flags & 128)
-    hipLaunchKernelGGL(chol_panel_kernel, grid, dim3(256), 0, st, A, Dinv, info, p_pad, J, nblk, flags);
-  else
-    hipLaunchKernelGGL(chol_panel4_kernel, grid, dim3(256), 0, st, A, Dinv, info, p_pad, J, nblk, flags);
+  hipLaunchKernelGGL(chol_panel_kernel, grid, dim3(256), 0, st, A, Dinv, info, p_pad, J, nblk, flags);
   return hipGetLastError();
 }
 
@@ -762,419 +545,12 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
   }
 }
 
-// Same algorithm on the 4x4x4 fp64 MFMA (see tiles.h): 1.6x the issue rate of the 16x16x4 form.
-// Accumulator rotation s of tile (x, y) holds element (row 16 x + acc4_row, col 16 y + acc4_col(s)).
-// For the second product out = L_II^-1 * C the accumulators are again the B operand; block g of a
-// register only holds 4 of the tile's 16 rows, so the other three row groups are fetched from the
-// neighbouring blocks by a lane rotation (u = 1..3).
-__global__ __launch_bounds__(256, 2) void strip4_kernel(StripArgs a) {
-  __shared__ __attribute__((aligned(16))) double s_rk[64 * RK_LD];
-  __shared__ __attribute__((aligned(16))) double s_kc[16 * KC_LD];
-  __shared__ __attribute__((aligned(16))) double s_dinv[64 * DI_LD];
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int l15 = lane & 15, q = lane >> 4, g = (lane >> 2) & 3;
-  const int ord = blockIdx.x;
-  const int c0 = blockIdx.y * 128;
-  const int p = a.p, p_pad = a.p_pad, m_pad = a.m_pad;
-  const int nblk = p_pad / NB;
-  const int n_iblk = (p + NB - 1) / NB;
-  const int64_t lda = lda_of(p_pad), ldv = ldv_of(m_pad);
-  const double* L = a.A + (int64_t)ord * p_pad * lda;
-  const double* Lt = a.tri ? a.rhs + (int64_t)ord * p_pad * lda : nullptr;
-  const int32_t* perm = a.tri ? nullptr : a.perms + (int64_t)ord * p;
-  double* V = a.V + (int64_t)ord * v_rows_of(p) * ldv;
-  const int arow = acc4_row(lane);
-  int acol[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) acol[s] = acc4_col(lane, s);
-
-  const int ib0 = a.tri ? c0 / NB : 0;
-  const int kstart = a.tri ? c0 : 0;
-  if (a.tri) {
-    for (int idx = tid; idx < ib0 * NB * 64; idx += 256) {
-      const int row = idx >> 6, c2 = idx & 63;
-      *reinterpret_cast<v2d*>(V + row * ldv + c0 + 2 * c2) = v2d{0.0, 0.0};
-    }
-  }
-
-  for (int ib = ib0; ib < n_iblk; ++ib) {
-    const int I0 = ib * NB;
-    double acc[4][2][4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[x][y][s] = 0.0;
-
-    const double* srcL = L + I0 * lda + kstart;
-    const double* srcV = V + kstart * ldv + c0;
-    const int nch = (I0 - kstart) / KCH;
-    RKRegs<64> rl = {};
-    KCRegs rv = {};
-    if (nch > 0) {
-      rk_load<64>(rl, srcL, lda, tid, 64);
-      kc_load(rv, srcV, ldv, tid);
-    }
-    for (int c = 0; c < nch; ++c) {
-      __syncthreads();
-      rk_store<64>(rl, s_rk, tid);
-      kc_store(rv, s_kc, tid);
-      __syncthreads();
-      if (c + 1 < nch) {
-        rk_load<64>(rl, srcL + (c + 1) * KCH, lda, tid, 64);
-        kc_load(rv, srcV + (c + 1) * KCH * ldv, ldv, tid);
-      }
-      // tri: V[k][c] = 0 for c > k, so columns c0+64.. (waves 2, 3) see only zeros while k < c0+64
-      if (a.tri && w >= 2 && c < 4) continue;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        double av[4], bv[2][4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) av[x] = s_rk[(16 * x + l15) * RK_LD + 4 * kk + q];
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) bv[y][s] = s_kc[(4 * kk + q) * KC_LD + 32 * w + 16 * y + acol[s]];
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-          for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc[x][y][s] = mfma4(av[x], bv[y][s], acc[x][y][s]);
-      }
-    }
-
-    __syncthreads();  // s_dinv is still being read by slower waves of the previous block
-    load_block64(s_dinv, a.Dinv + ((int64_t)ord * nblk + ib) * 4096, tid);
-
-    // C = RHS[I] - acc
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      const int i = I0 + 16 * x + arow;
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int c = c0 + 32 * w + 16 * y + acol[s];
-          double rv0 = 0.0;
-          if (a.tri) {
-            if (c < I0 + NB) rv0 = Lt[i * lda + c];
-          } else {
-            if (i < p) rv0 = a.rhs[(int64_t)perm[i] * m_pad + c];
-          }
-          acc[x][y][s] = rv0 - acc[x][y][s];
-        }
-    }
-    __syncthreads();
-
-    // out = L_II^-1 * C:  out_{s'} += A_u * rot_u(C_{(s'-u)&3}),  A_u(lane) = Dinv[16 xp + l15][16 x + 4 ((g+u)&3) + q]
-    double outv[4][2][4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) outv[x][y][s] = 0.0;
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        double am[4];
-#pragma unroll
-        for (int xp = x; xp < 4; ++xp)
-          am[xp] = s_dinv[(16 * xp + l15) * DI_LD + 16 * x + 4 * ((g + u) & 3) + q];
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const double r = (u == 0) ? acc[x][y][s] : rot_blocks(acc[x][y][s], lane, u);
-#pragma unroll
-            for (int xp = x; xp < 4; ++xp)
-              outv[xp][y][(s + u) & 3] = mfma4(am[xp], r, outv[xp][y][(s + u) & 3]);
-          }
-      }
-
-#pragma unroll
-    for (int xp = 0; xp < 4; ++xp) {
-      const int i = I0 + 16 * xp + arow;
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) V[i * ldv + c0 + 32 * w + 16 * y + acol[s]] = outv[xp][y][s];
-    }
-    // the next block's k-loop reads these rows back (written by other waves of this workgroup)
-    __threadfence_block();
-    __syncthreads();
-  }
-}
-
-// =====================================================================================
-// strip (production form): 128-row x 128-column tiles on the 4x4x4 fp64 MFMA.
-// Both the 16x16x4 and the 64-row forms above are bound by operand traffic (24 KB per
-// 262 kflop chunk = 10.7 flop/B -> ~4.9 TB/s at 48 TFLOP/s, PMC in profiles/); a 128 x 128 tile
-// moves 32 KB per 524 kflop (16.4 flop/B), and the 4x4x4 MFMA issues 1.6x faster.
-// A 128-row step spans two diagonal blocks, so its solve has three stages:
-//     V_top = D1 C_top ;  C_bot -= L21 V_top ;  V_bot = D2 C_bot
-// each with the accumulators as the B operand (lane rotations supply the other row groups).
-// =====================================================================================
-// 512 threads: wave w owns all 128 rows of the 16 columns 16 w .. 16 w + 15 (32 accumulators), so the
-// three solve stages stay inside one wave and nothing spills.
-__global__ __launch_bounds__(512, 2) void strip128_kernel(StripArgs a) {
-  // one LDS region: operand tiles in the k-loop, then D1 / L21 / D2 in turn
-  constexpr int TILE = 128 * RK_LD + 16 * KC_LD;   // one k-chunk of both operands, 36,864 B
-  __shared__ __attribute__((aligned(16))) double s_all[2 * TILE];
-  static_assert(TILE >= 64 * DI_LD, "a 64 x 64 block must fit");
-  double* const s_buf0 = s_all;
-  double* const s_buf1 = s_all + TILE;
-  double* const s_blk = s_all;
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int l15 = lane & 15, q = lane >> 4, g = (lane >> 2) & 3;
-  const int ord = blockIdx.x;
-  const int c0 = blockIdx.y * 128;
-  const int p = a.p, p_pad = a.p_pad, m_pad = a.m_pad;
-  const int nblk = p_pad / NB;
-  const int n_iblk = (p + NB - 1) / NB;
-  const int64_t lda = lda_of(p_pad), ldv = ldv_of(m_pad);
-  const double* L = a.A + (int64_t)ord * p_pad * lda;
-  const double* Lt = a.tri ? a.rhs + (int64_t)ord * p_pad * lda : nullptr;
-  const int32_t* perm = a.tri ? nullptr : a.perms + (int64_t)ord * p;
-  double* V = a.V + (int64_t)ord * v_rows_of(p) * ldv;
-  const double* Dv = a.Dinv + (int64_t)ord * nblk * 4096;
-  const int arow = acc4_row(lane);
-  int acol[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) acol[s] = acc4_col(lane, s);
-
-  const int kstart = a.tri ? c0 : 0;
-  if (a.tri) {
-    // rows above the strip's first diagonal block are structurally zero; the lift kernel reads them
-    for (int idx = tid; idx < c0 * 64; idx += 512) {
-      const int row = idx >> 6, c2 = idx & 63;
-      *reinterpret_cast<v2d*>(V + row * ldv + c0 + 2 * c2) = v2d{0.0, 0.0};
-    }
-  }
-
-  for (int I0 = kstart; I0 < n_iblk * NB; I0 += 128) {
-    const bool has_bot = I0 + NB < n_iblk * NB;   // an odd block count leaves a half tile at the end
-    const int rows_valid = has_bot ? 128 : 64;
-    double acc[8][4];
-#pragma unroll
-    for (int x = 0; x < 8; ++x)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc[x][s] = 0.0;
-
-    const double* srcL = L + I0 * lda + kstart;
-    const double* srcV = V + kstart * ldv + c0;
-    const int nch = (I0 - kstart) / KCH;
-    // Staging with 512 threads: two 16-byte pieces per thread and tile.  Two LDS buffers and two
-    // register sets: the chunk stored at iteration c was requested two iterations earlier, and
-    // there is one barrier per chunk.
-    const int rk_c = tid & 7, rk_r = tid >> 3;     // rows rk_r, rk_r + 64
-    const int kc_c = tid & 63, kc_k = tid >> 6;    // k rows kc_k, kc_k + 8
-    struct Stage {
-      v2d l0, l1, v0, v1;
-    };
-    Stage sa = {}, sb = {};
-    // Loads are unconditional (chunk index clamped, a missing bottom half re-reads the top rows):
-    // a branch around a load would make the compiler drain every outstanding load at the next
-    // s_waitcnt, which collapses the two-chunk prefetch distance.
-    const int64_t bot_off = (has_bot ? (rk_r + 64) : rk_r) * lda;
-    auto fetch = [&](Stage& st, int c) {
-      c = min(c, nch - 1);
-      const double* sl = srcL + c * KCH + 2 * rk_c;
-      st.l0 = *reinterpret_cast<const v2d*>(sl + rk_r * lda);
-      st.l1 = *reinterpret_cast<const v2d*>(sl + bot_off);
-      const double* sv = srcV + (int64_t)c * KCH * ldv + 2 * kc_c;
-      st.v0 = *reinterpret_cast<const v2d*>(sv + kc_k * ldv);
-      st.v1 = *reinterpret_cast<const v2d*>(sv + (kc_k + 8) * ldv);
-    };
-    auto stash = [&](const Stage& st, double* buf) {
-      *reinterpret_cast<v2d*>(buf + rk_r * RK_LD + 2 * rk_c) = st.l0;
-      *reinterpret_cast<v2d*>(buf + (rk_r + 64) * RK_LD + 2 * rk_c) = st.l1;
-      *reinterpret_cast<v2d*>(buf + 128 * RK_LD + kc_k * KC_LD + 2 * kc_c) = st.v0;
-      *reinterpret_cast<v2d*>(buf + 128 * RK_LD + (kc_k + 8) * KC_LD + 2 * kc_c) = st.v1;
-    };
-    auto compute = [&](const double* buf, int c) {
-      // tri: V[k][c] = 0 for c > k, so columns c0+64.. (waves 4..7) see only zeros while k < c0+64
-      if (a.tri && w >= 4 && c < 4) return;
-      if (a.flags & 16) return;   // timing probe: no k-loop MFMAs
-      const double* rk = buf + l15 * RK_LD + q;
-      const double* kc = buf + 128 * RK_LD + q * KC_LD + 16 * w;
-      // operand registers are double-buffered over the four k-steps so that the LDS reads of
-      // step kk + 1 are in flight while the 32 MFMAs of step kk issue (a missing bottom half
-      // only occurs on the last step of an odd block count; its operands are zero)
-      double av[2][8], bv[2][4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) bv[0][s] = kc[acol[s]];
-#pragma unroll
-      for (int x = 0; x < 8; ++x) av[0][x] = rk[16 * x * RK_LD];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int cur = kk & 1, nxt = cur ^ 1;
-        if (kk < 3) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) bv[nxt][s] = kc[4 * (kk + 1) * KC_LD + acol[s]];
-#pragma unroll
-          for (int x = 0; x < 8; ++x) av[nxt][x] = rk[16 * x * RK_LD + 4 * (kk + 1)];
-        }
-#pragma unroll
-        for (int x = 0; x < 8; ++x)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) acc[x][s] = mfma4(av[cur][x], bv[cur][s], acc[x][s]);
-      }
-    };
-    if (nch > 0) {
-      fetch(sa, 0);
-      fetch(sb, 1);
-      stash(sa, s_buf0);
-      fetch(sa, 2);
-      __syncthreads();
-      for (int c = 0; c < nch; c += 2) {
-        stash(sb, s_buf1);          // chunk c + 1, requested two half-iterations ago
-        fetch(sb, c + 3);
-        compute(s_buf0, c);
-        __syncthreads();
-        stash(sa, s_buf0);          // chunk c + 2  (nch is a multiple of 8: 128-row steps)
-        fetch(sa, c + 4);
-        compute(s_buf1, c + 1);
-        __syncthreads();
-      }
-    } else {
-      __syncthreads();
-    }
-
-    // C = RHS[I] - acc
-#pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      const int i = I0 + 16 * x + arow;
-      const int cmax = (i / NB + 1) * NB;   // tri: L_t has nothing to the right of row i's diagonal block
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int c = c0 + 16 * w + acol[s];
-        double rhs = 0.0;
-        if (x < 4 || has_bot) {
-          if (a.tri) {
-            if (c < cmax) rhs = Lt[i * lda + c];
-          } else {
-            if (i < p) rhs = a.rhs[(int64_t)perm[i] * m_pad + c];
-          }
-        }
-        acc[x][s] = rhs - acc[x][s];
-      }
-    }
-
-    if (a.flags & 32) {            // timing probe: no solve stages
-      __syncthreads();
-      continue;
-    }
-    // ---- stage 1: V_top = D1 * C_top ------------------------------------------------------
-    // (the k-loop ended with a barrier: the operand tiles are dead, the block buffer aliases them)
-    load_block64<512>(s_blk, Dv + (int64_t)(I0 / NB) * 4096, tid);
-    __syncthreads();
-    double top[4][4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) top[x][s] = 0.0;
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        double am[4];
-#pragma unroll
-        for (int xp = x; xp < 4; ++xp) am[xp] = s_blk[(16 * xp + l15) * DI_LD + 16 * x + 4 * ((g + u) & 3) + q];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const double r = (u == 0) ? acc[x][s] : rot_blocks(acc[x][s], lane, u);
-#pragma unroll
-          for (int xp = x; xp < 4; ++xp) top[xp][(s + u) & 3] = mfma4(am[xp], r, top[xp][(s + u) & 3]);
-        }
-      }
-#pragma unroll
-    for (int xp = 0; xp < 4; ++xp) {
-      const int i = I0 + 16 * xp + arow;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) V[i * ldv + c0 + 16 * w + acol[s]] = top[xp][s];
-    }
-
-    if (has_bot) {
-      // ---- stage 2: C_bot -= L21 * V_top  (L21 = L[I0+64.., I0..I0+63], dense) ----------------
-      __syncthreads();
-      {
-        const double* L21 = L + (I0 + NB) * lda + I0;
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          const int idx = tid + 512 * qq, row = idx >> 5, c2 = idx & 31;
-          *reinterpret_cast<v2d*>(s_blk + row * DI_LD + 2 * c2) =
-              *reinterpret_cast<const v2d*>(L21 + row * lda + 2 * c2);
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          double am[4];
-#pragma unroll
-          for (int xp = 0; xp < 4; ++xp)
-            am[xp] = -s_blk[(16 * xp + l15) * DI_LD + 16 * x + 4 * ((g + u) & 3) + q];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const double r = (u == 0) ? top[x][s] : rot_blocks(top[x][s], lane, u);
-#pragma unroll
-            for (int xp = 0; xp < 4; ++xp) acc[4 + xp][(s + u) & 3] = mfma4(am[xp], r, acc[4 + xp][(s + u) & 3]);
-          }
-        }
-      // ---- stage 3: V_bot = D2 * C_bot --------------------------------------------------------
-      __syncthreads();
-      load_block64<512>(s_blk, Dv + (int64_t)(I0 / NB + 1) * 4096, tid);
-      __syncthreads();
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) top[x][s] = 0.0;
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          double am[4];
-#pragma unroll
-          for (int xp = x; xp < 4; ++xp)
-            am[xp] = s_blk[(16 * xp + l15) * DI_LD + 16 * x + 4 * ((g + u) & 3) + q];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const double r = (u == 0) ? acc[4 + x][s] : rot_blocks(acc[4 + x][s], lane, u);
-#pragma unroll
-            for (int xp = x; xp < 4; ++xp) top[xp][(s + u) & 3] = mfma4(am[xp], r, top[xp][(s + u) & 3]);
-          }
-        }
-#pragma unroll
-      for (int xp = 0; xp < 4; ++xp) {
-        const int i = I0 + NB + 16 * xp + arow;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) V[i * ldv + c0 + 16 * w + acol[s]] = top[xp][s];
-      }
-    }
-    // the next step's k-loop reads these rows back (written by other waves of this workgroup)
-    __threadfence_block();
-    __syncthreads();
-  }
-}
-
 hipError_t launch_strip(const StripArgs& a, hipStream_t st) {
   if (a.p < 1 || a.p_pad % NB != 0 || a.m_pad % 128 != 0 || a.n_ord < 1) return hipErrorInvalidValue;
   if (a.tri && a.m_pad > a.p_pad + 127) return hipErrorInvalidValue;
   if (!a.tri && a.perms == nullptr) return hipErrorInvalidValue;
   dim3 grid(a.n_ord, a.m_pad / 128);
-  if (a.flags & 4)
-    hipLaunchKernelGGL(strip_kernel, grid, dim3(256), 0, st, a);   // 16x16x4 MFMA, 64-row steps (A/B reference)
-  else if (a.flags & 8)
-    hipLaunchKernelGGL(strip4_kernel, grid, dim3(256), 0, st, a);  // 4x4x4 MFMA, 64-row steps (A/B reference)
-  else
-    hipLaunchKernelGGL(strip128_kernel, grid, dim3(512), 0, st, a);
+  hipLaunchKernelGGL(strip_kernel, grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

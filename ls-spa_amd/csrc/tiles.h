@@ -44,27 +44,14 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
 // row of an accumulator element inside its 16 x 16 tile
 __device__ __forceinline__ int acc_row(int l4, int r) { return l4 + 4 * r; }
 
-// ---- v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction ------------------
-// Measured on gfx950 (tools/mfma_bench3.hip): 16.5 cycles per instruction = 32 flop/clk/SIMD
-// (the vendor fp64 rate, 70-76 TFLOP/s sustained), against ~99 cycles per 2048-flop 16x16x4
-// instruction (47 TFLOP/s).  Lane maps, probed with one-hot operands (tools/mfma_probe4.hip), with
-// lane l = 16 q + 4 g + t:   A_g[i = t][k = q],  B_g[k = q][j = t],  D_g[i = q][j = t]   (block = g);
-// CBSZ / ABID broadcast has no effect for f64.
-//
-// A 16x16x4 step is done as four of them ("rotations" s = 0..3): with
-//   a   (lane) = A16[4 g + t][q]                       -- the same register the 16x16x4 form takes
-//   b_s (lane) = B16[q][4 ((g + s) & 3) + t]
-// acc_s (lane) accumulates D16[4 g + q][4 ((g + s) & 3) + t].
-__device__ __forceinline__ double mfma4(double a, double b, double c) {
-  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ int acc4_row(int lane) { return 4 * ((lane >> 2) & 3) + (lane >> 4); }
-__device__ __forceinline__ int acc4_col(int lane, int s) { return 4 * ((((lane >> 2) & 3) + s) & 3) + (lane & 3); }
-// value of v held by the lane whose block index is (g + u) & 3 (same q, t)
-__device__ __forceinline__ double rot_blocks(double v, int lane, int u) {
-  return __shfl(v, (lane & 48) | ((lane + 4 * u) & 15), 64);
-}
-
+// Note on v_mfma_f64_4x4x4_4b_f64: it issues every 16.5 cycles (32 flop/clk/SIMD, 70-76 TFLOP/s in
+// tools/mfma_bench3.hip / mfma_bench4.hip) against ~99 cycles per 2048-flop 16x16x4 instruction
+// (47 TFLOP/s), and a 16x16x4 step can be built from four of them (lane maps probed in
+// tools/mfma_probe4.hip: lane l = 16 q + 4 g + t holds A_g[i=t][k=q], B_g[k=q][j=t], D_g[i=q][j=t];
+// CBSZ/ABID broadcast is ignored for f64).  Panel and strip kernels written that way (git history:
+// "Experimental 4x4x4-MFMA kernel variants") were correct but not faster in situ -- 12 LDS operand
+// reads per 32 MFMAs instead of 6 per 8, lane rotations in the solve stage, lower occupancy -- so
+// the 16x16x4 form is kept for now.
 __device__ __forceinline__ d4 d4_zero() {
   d4 z = {0.0, 0.0, 0.0, 0.0};
   return z;
