@@ -121,10 +121,20 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    eng_stream = None
+    # developer switch: run the multi-rank code path (RCCL group, shared stream, forced collective)
+    # in a world of one, to rehearse on a single GPU exactly what the N > 1 launch executes
+    rehearse = world == 1 and os.environ.get("LSSPA_BENCH_REHEARSE_DIST") == "1"
+    if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-        comm = TorchComm()
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if rehearse:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+        # engine kernels, the all-reduce and the merge share one torch stream: no host sync per step
+        tstream, eng_stream = TorchComm.make_stream(dev)
+        comm = TorchComm(stream=tstream, force_collective=rehearse)
     else:
         comm = _Comm()
 
@@ -139,7 +149,7 @@ def main():
     ye = Xe @ w + torch.randn(rows, dtype=torch.float64, device=dev, generator=gen)
     torch.cuda.synchronize()
 
-    eng = HipEngine(local)
+    eng = HipEngine(local, stream=eng_stream)
     eng.profile(True)
     t0 = time.perf_counter()
     eng.load_device_data(Xa.data_ptr(), p, ya.data_ptr(), rows, Xe.data_ptr(), p, ye.data_ptr(), rows, p, 0.0)
@@ -159,7 +169,7 @@ def main():
 
     def barrier():
         eng.synchronize()
-        if world > 1:
+        if world > 1 or rehearse:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -180,7 +190,7 @@ def main():
         step(k)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or rehearse:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -278,7 +288,7 @@ def main():
     if out is not None:
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if world > 1 or rehearse:
         dist.destroy_process_group()
 
 

@@ -8,6 +8,11 @@ merge_sample_mean / merge_sample_cov (cvxgrp/ls-spa ls_spa/ls_spa.py:103-119, :2
 With backend "nccl" (= RCCL on ROCm) the buffer is reduced in place in HBM over xGMI;
 with "gloo" (CPU tests) it is a host tensor.  After the collective every rank holds the
 same moments, merges them identically and therefore takes the same stop decision.
+
+Stream discipline on the GPU: if the engine was created on a torch stream
+(``TorchComm.make_stream()`` -> ``HipEngine(device, stream=...)``) the kernels, the collective
+and the merge are ordered on that one stream and the host never blocks between them;
+otherwise the engine's own stream and torch's are joined by host synchronisation.
 """
 from __future__ import annotations
 
@@ -15,7 +20,7 @@ import numpy as np
 
 
 class TorchComm:
-    def __init__(self, group=None):
+    def __init__(self, group=None, stream=None, force_collective=False):
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
@@ -24,6 +29,15 @@ class TorchComm:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self._on_gpu = dist.get_backend(group) == "nccl"
+        self._stream = stream            # torch.cuda.Stream shared with the engine, or None
+        self._force = force_collective   # tests: run the collective even in a world of one
+
+    @staticmethod
+    def make_stream(device):
+        """A torch stream for the engine to run on; returns (torch_stream, raw hipStream_t)."""
+        import torch
+        s = torch.cuda.Stream(device=device)
+        return s, s.cuda_stream
 
     def _as_tensor(self, buf):
         torch = self._torch
@@ -32,14 +46,20 @@ class TorchComm:
         return torch.as_tensor(buf, device="cuda")  # zero-copy view through __cuda_array_interface__
 
     def allreduce_pending(self, engine):
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             return
         t = self._as_tensor(engine.pending_buffer())
-        if self._on_gpu:
-            engine.synchronize()                    # engine stream -> torch stream hand-off
+        if not self._on_gpu:
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
+            return
+        if self._stream is not None:
+            # engine kernels, collective and merge are all ordered on the shared stream
+            with self._torch.cuda.stream(self._stream):
+                self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
+            return
+        engine.synchronize()                        # engine stream -> torch stream hand-off
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
-        if self._on_gpu:
-            self._torch.cuda.current_stream().synchronize()
+        self._torch.cuda.current_stream().synchronize()
 
     def gather_lifts(self, local, counts):
         """All ranks' per-sample lift vectors (only needed for attribution_history /

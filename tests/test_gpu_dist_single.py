@@ -46,6 +46,26 @@ def test_pending_buffer_is_a_zero_copy_device_tensor_and_allreduce_runs(golden):
         np.testing.assert_allclose(mean, lifts.mean(0), rtol=0, atol=1e-13)
         np.testing.assert_allclose(cov, np.cov(lifts, rowvar=False, bias=True), rtol=0, atol=1e-14)
         eng.close()
+        # shared-stream discipline: engine on a torch stream, collective forced in the world of one,
+        # no host synchronisation between kernels, all-reduce and merge
+        ts, raw = TorchComm.make_stream(torch.device("cuda", 0))
+        eng2 = HipEngine(0, stream=raw)
+        comm2 = TorchComm(stream=ts, force_collective=True)
+        eng2.load_data(*d, 0.0)
+        eng2.reset_stats()
+        for k in range(4):
+            eng2.run_batch(g["perms64"][16 * k:16 * k + 16], True, accumulate=True)
+            comm2.allreduce_pending(eng2)
+            eng2.merge()
+        n2, mean2, cov2 = eng2.stats()
+        all_l = HipEngine(0)
+        all_l.load_data(*d, 0.0)
+        ref_l = all_l.run_batch(g["perms64"], True, want_lifts=True, accumulate=False)
+        assert n2 == 64
+        np.testing.assert_allclose(mean2, ref_l.mean(0), rtol=0, atol=1e-13)
+        np.testing.assert_allclose(cov2, np.cov(ref_l, rowvar=False, bias=True), rtol=0, atol=1e-14)
+        eng2.close()
+        all_l.close()
         # full driver through the communicator == without it
         a = ls_spa(*d, perms=g["perms64"], batch_size=16, tolerance=0.0, return_attribution_history=True,
                    _comm=TorchComm())
