@@ -33,8 +33,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
   const int32_t* perm = a.perms + (int64_t)ord * p;
   const double* S = a.S[src];
   const double* svec = a.s[src];
-  const int64_t lda = lda_of(p_pad);
-  double* out = a.A + (int64_t)mat * p_pad * lda;
+  double* out = a.A + (int64_t)mat * p_pad * p_pad;   // chunk-major, see tiles.h
 
   const int jmax = min(i0 + GROWS, p);  // permutation entries this workgroup can touch
   for (int j = tid; j < jmax; j += 256) sperm[j] = perm[j];
@@ -44,7 +43,6 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     const int i = i0 + ii;
     if (i >= p_pad) break;
     const int jend = min(((i + 1 + NB - 1) / NB) * NB, p_pad);  // zero-fill to the block edge
-    double* orow = out + i * lda;
     if (i < p) {
       const double* srow = S + (int64_t)sperm[i] * a.ld_src;
       __syncthreads();  // previous row's picks are done
@@ -60,13 +58,13 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
         double2 v;
         v.x = (j <= i) ? rowbuf[sperm[j]] : 0.0;
         v.y = (j + 1 <= i) ? rowbuf[sperm[j + 1]] : 0.0;
-        *reinterpret_cast<double2*>(orow + j) = v;
+        *reinterpret_cast<double2*>(out + cm_off(p_pad, i, j)) = v;   // j even: both in one chunk
       }
     } else if (i == p) {
       for (int j = tid; j < jend; j += 256)
-        orow[j] = (j < p) ? svec[sperm[j]] : (j == p ? a.aug[src] : 0.0);
+        out[cm_off(p_pad, i, j)] = (j < p) ? svec[sperm[j]] : (j == p ? a.aug[src] : 0.0);
     } else {
-      for (int j = tid; j < jend; j += 256) orow[j] = (j == i) ? 1.0 : 0.0;
+      for (int j = tid; j < jend; j += 256) out[cm_off(p_pad, i, j)] = (j == i) ? 1.0 : 0.0;
     }
   }
 }
@@ -105,13 +103,14 @@ struct ElimScratch {
   int bad;
 };
 
-// Factor the 64 x 64 diagonal block at Mt (row stride lda, lower part meaningful) in place and
+// Factor the 64 x 64 diagonal block of M at (r0, r0) (chunk-major, lower part meaningful) in place and
 // write its inverse to Dg.  256 threads.  Owner layout: thread (ty, tx) keeps T(ty + 16 a, tx + 16 c)
 // and Y(ty + 16 a, tx + 16 c) in registers.  Elimination on [T | Y] without scaling: after step k
 // column k of T is final (= L[:,k] * L[k][k]) and row k of Y is final (= (L^-1)[k,:] * L[k][k]).
 // Per step only column k of T, row k of Y and the pivot travel through LDS (one barrier per step).
-__device__ __forceinline__ void eliminate_block64(double* __restrict__ Mt, int64_t lda, double* __restrict__ Dg,
-                                                  int32_t* __restrict__ info, ElimScratch* sc, int tid) {
+__device__ __forceinline__ void eliminate_block64(double* __restrict__ M, int p_pad, int r0,
+                                                  double* __restrict__ Dg, int32_t* __restrict__ info,
+                                                  ElimScratch* sc, int tid) {
   const int ty = tid >> 4, tx = tid & 15;
   double T[4][4], Y[4][4];
   if (tid == 0) sc->bad = 0;
@@ -120,7 +119,7 @@ __device__ __forceinline__ void eliminate_block64(double* __restrict__ Mt, int64
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int row = ty + 16 * a, col = tx + 16 * c;
-      T[a][c] = (col <= row) ? Mt[row * lda + col] : 0.0;
+      T[a][c] = (col <= row) ? M[cm_off(p_pad, r0 + row, r0 + col)] : 0.0;
       Y[a][c] = (row == col) ? 1.0 : 0.0;
     }
 
@@ -188,7 +187,7 @@ __device__ __forceinline__ void eliminate_block64(double* __restrict__ Mt, int64
       if (col < row) lv = T[a][c] * sc->dd[col];
       if (col == row) lv = 1.0 / sc->dd[col];
       if (col <= row) xv = Y[a][c] * sc->dd[row];
-      Mt[row * lda + col] = lv;
+      M[cm_off(p_pad, r0 + row, r0 + col)] = lv;
       Dg[row * 64 + col] = xv;
     }
   if (tid == 0 && sc->bad) atomicOr(&info[0], 1);
@@ -201,10 +200,8 @@ __global__ __launch_bounds__(256, 2) void chol_diag_kernel(double* __restrict__ 
                                                            int nblk) {
   __shared__ ElimScratch sc;
   const int mt = blockIdx.x;
-  const int64_t lda = lda_of(p_pad);
-  double* M = A + (int64_t)mt * p_pad * lda;
-  const int J0 = J * NB;
-  eliminate_block64(M + J0 * lda + J0, lda, Dinv + ((int64_t)mt * nblk + J) * 4096, info, &sc, threadIdx.x);
+  double* M = A + (int64_t)mt * p_pad * p_pad;
+  eliminate_block64(M, p_pad, J * NB, Dinv + ((int64_t)mt * nblk + J) * 4096, info, &sc, threadIdx.x);
 }
 
 hipError_t launch_chol_diag(double* A, double* Dinv, int32_t* info, int p_pad, int J, int n_mats,
@@ -238,21 +235,22 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
   // the next diagonal block, start first
   const int mt = blockIdx.x;
   const int tile = blockIdx.y;
-  const int64_t lda = lda_of(p_pad);
-  double* M = A + (int64_t)mt * p_pad * lda;
+  double* M = A + (int64_t)mt * p_pad * p_pad;
   const int J0 = J * NB;
   const int I0 = J0 + NB + tile * 128;
   const int rows_valid = min(128, p_pad - I0);
 
-  const double* srcJ = M + J0 * lda;
-  const double* srcI = M + I0 * lda;
+  // chunk-major: rows J0.. / I0.. of k-chunk c are contiguous blocks, one chunk = p_pad * 16 doubles
+  const double* srcJ = M + cm_off(p_pad, J0, 0);
+  const double* srcI = M + cm_off(p_pad, I0, 0);
+  const int64_t chunk = (int64_t)p_pad * 16;
 
   const int nch = J0 / KCH;
   RKRegs<64> rj = {};
   RKRegs<128> ri = {};
   if (nch > 0) {
-    rk_load<64>(rj, srcJ, lda, tid, 64);
-    rk_load<128>(ri, srcI, lda, tid, rows_valid);
+    rk_load<64>(rj, srcJ, CM_LD, tid, 64);
+    rk_load<128>(ri, srcI, CM_LD, tid, rows_valid);
   }
 
   // acc[x][y][r] <-> (column j = 16 x + l4 + 4 r of block J, row i = 32 w + 16 y + l15 of the tile)
@@ -265,7 +263,7 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = 32 * w + rr + 8 * q;
-        t[x][q] = (i < rows_valid) ? *reinterpret_cast<const v2d*>(srcI + i * lda + J0 + 16 * x + 2 * ch)
+        t[x][q] = (i < rows_valid) ? *reinterpret_cast<const v2d*>(M + cm_off(p_pad, I0 + i, J0 + 16 * x + 2 * ch))
                                    : v2d{0.0, 0.0};
       }
 #pragma unroll
@@ -289,10 +287,11 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
     rk_store<128>(ri, s_rki, tid);
     __syncthreads();
     if (c + 1 < nch) {
-      rk_load<64>(rj, srcJ + (c + 1) * KCH, lda, tid, 64);
-      rk_load<128>(ri, srcI + (c + 1) * KCH, lda, tid, rows_valid);
+      rk_load<64>(rj, srcJ + (c + 1) * chunk, CM_LD, tid, 64);
+      rk_load<128>(ri, srcI + (c + 1) * chunk, CM_LD, tid, rows_valid);
     }
     if (32 * w >= rows_valid) continue;  // half tile at the bottom: this wave's rows do not exist
+    if (flags & 16) continue;            // timing probe: no k-loop MFMAs (results wrong)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       double av[4], bv[2];
@@ -356,7 +355,7 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
     for (int q = 0; q < 4; ++q) {
       const int rr = row + 32 * q;
       if (rr < rows_valid)
-        *reinterpret_cast<v2d*>(M + (I0 + rr) * lda + J0 + 16 * xp + 2 * c) =
+        *reinterpret_cast<v2d*>(M + cm_off(p_pad, I0 + rr, J0 + 16 * xp + 2 * c)) =
             *reinterpret_cast<const v2d*>(s_out + rr * RK_LD + 2 * c);
     }
     if (64 * sb >= rows_valid) continue;
@@ -376,7 +375,7 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
   }
   // A[I',I'] -= L[I',J] L[I',J]^T on the sub-block's diagonal tile (owned by this workgroup alone)
   if (64 * sb < rows_valid) {
-    double* D = M + (I0 + 64 * sb) * lda + I0 + 64 * sb;
+    const int d0 = I0 + 64 * sb;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -385,7 +384,7 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * t1[a] + acc_row(l4, r), col = 16 * b + l15;
-          if (col <= row) D[row * lda + col] -= upd[a][b][r];
+          if (col <= row) M[cm_off(p_pad, d0 + row, d0 + col)] -= upd[a][b][r];
         }
       }
   }
@@ -396,7 +395,7 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
   if (tile == 0 && !(flags & 2)) {
     __threadfence_block();
     __syncthreads();  // the update above was written by waves 0 and 1; region A is free again
-    eliminate_block64(M + I0 * lda + I0, lda, Dinv + ((int64_t)mt * nblk + J + 1) * 4096, info,
+    eliminate_block64(M, p_pad, I0, Dinv + ((int64_t)mt * nblk + J + 1) * 4096, info,
                       reinterpret_cast<ElimScratch*>(s_a), tid);
   }
 }
@@ -433,9 +432,10 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
   const int p = a.p, p_pad = a.p_pad, m_pad = a.m_pad;
   const int nblk = p_pad / NB;
   const int n_iblk = (p + NB - 1) / NB;
-  const int64_t lda = lda_of(p_pad), ldv = ldv_of(m_pad);
-  const double* L = a.A + (int64_t)ord * p_pad * lda;
-  const double* Lt = a.tri ? a.rhs + (int64_t)ord * p_pad * lda : nullptr;
+  const int64_t ldv = ldv_of(m_pad);
+  const int64_t chunk = (int64_t)p_pad * 16;
+  const double* L = a.A + (int64_t)ord * p_pad * p_pad;   // chunk-major
+  const double* Lt = a.tri ? a.rhs + (int64_t)ord * p_pad * p_pad : nullptr;
   const int32_t* perm = a.tri ? nullptr : a.perms + (int64_t)ord * p;
   double* V = a.V + (int64_t)ord * v_rows_of(p) * ldv;
 
@@ -457,13 +457,13 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
 #pragma unroll
       for (int y = 0; y < 2; ++y) acc[x][y] = d4_zero();
 
-    const double* srcL = L + I0 * lda + kstart;
+    const double* srcL = L + cm_off(p_pad, I0, kstart);
     const double* srcV = V + kstart * ldv + c0;
     const int nch = (I0 - kstart) / KCH;
     RKRegs<64> rl = {};
     KCRegs rv = {};
     if (nch > 0) {
-      rk_load<64>(rl, srcL, lda, tid, 64);
+      rk_load<64>(rl, srcL, CM_LD, tid, 64);
       kc_load(rv, srcV, ldv, tid);
     }
     for (int c = 0; c < nch; ++c) {
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
       kc_store(rv, s_kc, tid);
       __syncthreads();
       if (c + 1 < nch) {
-        rk_load<64>(rl, srcL + (c + 1) * KCH, lda, tid, 64);
+        rk_load<64>(rl, srcL + (c + 1) * chunk, CM_LD, tid, 64);
         kc_load(rv, srcV + (c + 1) * KCH * ldv, ldv, tid);
       }
       // tri: V[k][c] = 0 for c > k, so columns c0+64.. (waves 2, 3) see only zeros while k < c0+64
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
           const int c = c0 + 32 * w + 16 * y + l15;
           double rv0 = 0.0;
           if (a.tri) {
-            if (c < I0 + NB) rv0 = Lt[i * lda + c];
+            if (c < I0 + NB) rv0 = Lt[cm_off(p_pad, i, c)];
           } else {
             if (i < p) rv0 = a.rhs[(int64_t)perm[i] * m_pad + c];
           }

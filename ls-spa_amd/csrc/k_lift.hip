@@ -28,15 +28,14 @@ __global__ __launch_bounds__(256) void lift_partial_kernel(LiftArgs a) {
   const int cs = strip * 64;
   const int p = a.p, p_pad = a.p_pad, m_pad = a.m_pad;
   const int n_iblk = (p + NB - 1) / NB;
-  const int64_t lda = lda_of(p_pad), ldv = ldv_of(m_pad);
-  const double* L = a.A + (int64_t)ord * p_pad * lda;
-  const double* zrow = L + p * lda;
+  const int64_t ldv = ldv_of(m_pad);
+  const double* L = a.A + (int64_t)ord * p_pad * p_pad;   // chunk-major: row p is L[cm_off(p_pad, p, j)]
   const double* V = a.V + (int64_t)ord * v_rows_of(p) * ldv;
   double* Pp = a.Ppart + ((int64_t)ord * nstrips + strip) * p_pad;
   const int c = cs + lane;
   double yt;
   if (a.tri)
-    yt = (c < p) ? a.At[(int64_t)ord * p_pad * lda + p * lda + c] : 0.0;
+    yt = (c < p) ? a.At[(int64_t)ord * p_pad * p_pad + cm_off(p_pad, p, c)] : 0.0;
   else
     yt = a.ytil[c];
   double* E = s_E[w];
@@ -52,7 +51,7 @@ __global__ __launch_bounds__(256) void lift_partial_kernel(LiftArgs a) {
     double v[16];
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) v[jj] = (j0 + jj < p) ? V[(j0 + jj) * ldv + c] : 0.0;
-    const double zl = (j0 + r16 < p) ? zrow[j0 + r16] : 0.0;  // lane r16 holds z[j0 + r16]
+    const double zl = (j0 + r16 < p) ? L[cm_off(p_pad, p, j0 + r16)] : 0.0;  // lane r16 holds z[j0 + r16]
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
       const double zj = __shfl(zl, jj, 64);
@@ -82,12 +81,12 @@ __global__ __launch_bounds__(256) void lift_finish_kernel(LiftArgs a) {
   for (int k = 0; k < a.per_sample; ++k) {
     const int ord = sample * a.per_sample + k;
     const int32_t* perm = a.perms + (int64_t)ord * p;
-    const double* zrow = a.A + (int64_t)ord * p_pad * lda_of(p_pad) + p * lda_of(p_pad);
+    const double* Lm = a.A + (int64_t)ord * p_pad * p_pad;
     const double* Pp = a.Ppart + (int64_t)ord * nstrips * p_pad;
     for (int j = threadIdx.x; j < p; j += 256) {
       double s = 0.0;
       for (int t = 0; t < nstrips; ++t) s += Pp[(int64_t)t * p_pad + j];
-      const double val = zrow[j] * s * wgt;
+      const double val = Lm[cm_off(p_pad, p, j)] * s * wgt;
       const int f = perm[j];
       if (k == 0)
         out[f] = val;
@@ -243,19 +242,17 @@ __global__ __launch_bounds__(1024) void backsolve_kernel(const double* __restric
   double* wv = reinterpret_cast<double*>(smem_raw);
   __shared__ double s_t;
   const int tid = threadIdx.x;
-  const int64_t lda = lda_of(p_pad);
-  for (int i = tid; i < p; i += 1024) wv[i] = L[p * lda + i];
+  for (int i = tid; i < p; i += 1024) wv[i] = L[cm_off(p_pad, p, i)];
   __syncthreads();
   for (int j = p - 1; j >= 0; --j) {
-    const double* row = L + j * lda;
     if (tid == 0) {
-      const double t = wv[j] / row[j];
+      const double t = wv[j] / L[cm_off(p_pad, j, j)];
       s_t = t;
       theta[j] = t;
     }
     __syncthreads();
     const double t = s_t;
-    for (int i = tid; i < j; i += 1024) wv[i] -= t * row[i];
+    for (int i = tid; i < j; i += 1024) wv[i] -= t * L[cm_off(p_pad, j, i)];
     __syncthreads();
   }
 }

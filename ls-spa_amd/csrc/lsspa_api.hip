@@ -230,7 +230,7 @@ size_t bytes_per_ordering(const lsspa_ctx* ctx) {
   const size_t pp = ctx->p_pad, nblk = pp / NB, n_iblk = (ctx->p + NB - 1) / NB;
   const size_t nm = ctx->tri ? 2 : 1;
   (void)n_iblk;
-  return nm * pp * (size_t)lda_of(ctx->p_pad) * 8 + (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad) * 8 +
+  return nm * pp * pp * 8 + (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad) * 8 +
          nm * nblk * 4096 * 8 +
          (size_t)(ctx->m_pad / 64) * pp * 8 + (size_t)ctx->p * 4;
 }
@@ -257,7 +257,7 @@ int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
       dev_free(ctx->perms_d);
       const size_t pp = ctx->p_pad, nblk = pp / NB, n_iblk = (ctx->p + NB - 1) / NB;
       const size_t nm = ctx->tri ? 2 : 1;
-      TRY(dev_alloc(ctx, ctx->A, nm * cap * pp * (size_t)lda_of(ctx->p_pad)));
+      TRY(dev_alloc(ctx, ctx->A, nm * cap * pp * pp));
       (void)n_iblk;
       TRY(dev_alloc(ctx, ctx->V, (size_t)cap * (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad)));
       TRY(dev_alloc(ctx, ctx->Dinv, nm * cap * nblk * 4096));
@@ -330,7 +330,7 @@ int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
     StripArgs sa;
     sa.A = ctx->A.ptr;
     sa.Dinv = ctx->Dinv.ptr;
-    sa.rhs = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * (size_t)lda_of(p_pad) : ctx->Ft.ptr;
+    sa.rhs = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * p_pad : ctx->Ft.ptr;
     sa.perms = ctx->perms_d.ptr;
     sa.V = ctx->V.ptr;
     sa.p = p;
@@ -345,7 +345,7 @@ int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
     ProfScope ps(ctx, LSSPA_K_LIFT);
     LiftArgs la;
     la.A = ctx->A.ptr;
-    la.At = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * (size_t)lda_of(p_pad) : nullptr;
+    la.At = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * p_pad : nullptr;
     la.ytil = ctx->tri ? nullptr : ctx->ytil.ptr;
     la.V = ctx->V.ptr;
     la.perms = ctx->perms_d.ptr;
@@ -711,26 +711,25 @@ int lsspa_get_factors(lsspa_ctx* ctx, double* R_tr, double* q_tr, double* F_te, 
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
-  const int p = ctx->p, m = ctx->m;
-  const size_t pp = (size_t)lda_of(ctx->p_pad);   // row stride of the factor matrices
-  const size_t mat = (size_t)ctx->p_pad * pp;
+  const int p = ctx->p, m = ctx->m, ppad = ctx->p_pad;
+  const size_t mat = (size_t)ppad * ppad;       // chunk-major factor matrices (tiles.h: cm_off)
   TRY(factor_identity(ctx, nullptr));
   std::vector<double> L(mat);
   HIPCHK(hipMemcpy(L.data(), ctx->A.ptr, L.size() * 8, hipMemcpyDeviceToHost));
   if (R_tr)
     for (int a = 0; a < p; ++a)
-      for (int b = 0; b < p; ++b) R_tr[(size_t)a * p + b] = (b >= a) ? L[(size_t)b * pp + a] : 0.0;
+      for (int b = 0; b < p; ++b) R_tr[(size_t)a * p + b] = (b >= a) ? L[cm_off(ppad, b, a)] : 0.0;
   if (q_tr)
-    for (int a = 0; a < p; ++a) q_tr[a] = L[(size_t)p * pp + a];
+    for (int a = 0; a < p; ++a) q_tr[a] = L[cm_off(ppad, p, a)];
   if (ctx->tri) {
     if (F_te || q_te) {
       // slot layout of run_orderings: the test matrices follow the n_ord = 1 train matrices
       HIPCHK(hipMemcpy(L.data(), ctx->A.ptr + mat, L.size() * 8, hipMemcpyDeviceToHost));
       if (F_te)
         for (int a = 0; a < p; ++a)
-          for (int b = 0; b < p; ++b) F_te[(size_t)a * p + b] = (b >= a) ? L[(size_t)b * pp + a] : 0.0;
+          for (int b = 0; b < p; ++b) F_te[(size_t)a * p + b] = (b >= a) ? L[cm_off(ppad, b, a)] : 0.0;
       if (q_te)
-        for (int a = 0; a < p; ++a) q_te[a] = L[(size_t)p * pp + a];
+        for (int a = 0; a < p; ++a) q_te[a] = L[cm_off(ppad, p, a)];
     }
   } else {
     if (F_te) {
@@ -906,10 +905,17 @@ int lsspa_debug_factor(lsspa_ctx* ctx, const int32_t* perm, double* L, double* L
   std::vector<char> seen;
   if (!is_permutation(perm, ctx->p, seen)) return ctx->fail(LSSPA_ERR_ARG, "perm is not a permutation");
   TRY(factor_identity(ctx, perm));
-  const size_t lda = (size_t)lda_of(ctx->p_pad), ldv = (size_t)ldv_of(ctx->m_pad), mp = ctx->m_pad;
-  if (L) HIPCHK(hipMemcpy2D(L, pp * 8, ctx->A.ptr, lda * 8, pp * 8, pp, hipMemcpyDeviceToHost));
-  if (Lt && ctx->tri)
-    HIPCHK(hipMemcpy2D(Lt, pp * 8, ctx->A.ptr + pp * lda, lda * 8, pp * 8, pp, hipMemcpyDeviceToHost));
+  const size_t ldv = (size_t)ldv_of(ctx->m_pad), mp = ctx->m_pad;
+  // the device matrices are chunk-major; hand them out dense row-major
+  auto unpack = [&](const double* dev, double* dst) -> int {
+    std::vector<double> tmp(pp * pp);
+    HIPCHK(hipMemcpy(tmp.data(), dev, pp * pp * 8, hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < pp; ++r)
+      for (size_t c = 0; c < pp; ++c) dst[r * pp + c] = tmp[cm_off((int)pp, (int)r, (int)c)];
+    return LSSPA_OK;
+  };
+  if (L) TRY(unpack(ctx->A.ptr, L));
+  if (Lt && ctx->tri) TRY(unpack(ctx->A.ptr + pp * pp, Lt));
   if (V) HIPCHK(hipMemcpy2D(V, mp * 8, ctx->V.ptr, ldv * 8, mp * 8, n_iblk * NB, hipMemcpyDeviceToHost));
   return LSSPA_OK;
 }

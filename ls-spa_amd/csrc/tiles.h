@@ -29,11 +29,20 @@ constexpr int KC_LD = 144;    // LDS row stride (doubles) of a [16 k][128 cols] 
                               // the two k rows of a 32-lane group on disjoint bank halves
 constexpr int DI_LD = 66;     // LDS row stride of a 64 x 64 block read as an A operand
 constexpr int TT_LD = 65;     // LDS row stride of the in-LDS elimination tiles (column walks)
-// Row strides of the per-ordering matrices in HBM.  p_pad and m_pad are multiples of 64 / 128, and
-// a power-of-two row stride sends every row of a tile to the same few memory channels; 32 extra
-// doubles (256 B, one channel-interleave granule) per row spread a tile's rows over the channels.
+// Layout of the per-ordering work matrices in HBM: CHUNK-MAJOR.  A p_pad x p_pad matrix is stored as
+// p_pad/16 column chunks of 16 columns; inside a chunk the rows follow each other (128 B per row):
+//     element (r, c)  ->  ((c >> 4) * p_pad + r) * 16 + (c & 15)
+// Every operand tile the factorisation kernels stage -- R rows x 16 k -- is then ONE contiguous
+// R * 128-byte block (8-16 KB) instead of R separate 128-byte row segments 8 KB apart, which is what
+// a row-major matrix gives and what held the k-loops at ~3.9 TB/s.
+// The tile loaders below take it as a row-major tile with row stride CM_LD = 16.
+constexpr int CM_LD = 16;
+__host__ __device__ inline int64_t cm_off(int p_pad, int r, int c) {
+  return ((int64_t)(c >> 4) * p_pad + r) * 16 + (c & 15);
+}
+// V (solve result) stays row-major: its tiles are 16 rows x 1 KB.  32 extra doubles per row keep a
+// tile's rows from landing on the same few memory channels (m_pad is a multiple of 128).
 constexpr int LD_PAD = 32;
-__host__ __device__ inline int64_t lda_of(int p_pad) { return (int64_t)p_pad + LD_PAD; }
 __host__ __device__ inline int64_t ldv_of(int m_pad) { return (int64_t)m_pad + LD_PAD; }
 // rows of a V matrix: the ordering's row blocks rounded up to the 128-row strip step
 __host__ __device__ inline int64_t v_rows_of(int p) { return (int64_t)((p + 127) / 128) * 128; }
