@@ -291,7 +291,6 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
       rk_load<128>(ri, srcI + (c + 1) * chunk, CM_LD, tid, rows_valid);
     }
     if (32 * w >= rows_valid) continue;  // half tile at the bottom: this wave's rows do not exist
-    if (flags & 16) continue;            // timing probe: no k-loop MFMAs (results wrong)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       double av[4], bv[2];

@@ -18,7 +18,7 @@ def load(d):
     return agg
 
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
-per_batch = {"gather_kernel": 1, "chol_diag_kernel": 16, "chol_panel_kernel": 15, "strip_kernel": 1,
+per_batch = {"gather_kernel": 1, "chol_diag_kernel": 1, "chol_panel_kernel": 15, "strip_kernel": 1,
              "lift_partial_kernel": 1, "lift_finish_kernel": 1, "stats_batch_kernel": 1}
 rows, traffic = [], {}
 for k, n in per_batch.items():
