@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
   const double* S = a.S[src];
   const double* svec = a.s[src];
   double* out = a.A + (int64_t)mat * p_pad * p_pad;   // chunk-major, see tiles.h
+  double* d0 = a.diag0 + (int64_t)mat * p_pad;
 
   const int jmax = min(i0 + GROWS, p);  // permutation entries this workgroup can touch
   for (int j = tid; j < jmax; j += 256) sperm[j] = perm[j];
@@ -60,11 +61,14 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
         v.y = (j + 1 <= i) ? rowbuf[sperm[j + 1]] : 0.0;
         *reinterpret_cast<double2*>(out + cm_off(p_pad, i, j)) = v;   // j even: both in one chunk
       }
+      if (tid == 0) d0[i] = rowbuf[sperm[i]];
     } else if (i == p) {
       for (int j = tid; j < jend; j += 256)
         out[cm_off(p_pad, i, j)] = (j < p) ? svec[sperm[j]] : (j == p ? a.aug[src] : 0.0);
+      if (tid == 0) d0[i] = a.aug[src];
     } else {
       for (int j = tid; j < jend; j += 256) out[cm_off(p_pad, i, j)] = (j == i) ? 1.0 : 0.0;
+      if (tid == 0) d0[i] = 1.0;
     }
   }
 }
@@ -108,8 +112,11 @@ struct ElimScratch {
 // and Y(ty + 16 a, tx + 16 c) in registers.  Elimination on [T | Y] without scaling: after step k
 // column k of T is final (= L[:,k] * L[k][k]) and row k of Y is final (= (L^-1)[k,:] * L[k][k]).
 // Per step only column k of T, row k of Y and the pivot travel through LDS (one barrier per step).
+// A pivot d is accepted when d > piv_tol * (the matrix's own diagonal entry before any update), i.e.
+// when the feature keeps more than piv_tol of its variance after regressing on the earlier ones.
 __device__ __forceinline__ void eliminate_block64(double* __restrict__ M, int p_pad, int r0,
-                                                  double* __restrict__ Dg, int32_t* __restrict__ info,
+                                                  double* __restrict__ Dg, const double* __restrict__ diag0,
+                                                  double piv_tol, int32_t* __restrict__ info,
                                                   ElimScratch* sc, int tid) {
   const int ty = tid >> 4, tx = tid & 15;
   double T[4][4], Y[4][4];
@@ -140,7 +147,7 @@ __device__ __forceinline__ void eliminate_block64(double* __restrict__ M, int p_
       }
       __syncthreads();
       double d = sc->piv[buf];
-      if (!(d > 0.0)) {  // not positive definite (or NaN): flag it and keep going finitely
+      if (!(d > piv_tol * diag0[r0 + k])) {  // numerically not positive definite (or NaN): flag it, go on finitely
         d = 1.0;
         if (tid == 0) sc->bad = 1;
       }
@@ -196,18 +203,20 @@ __device__ __forceinline__ void eliminate_block64(double* __restrict__ M, int p_
 // Stand-alone launch: only block 0 needs it (later diagonal blocks are factored by the panel
 // workgroup that applied their last update).
 __global__ __launch_bounds__(256, 2) void chol_diag_kernel(double* __restrict__ A, double* __restrict__ Dinv,
+                                                           const double* __restrict__ diag0, double piv_tol,
                                                            int32_t* __restrict__ info, int p_pad, int J,
                                                            int nblk) {
   __shared__ ElimScratch sc;
   const int mt = blockIdx.x;
   double* M = A + (int64_t)mt * p_pad * p_pad;
-  eliminate_block64(M, p_pad, J * NB, Dinv + ((int64_t)mt * nblk + J) * 4096, info, &sc, threadIdx.x);
+  eliminate_block64(M, p_pad, J * NB, Dinv + ((int64_t)mt * nblk + J) * 4096, diag0 + (int64_t)mt * p_pad,
+                    piv_tol, info, &sc, threadIdx.x);
 }
 
-hipError_t launch_chol_diag(double* A, double* Dinv, int32_t* info, int p_pad, int J, int n_mats,
-                            hipStream_t st) {
+hipError_t launch_chol_diag(double* A, double* Dinv, const double* diag0, double piv_tol, int32_t* info,
+                            int p_pad, int J, int n_mats, hipStream_t st) {
   if (p_pad % NB != 0 || J < 0 || J >= p_pad / NB || n_mats < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(chol_diag_kernel, dim3(n_mats), dim3(256), 0, st, A, Dinv, info, p_pad, J,
+  hipLaunchKernelGGL(chol_diag_kernel, dim3(n_mats), dim3(256), 0, st, A, Dinv, diag0, piv_tol, info, p_pad, J,
                      p_pad / NB);
   return hipGetLastError();
 }
@@ -216,6 +225,7 @@ hipError_t launch_chol_diag(double* A, double* Dinv, int32_t* info, int p_pad, i
 // its slice of the output buffer, coalesced, no workgroup barrier) and collect +L[J,K] L[I,K]^T.
 // -C^T is exactly the B operand of (L_JJ^-1) * C^T: no LDS round trip between the two products.
 __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__ A, double* __restrict__ Dinv,
+                                                            const double* __restrict__ diag0, double piv_tol,
                                                             int32_t* __restrict__ info, int p_pad, int J,
                                                             int nblk, int flags) {
   // LDS: 52,224 B, so that three workgroups fit one CU.  Region A holds the two operand tiles
@@ -394,18 +404,19 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
   if (tile == 0 && !(flags & 2)) {
     __threadfence_block();
     __syncthreads();  // the update above was written by waves 0 and 1; region A is free again
-    eliminate_block64(M, p_pad, I0, Dinv + ((int64_t)mt * nblk + J + 1) * 4096, info,
-                      reinterpret_cast<ElimScratch*>(s_a), tid);
+    eliminate_block64(M, p_pad, I0, Dinv + ((int64_t)mt * nblk + J + 1) * 4096, diag0 + (int64_t)mt * p_pad,
+                      piv_tol, info, reinterpret_cast<ElimScratch*>(s_a), tid);
   }
 }
 
-hipError_t launch_chol_panel(double* A, double* Dinv, int32_t* info, int p_pad, int J, int n_mats, int flags,
-                             hipStream_t st) {
+hipError_t launch_chol_panel(double* A, double* Dinv, const double* diag0, double piv_tol, int32_t* info,
+                             int p_pad, int J, int n_mats, int flags, hipStream_t st) {
   const int nblk = p_pad / NB;
   if (p_pad % NB != 0 || J < 0 || J >= nblk - 1 || n_mats < 1) return hipErrorInvalidValue;
   const int rows_below = p_pad - (J + 1) * NB;
   dim3 grid(n_mats, (rows_below + 127) / 128);
-  hipLaunchKernelGGL(chol_panel_kernel, grid, dim3(256), 0, st, A, Dinv, info, p_pad, J, nblk, flags);
+  hipLaunchKernelGGL(chol_panel_kernel, grid, dim3(256), 0, st, A, Dinv, diag0, piv_tol, info, p_pad, J, nblk,
+                     flags);
   return hipGetLastError();
 }
 

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(const T* __restrict__ X, c
 
 // C[i][j] = C[j][i] = sum over slices of the pair's slab, fixed order
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ slabs, int n_split,
-                                                          int n_pairs, int P1pad, double* __restrict__ C) {
+                                                          int n_pairs, int P1pad, double* __restrict__ C,
+                                                          int accumulate) {
   int pair = blockIdx.x, ti = 0;
   while (pair >= ti + 1) {
     pair -= ti + 1;
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
     double s = 0.0;
     for (int k = 0; k < n_split; ++k) s += slabs[((int64_t)k * n_pairs + blockIdx.x) * (128 * 128) + e];
     const int i = ti * 128 + (e >> 7), j = tj * 128 + (e & 127);
+    if (accumulate) s += C[(int64_t)i * P1pad + j];   // fixed chunk order: still reproducible
     C[(int64_t)i * P1pad + j] = s;
     if (ti != tj) C[(int64_t)j * P1pad + i] = s;
   }
@@ -162,7 +164,8 @@ hipError_t launch_gram(const GramArgs& a, hipStream_t st) {
                        (const double*)a.y, a.n, a.ld, a.p, (int)rps, np, a.slabs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(np, 8), dim3(256), 0, st, a.slabs, a.n_split, np, P1pad, a.C);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(np, 8), dim3(256), 0, st, a.slabs, a.n_split, np, P1pad, a.C,
+                     a.accumulate);
   return hipGetLastError();
 }
 

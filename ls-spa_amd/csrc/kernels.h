@@ -14,15 +14,17 @@ struct GatherArgs {
   const int32_t* perms;    // [n_ord][p]
   int p, p_pad, n_ord, n_src;  // n_src = 1 (train only) or 2
   double* A;               // [n_src * n_ord][p_pad][p_pad], lower triangles written
+  double* diag0;           // [n_src * n_ord][p_pad]: the permuted diagonals before any update (pivot scale)
 };
 hipError_t launch_gather(const GatherArgs& a, hipStream_t st);
 
 // one left-looking block step J of the batched Cholesky factorisation
-hipError_t launch_chol_diag(double* A, double* Dinv, int32_t* info, int p_pad, int J, int n_mats,
-                            hipStream_t st);
+// diag0 / piv_tol: a pivot d counts as non-positive (LSSPA_INFO_NOT_PD) when d <= piv_tol * diag0
+hipError_t launch_chol_diag(double* A, double* Dinv, const double* diag0, double piv_tol, int32_t* info,
+                            int p_pad, int J, int n_mats, hipStream_t st);
 // panel step J; unless flags & 2, its tile-0 workgroups also factor diagonal block J + 1
-hipError_t launch_chol_panel(double* A, double* Dinv, int32_t* info, int p_pad, int J, int n_mats, int flags,
-                             hipStream_t st);
+hipError_t launch_chol_panel(double* A, double* Dinv, const double* diag0, double piv_tol, int32_t* info,
+                             int p_pad, int J, int n_mats, int flags, hipStream_t st);
 
 struct StripArgs {
   const double* A;         // factored train matrices, [n_ord][p_pad][p_pad]
@@ -68,6 +70,7 @@ struct GramArgs {
   double* slabs;           // workspace [n_split][n_pairs][128][128]
   int n_split;
   double* C;               // out: [P1pad][P1pad] full symmetric, P1pad = round_up(p + 1, 128)
+  int accumulate;          // C += (row chunks of a streamed matrix) instead of C =
 };
 size_t gram_workspace_bytes(int p, int n_split);
 int gram_default_split(int64_t n, int p);

@@ -50,7 +50,7 @@ struct lsspa_ctx {
   // per-batch workspace
   int cap_ord = 0;      // orderings the workspace can hold
   int cap_samples = 0;  // samples the lifts buffer can hold
-  DevBuf<double> A, V, Dinv, Ppart, lifts;
+  DevBuf<double> A, V, Dinv, Ppart, lifts, diag0;
   DevBuf<int32_t> perms_d, info_d;
   // pinned staging of the orderings: two buffers in turn, each guarded by the event of its last
   // H2D copy, so the host can prepare batch k+1 while the GPU still runs batch k (no stream sync)
@@ -231,7 +231,7 @@ size_t bytes_per_ordering(const lsspa_ctx* ctx) {
   const size_t nm = ctx->tri ? 2 : 1;
   (void)n_iblk;
   return nm * pp * pp * 8 + (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad) * 8 +
-         nm * nblk * 4096 * 8 +
+         nm * nblk * 4096 * 8 + nm * pp * 8 +
          (size_t)(ctx->m_pad / 64) * pp * 8 + (size_t)ctx->p * 4;
 }
 
@@ -253,6 +253,7 @@ int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
       dev_free(ctx->A);
       dev_free(ctx->V);
       dev_free(ctx->Dinv);
+      dev_free(ctx->diag0);
       dev_free(ctx->Ppart);
       dev_free(ctx->perms_d);
       const size_t pp = ctx->p_pad, nblk = pp / NB, n_iblk = (ctx->p + NB - 1) / NB;
@@ -261,6 +262,7 @@ int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
       (void)n_iblk;
       TRY(dev_alloc(ctx, ctx->V, (size_t)cap * (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad)));
       TRY(dev_alloc(ctx, ctx->Dinv, nm * cap * nblk * 4096));
+      TRY(dev_alloc(ctx, ctx->diag0, nm * cap * pp));
       TRY(dev_alloc(ctx, ctx->Ppart, (size_t)cap * (ctx->m_pad / 64) * pp));
       TRY(dev_alloc(ctx, ctx->perms_d, (size_t)cap * ctx->p));
       ctx->cap_ord = cap;
@@ -311,18 +313,22 @@ int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
     ga.n_ord = n_ord;
     ga.n_src = n_src;
     ga.A = ctx->A.ptr;
+    ga.diag0 = ctx->diag0.ptr;
     HIPCHK(launch_gather(ga, ctx->stream));
   }
   const bool fused = !(ctx->flags & 2);  // panel step J also factors diagonal block J + 1
+  // a pivot below ~p ulps of its feature's own variance is numerically zero (collinear feature)
+  const double piv_tol = 16.0 * (double)p * 2.220446049250313e-16;
   for (int J = 0; J < nblk; ++J) {
     if (J == 0 || !fused) {
       ProfScope ps(ctx, LSSPA_K_CHOL_DIAG);
-      HIPCHK(launch_chol_diag(ctx->A.ptr, ctx->Dinv.ptr, ctx->info_d.ptr, p_pad, J, n_mats, ctx->stream));
+      HIPCHK(launch_chol_diag(ctx->A.ptr, ctx->Dinv.ptr, ctx->diag0.ptr, piv_tol, ctx->info_d.ptr, p_pad, J,
+                              n_mats, ctx->stream));
     }
     if (J + 1 < nblk) {
       ProfScope ps(ctx, LSSPA_K_CHOL_PANEL);
-      HIPCHK(launch_chol_panel(ctx->A.ptr, ctx->Dinv.ptr, ctx->info_d.ptr, p_pad, J, n_mats, ctx->flags,
-                               ctx->stream));
+      HIPCHK(launch_chol_panel(ctx->A.ptr, ctx->Dinv.ptr, ctx->diag0.ptr, piv_tol, ctx->info_d.ptr, p_pad, J,
+                               n_mats, ctx->flags, ctx->stream));
     }
   }
   {
@@ -465,7 +471,7 @@ int lsspa_destroy(lsspa_ctx* ctx) {
   }
   dev_free(ctx->G); dev_free(ctx->g); dev_free(ctx->H); dev_free(ctx->h); dev_free(ctx->Ft);
   dev_free(ctx->ytil); dev_free(ctx->scal); dev_free(ctx->A); dev_free(ctx->V); dev_free(ctx->Dinv);
-  dev_free(ctx->Ppart); dev_free(ctx->lifts); dev_free(ctx->perms_d); dev_free(ctx->info_d);
+  dev_free(ctx->Ppart); dev_free(ctx->lifts); dev_free(ctx->diag0); dev_free(ctx->perms_d); dev_free(ctx->info_d);
   dev_free(ctx->mean); dev_free(ctx->M2); dev_free(ctx->pend); dev_free(ctx->state_n);
   for (int b = 0; b < 2; ++b) {
     if (ctx->perms_h[b]) (void)hipHostFree(ctx->perms_h[b]);
@@ -518,6 +524,7 @@ static int gram_side(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, in
     ga.slabs = slabs.ptr;
     ga.n_split = n_split;
     ga.C = C.ptr;
+    ga.accumulate = 0;
     hipError_t e = launch_gram(ga, ctx->stream);
     if (e == hipSuccess) e = launch_gram_finalize(C.ptr, p, scale, reg, G, ctx->p_pad, g, scalar_out, ctx->stream);
     if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "gram launch", e);
@@ -525,6 +532,98 @@ static int gram_side(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, in
   if (rc == LSSPA_OK) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "gram sync", e);
+  }
+  dev_free(slabs);
+  dev_free(C);
+  return rc;
+}
+
+// Gram of a HOST-resident [n][ld] matrix, streamed: the rows cross PCIe in chunks through two device
+// buffers on a copy stream while the previous chunk's Gram runs on the compute stream; the chunk
+// Grams accumulate in C in chunk order.  The caller's array is pinned in place for the duration
+// (hipHostRegister) when the runtime allows it, so the copies are true DMA.
+static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, int64_t ld, int p,
+                              int is_f32, double scale, double reg, double* G, double* g, double* scalar_out) {
+  const size_t es = is_f32 ? 4 : 8;
+  const int P1pad = round_up(p + 1, 128);
+  int64_t rows = (((int64_t)96 << 20) / ((int64_t)p * (int64_t)es) / 16) * 16;   // ~96 MB chunks
+  rows = std::max<int64_t>(1024, std::min<int64_t>(rows, ((n + 15) / 16) * 16));
+  const int n_split = gram_default_split(rows, p);
+  DevBuf<double> slabs, C;
+  void* dX[2] = {nullptr, nullptr};
+  void* dy[2] = {nullptr, nullptr};
+  hipStream_t cs = nullptr;
+  hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+  bool reg_x = false, reg_y = false;
+  int rc = dev_alloc(ctx, slabs, gram_workspace_bytes(p, n_split) / sizeof(double));
+  if (rc == LSSPA_OK) rc = dev_alloc(ctx, C, (size_t)P1pad * P1pad);
+  hipError_t e = hipSuccess;
+  if (rc == LSSPA_OK) {
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+      e = hipMalloc(&dX[b], (size_t)rows * p * es);
+      if (e == hipSuccess) e = hipMalloc(&dy[b], (size_t)rows * es);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&copied[b], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_NOMEM, "streamed reduction buffers", e);
+  }
+  if (rc == LSSPA_OK) {
+    // pin the caller's arrays in place; harmless if refused (the copies then stage through the runtime)
+    reg_x = hipHostRegister(const_cast<void*>(X), (size_t)n * ld * es, hipHostRegisterDefault) == hipSuccess;
+    reg_y = hipHostRegister(const_cast<void*>(y), (size_t)n * es, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+    ProfScope ps(ctx, LSSPA_K_GRAM);
+    int k = 0;
+    for (int64_t r0 = 0; r0 < n && e == hipSuccess; r0 += rows, ++k) {
+      const int b = k & 1;
+      const int64_t nr = std::min<int64_t>(rows, n - r0);
+      if (k >= 2) e = hipStreamWaitEvent(cs, consumed[b], 0);   // the Gram of chunk k-2 has read this buffer
+      const char* src = static_cast<const char*>(X) + (size_t)r0 * ld * es;
+      if (e == hipSuccess) {
+        if (ld == p)
+          e = hipMemcpyAsync(dX[b], src, (size_t)nr * p * es, hipMemcpyHostToDevice, cs);
+        else
+          e = hipMemcpy2DAsync(dX[b], (size_t)p * es, src, (size_t)ld * es, (size_t)p * es, (size_t)nr,
+                               hipMemcpyHostToDevice, cs);
+      }
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(dy[b], static_cast<const char*>(y) + (size_t)r0 * es, (size_t)nr * es,
+                           hipMemcpyHostToDevice, cs);
+      if (e == hipSuccess) e = hipEventRecord(copied[b], cs);
+      if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, copied[b], 0);
+      if (e == hipSuccess) {
+        GramArgs ga;
+        ga.X = dX[b];
+        ga.y = dy[b];
+        ga.n = nr;
+        ga.ld = p;
+        ga.p = p;
+        ga.is_f32 = is_f32;
+        ga.slabs = slabs.ptr;
+        ga.n_split = n_split;
+        ga.C = C.ptr;
+        ga.accumulate = k > 0;
+        e = launch_gram(ga, ctx->stream);
+      }
+      if (e == hipSuccess) e = hipEventRecord(consumed[b], ctx->stream);
+    }
+    if (e == hipSuccess) e = launch_gram_finalize(C.ptr, p, scale, reg, G, ctx->p_pad, g, scalar_out, ctx->stream);
+    if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "streamed gram", e);
+  }
+  hipError_t es1 = hipStreamSynchronize(ctx->stream);
+  if (cs) {
+    (void)hipStreamSynchronize(cs);
+    (void)hipStreamDestroy(cs);
+  }
+  if (rc == LSSPA_OK && es1 != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "streamed gram sync", es1);
+  if (reg_x) (void)hipHostUnregister(const_cast<void*>(X));
+  if (reg_y) (void)hipHostUnregister(const_cast<void*>(y));
+  for (int b = 0; b < 2; ++b) {
+    if (dX[b]) (void)hipFree(dX[b]);
+    if (dy[b]) (void)hipFree(dy[b]);
+    if (copied[b]) (void)hipEventDestroy(copied[b]);
+    if (consumed[b]) (void)hipEventDestroy(consumed[b]);
   }
   dev_free(slabs);
   dev_free(C);
@@ -553,6 +652,13 @@ int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const vo
     void *tX = nullptr, *ty = nullptr;
     int64_t dld = ld;
     int rc = LSSPA_OK;
+    if (location == LSSPA_HOST && (train || tri)) {
+      if (train)
+        return gram_side_streamed(ctx, X, y, n, ld, p, dtype == LSSPA_F32, 1.0 / (double)n, reg, ctx->G.ptr,
+                                  ctx->g.ptr, ctx->scal.ptr + 0);
+      return gram_side_streamed(ctx, X, y, n, ld, p, dtype == LSSPA_F32, 1.0, 0.0, ctx->H.ptr, ctx->h.ptr,
+                                ctx->scal.ptr + 1);
+    }
     if (location == LSSPA_HOST) {
       hipError_t e = hipMalloc(&tX, (size_t)n * p * es);
       if (e == hipSuccess) e = hipMalloc(&ty, (size_t)n * es);
