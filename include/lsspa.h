@@ -63,6 +63,12 @@ int lsspa_set_reduced(lsspa_ctx* ctx, int32_t p, const double* G, const double* 
                       int32_t tri, const double* H, const double* h, int32_t m, const double* Ft,
                       const double* ytil, double y_norm_sq);
 
+/* Element type of the per-ordering work (Cholesky factors, solves): LSSPA_F64 (default; matches the
+ * reference to ~1e-15) or LSSPA_F32 (half the HBM traffic, fp32 MFMA; the Gram reduction, the lift
+ * accumulation and the running statistics stay fp64).  The reference has no counterpart: it computes
+ * in float64 throughout (ls_spa/ls_spa.py:309-317). */
+int lsspa_set_precision(lsspa_ctx* ctx, int32_t dtype);
+
 int lsspa_get_problem(const lsspa_ctx* ctx, int32_t* p, int32_t* m, int32_t* tri, double* y_norm_sq);
 /* device -> host copies of the reduced problem; any pointer may be NULL */
 int lsspa_get_gram(lsspa_ctx* ctx, double* G, double* g, double* H, double* h);
@@ -110,7 +116,7 @@ int lsspa_profile_reset(lsspa_ctx* ctx);
 int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);
 
 /* test hooks */
-int lsspa_mfma_probe(lsspa_ctx* ctx, const double* A16x4, const double* B4x16, double* D16x16);
+int lsspa_mfma_probe(lsspa_ctx* ctx, const double* A16x4, const double* B4x16, double* D16x16, int32_t dtype);
 /* factor one ordering and copy the padded factor(s) out: L [p_pad][p_pad] (train),
  * Lt [p_pad][p_pad] (test, tri mode only, else untouched), V [n_iblk*64][m_pad] */
 int lsspa_debug_factor(lsspa_ctx* ctx, const int32_t* perm, double* L, double* Lt, double* V,

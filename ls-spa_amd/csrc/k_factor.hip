@@ -1,5 +1,6 @@
 // Per-ordering factorisation kernels: permuted gather, blocked left-looking Cholesky
-// (diagonal-block and panel steps) and the strip triangular solve.
+// (diagonal-block and panel steps) and the strip triangular solve.  Templated on the element type
+// of the work matrices (double: default; float: fp32 mode), see tiles.h.
 //
 // What they replace in the reference (cvxgrp/ls-spa, ls_spa/ls_spa.py):
 //   gather      -> X_train[:, perm], X_test[:, perm]                    (:275-276)
@@ -15,14 +16,18 @@ namespace lsspa {
 // gather:  A[mat][i][j] = S[perm[i]][perm[j]]  (j <= i),  row p = s[perm[.]] | aug,
 //          rows > p = identity.  One workgroup walks GROWS output rows; each source row
 //          is read once, coalesced, into LDS and the permuted columns are picked there,
-//          so both the global read and the global write are contiguous.
+//          so both the global read and the global write are contiguous.  The source Gram
+//          matrices are fp64 in both modes; fp32 mode rounds on the way out.
 // =====================================================================================
 constexpr int GROWS = 16;
 
+template <typename T>
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* rowbuf = reinterpret_cast<double*>(smem_raw);                      // [p_pad]
   int32_t* sperm = reinterpret_cast<int32_t*>(smem_raw + sizeof(double) * a.p_pad);  // [p_pad]
+  constexpr int VE = Tr<T>::VE;
+  typedef typename Tr<T>::vec_t vec_t;
 
   const int tid = threadIdx.x;
   const int mat = blockIdx.y;
@@ -33,7 +38,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
   const int32_t* perm = a.perms + (int64_t)ord * p;
   const double* S = a.S[src];
   const double* svec = a.s[src];
-  double* out = a.A + (int64_t)mat * p_pad * p_pad;   // chunk-major, see tiles.h
+  T* out = static_cast<T*>(a.A) + (int64_t)mat * p_pad * p_pad;   // chunk-major, see tiles.h
   double* d0 = a.diag0 + (int64_t)mat * p_pad;
 
   const int jmax = min(i0 + GROWS, p);  // permutation entries this workgroup can touch
@@ -49,25 +54,25 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
       __syncthreads();  // previous row's picks are done
       for (int c = 2 * tid; c < p; c += 512) {
         if (c + 1 < p) {
-          *reinterpret_cast<double2*>(rowbuf + c) = *reinterpret_cast<const double2*>(srow + c);
+          *reinterpret_cast<v2d*>(rowbuf + c) = *reinterpret_cast<const v2d*>(srow + c);
         } else {
           rowbuf[c] = srow[c];
         }
       }
       __syncthreads();
-      for (int j = 2 * tid; j < jend; j += 512) {
-        double2 v;
-        v.x = (j <= i) ? rowbuf[sperm[j]] : 0.0;
-        v.y = (j + 1 <= i) ? rowbuf[sperm[j + 1]] : 0.0;
-        *reinterpret_cast<double2*>(out + cm_off(p_pad, i, j)) = v;   // j even: both in one chunk
+      for (int j = VE * tid; j < jend; j += VE * 256) {   // VE consecutive j stay inside one 16-column chunk
+        vec_t v;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[e] = (j + e <= i) ? (T)rowbuf[sperm[j + e]] : (T)0;
+        *reinterpret_cast<vec_t*>(out + cm_off(p_pad, i, j)) = v;
       }
       if (tid == 0) d0[i] = rowbuf[sperm[i]];
     } else if (i == p) {
       for (int j = tid; j < jend; j += 256)
-        out[cm_off(p_pad, i, j)] = (j < p) ? svec[sperm[j]] : (j == p ? a.aug[src] : 0.0);
+        out[cm_off(p_pad, i, j)] = (T)((j < p) ? svec[sperm[j]] : (j == p ? a.aug[src] : 0.0));
       if (tid == 0) d0[i] = a.aug[src];
     } else {
-      for (int j = tid; j < jend; j += 256) out[cm_off(p_pad, i, j)] = (j == i) ? 1.0 : 0.0;
+      for (int j = tid; j < jend; j += 256) out[cm_off(p_pad, i, j)] = (j == i) ? (T)1 : (T)0;
       if (tid == 0) d0[i] = 1.0;
     }
   }
@@ -78,11 +83,14 @@ hipError_t launch_gather(const GatherArgs& a, hipStream_t st) {
       (a.ld_src & 1))
     return hipErrorInvalidValue;
   const size_t shmem = sizeof(double) * a.p_pad + sizeof(int32_t) * a.p_pad;
-  if (shmem > 160 * 1024) return hipErrorInvalidValue;
+  if (shmem > 64 * 1024) return hipErrorInvalidValue;
   dim3 grid((a.p_pad + GROWS - 1) / GROWS, a.n_ord * a.n_src);
   // aug row reads sperm[j] for all j < p: the workgroup holding row p must have them all
   // (jmax = min(i0 + GROWS, p) = p there), so nothing else to arrange.
-  hipLaunchKernelGGL(gather_kernel, grid, dim3(256), shmem, st, a);
+  if (a.f32)
+    hipLaunchKernelGGL(gather_kernel<float>, grid, dim3(256), shmem, st, a);
+  else
+    hipLaunchKernelGGL(gather_kernel<double>, grid, dim3(256), shmem, st, a);
   return hipGetLastError();
 }
 
@@ -98,12 +106,13 @@ hipError_t launch_gather(const GatherArgs& a, hipStream_t st) {
 //                        then, while L[I,J] sits in LDS for its coalesced store, the two
 //                        diagonal tiles of the tile's own rows get  -= L[I',J] L[I',J]^T.
 // =====================================================================================
-// LDS scratch of the 64 x 64 elimination (2,600 B)
+// LDS scratch of the 64 x 64 elimination
+template <typename T>
 struct ElimScratch {
-  double col[2][64];  // column k of T (unscaled), double-buffered by k parity
-  double row[2][64];  // row k of Y
-  double piv[2];
-  double dd[64];
+  T col[2][64];  // column k of T (unscaled), double-buffered by k parity
+  T row[2][64];  // row k of Y
+  T piv[2];
+  T dd[64];
   int bad;
 };
 
@@ -114,20 +123,20 @@ struct ElimScratch {
 // Per step only column k of T, row k of Y and the pivot travel through LDS (one barrier per step).
 // A pivot d is accepted when d > piv_tol * (the matrix's own diagonal entry before any update), i.e.
 // when the feature keeps more than piv_tol of its variance after regressing on the earlier ones.
-__device__ __forceinline__ void eliminate_block64(double* __restrict__ M, int p_pad, int r0,
-                                                  double* __restrict__ Dg, const double* __restrict__ diag0,
-                                                  double piv_tol, int32_t* __restrict__ info,
-                                                  ElimScratch* sc, int tid) {
+template <typename T>
+__device__ __forceinline__ void eliminate_block64(T* __restrict__ M, int p_pad, int r0, T* __restrict__ Dg,
+                                                  const double* __restrict__ diag0, double piv_tol,
+                                                  int32_t* __restrict__ info, ElimScratch<T>* sc, int tid) {
   const int ty = tid >> 4, tx = tid & 15;
-  double T[4][4], Y[4][4];
+  T Tm[4][4], Y[4][4];
   if (tid == 0) sc->bad = 0;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int row = ty + 16 * a, col = tx + 16 * c;
-      T[a][c] = (col <= row) ? M[cm_off(p_pad, r0 + row, r0 + col)] : 0.0;
-      Y[a][c] = (row == col) ? 1.0 : 0.0;
+      Tm[a][c] = (col <= row) ? M[cm_off(p_pad, r0 + row, r0 + col)] : (T)0;
+      Y[a][c] = (row == col) ? (T)1 : (T)0;
     }
 
 #pragma unroll
@@ -138,22 +147,22 @@ __device__ __forceinline__ void eliminate_block64(double* __restrict__ M, int p_
       const int buf = k & 1;
       if (tx == kk) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) sc->col[buf][ty + 16 * a] = T[a][kc];
+        for (int a = 0; a < 4; ++a) sc->col[buf][ty + 16 * a] = Tm[a][kc];
       }
       if (ty == kk) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) sc->row[buf][tx + 16 * c] = Y[kc][c];
-        if (tx == kk) sc->piv[buf] = T[kc][kc];
+        if (tx == kk) sc->piv[buf] = Tm[kc][kc];
       }
       __syncthreads();
-      double d = sc->piv[buf];
-      if (!(d > piv_tol * diag0[r0 + k])) {  // numerically not positive definite (or NaN): flag it, go on finitely
-        d = 1.0;
+      T d = sc->piv[buf];
+      if (!((double)d > piv_tol * diag0[r0 + k])) {  // numerically not positive definite (or NaN): flag it, go on
+        d = (T)1;
         if (tid == 0) sc->bad = 1;
       }
       if (tid == 0) sc->dd[k] = d;
-      const double invd = 1.0 / d;
-      double cj[4], rc[4];
+      const T invd = (T)1 / d;
+      T cj[4], rc[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         cj[c] = sc->col[buf][tx + 16 * c];
@@ -165,16 +174,16 @@ __device__ __forceinline__ void eliminate_block64(double* __restrict__ M, int p_
       for (int a = 0; a < 4; ++a) {
         if (a < kc) continue;
         const int i = ty + 16 * a;
-        const double f = (i > k) ? sc->col[buf][i] * invd : 0.0;
+        const T f = (i > k) ? sc->col[buf][i] * invd : (T)0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int j = tx + 16 * c;
           if (c < kc) {
             Y[a][c] -= f * rc[c];
           } else if (c > kc) {
-            if (c <= a && j <= i) T[a][c] -= f * cj[c];
+            if (c <= a && j <= i) Tm[a][c] -= f * cj[c];
           } else {
-            if (j > k && j <= i) T[a][c] -= f * cj[c];
+            if (j > k && j <= i) Tm[a][c] -= f * cj[c];
             if (j <= k) Y[a][c] -= f * rc[c];
           }
         }
@@ -182,7 +191,7 @@ __device__ __forceinline__ void eliminate_block64(double* __restrict__ M, int p_
     }
   }
   __syncthreads();
-  if (tid < 64) sc->dd[tid] = 1.0 / sqrt(sc->dd[tid]);  // now holds 1 / L[k][k]
+  if (tid < 64) sc->dd[tid] = (T)1 / sqrt(sc->dd[tid]);  // now holds 1 / L[k][k]
   __syncthreads();
 
 #pragma unroll
@@ -190,9 +199,9 @@ __device__ __forceinline__ void eliminate_block64(double* __restrict__ M, int p_
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int row = ty + 16 * a, col = tx + 16 * c;
-      double lv = 0.0, xv = 0.0;
-      if (col < row) lv = T[a][c] * sc->dd[col];
-      if (col == row) lv = 1.0 / sc->dd[col];
+      T lv = (T)0, xv = (T)0;
+      if (col < row) lv = Tm[a][c] * sc->dd[col];
+      if (col == row) lv = (T)1 / sc->dd[col];
       if (col <= row) xv = Y[a][c] * sc->dd[row];
       M[cm_off(p_pad, r0 + row, r0 + col)] = lv;
       Dg[row * 64 + col] = xv;
@@ -202,42 +211,51 @@ __device__ __forceinline__ void eliminate_block64(double* __restrict__ M, int p_
 
 // Stand-alone launch: only block 0 needs it (later diagonal blocks are factored by the panel
 // workgroup that applied their last update).
-__global__ __launch_bounds__(256, 2) void chol_diag_kernel(double* __restrict__ A, double* __restrict__ Dinv,
+template <typename T>
+__global__ __launch_bounds__(256, 2) void chol_diag_kernel(T* __restrict__ A, T* __restrict__ Dinv,
                                                            const double* __restrict__ diag0, double piv_tol,
                                                            int32_t* __restrict__ info, int p_pad, int J,
                                                            int nblk) {
-  __shared__ ElimScratch sc;
+  __shared__ ElimScratch<T> sc;
   const int mt = blockIdx.x;
-  double* M = A + (int64_t)mt * p_pad * p_pad;
-  eliminate_block64(M, p_pad, J * NB, Dinv + ((int64_t)mt * nblk + J) * 4096, diag0 + (int64_t)mt * p_pad,
-                    piv_tol, info, &sc, threadIdx.x);
+  T* M = A + (int64_t)mt * p_pad * p_pad;
+  eliminate_block64<T>(M, p_pad, J * NB, Dinv + ((int64_t)mt * nblk + J) * 4096, diag0 + (int64_t)mt * p_pad,
+                       piv_tol, info, &sc, threadIdx.x);
 }
 
-hipError_t launch_chol_diag(double* A, double* Dinv, const double* diag0, double piv_tol, int32_t* info,
-                            int p_pad, int J, int n_mats, hipStream_t st) {
+hipError_t launch_chol_diag(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
+                            int J, int n_mats, int f32, hipStream_t st) {
   if (p_pad % NB != 0 || J < 0 || J >= p_pad / NB || n_mats < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(chol_diag_kernel, dim3(n_mats), dim3(256), 0, st, A, Dinv, diag0, piv_tol, info, p_pad, J,
-                     p_pad / NB);
+  if (f32)
+    hipLaunchKernelGGL(chol_diag_kernel<float>, dim3(n_mats), dim3(256), 0, st, (float*)A, (float*)Dinv, diag0,
+                       piv_tol, info, p_pad, J, p_pad / NB);
+  else
+    hipLaunchKernelGGL(chol_diag_kernel<double>, dim3(n_mats), dim3(256), 0, st, (double*)A, (double*)Dinv,
+                       diag0, piv_tol, info, p_pad, J, p_pad / NB);
   return hipGetLastError();
 }
 
 // The accumulators hold -C^T: they start at -A[I,J]^T (each wave stages its own 32 rows through
 // its slice of the output buffer, coalesced, no workgroup barrier) and collect +L[J,K] L[I,K]^T.
 // -C^T is exactly the B operand of (L_JJ^-1) * C^T: no LDS round trip between the two products.
-__global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__ A, double* __restrict__ Dinv,
+template <typename T>
+__global__ __launch_bounds__(256, 3) void chol_panel_kernel(T* __restrict__ A, T* __restrict__ Dinv,
                                                             const double* __restrict__ diag0, double piv_tol,
                                                             int32_t* __restrict__ info, int p_pad, int J,
                                                             int nblk, int flags) {
-  // LDS: 52,224 B, so that three workgroups fit one CU.  Region A holds the two operand tiles
+  typedef typename Tr<T>::acc_t acc_t;
+  typedef typename Tr<T>::vec_t vec_t;
+  constexpr int VE = Tr<T>::VE;
+  // LDS (fp64: 52,224 B, so that three workgroups fit one CU).  Region A holds the two operand tiles
   // of the main loop and, after it, L_JJ^-1; region B is the output / update staging tile.
-  __shared__ __attribute__((aligned(16))) double s_a[64 * DI_LD];
-  __shared__ __attribute__((aligned(16))) double s_b[128 * RK_LD];
+  __shared__ __attribute__((aligned(16))) T s_a[64 * DI_LD];
+  __shared__ __attribute__((aligned(16))) T s_b[128 * RK_LD];
   static_assert(64 * DI_LD >= 64 * RK_LD + 128 * RK_LD, "operand tiles must fit region A");
-  static_assert(sizeof(ElimScratch) <= sizeof(double) * 64 * DI_LD, "elimination scratch must fit region A");
-  double* const s_rkj = s_a;
-  double* const s_rki = s_a + 64 * RK_LD;
-  double* const s_dinv = s_a;
-  double* const s_out = s_b;
+  static_assert(sizeof(ElimScratch<T>) <= sizeof(T) * 64 * DI_LD, "elimination scratch must fit region A");
+  T* const s_rkj = s_a;
+  T* const s_rki = s_a + 64 * RK_LD;
+  T* const s_dinv = s_a;
+  T* const s_out = s_b;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -245,65 +263,68 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
   // the next diagonal block, start first
   const int mt = blockIdx.x;
   const int tile = blockIdx.y;
-  double* M = A + (int64_t)mt * p_pad * p_pad;
+  T* M = A + (int64_t)mt * p_pad * p_pad;
   const int J0 = J * NB;
   const int I0 = J0 + NB + tile * 128;
   const int rows_valid = min(128, p_pad - I0);
 
-  // chunk-major: rows J0.. / I0.. of k-chunk c are contiguous blocks, one chunk = p_pad * 16 doubles
-  const double* srcJ = M + cm_off(p_pad, J0, 0);
-  const double* srcI = M + cm_off(p_pad, I0, 0);
+  // chunk-major: rows J0.. / I0.. of k-chunk c are contiguous blocks, one chunk = p_pad * 16 elements
+  const T* srcJ = M + cm_off(p_pad, J0, 0);
+  const T* srcI = M + cm_off(p_pad, I0, 0);
   const int64_t chunk = (int64_t)p_pad * 16;
 
   const int nch = J0 / KCH;
-  RKRegs<64> rj = {};
-  RKRegs<128> ri = {};
+  RKRegs<T, 64> rj = {};
+  RKRegs<T, 128> ri = {};
   if (nch > 0) {
-    rk_load<64>(rj, srcJ, CM_LD, tid, 64);
-    rk_load<128>(ri, srcI, CM_LD, tid, rows_valid);
+    rk_load<T, 64>(rj, srcJ, CM_LD, tid, 64);
+    rk_load<T, 128>(ri, srcI, CM_LD, tid, rows_valid);
   }
 
-  // acc[x][y][r] <-> (column j = 16 x + l4 + 4 r of block J, row i = 32 w + 16 y + l15 of the tile)
-  d4 acc[4][2];
+  // acc[x][y][r] <-> (column j = 16 x + acc_row(l4, r) of block J, row i = 32 w + 16 y + l15 of the tile)
+  acc_t acc[4][2];
   {
-    const int rr = lane >> 3, ch = lane & 7;  // 8 rows x 8 16-byte chunks per wave instruction
-    v2d t[4][4];
+    constexpr int VPR = 16 / VE;        // 16-byte vectors per 16-column row piece
+    constexpr int RPI = 64 / VPR;       // rows per wave instruction: 8 (fp64) / 16 (fp32)
+    constexpr int NQ = 32 / RPI;        // passes over the wave's 32 rows
+    const int rr = lane / VPR, ch = lane % VPR;
+    vec_t t[4][NQ];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = 32 * w + rr + 8 * q;
-        t[x][q] = (i < rows_valid) ? *reinterpret_cast<const v2d*>(M + cm_off(p_pad, I0 + i, J0 + 16 * x + 2 * ch))
-                                   : v2d{0.0, 0.0};
+      for (int q = 0; q < NQ; ++q) {
+        const int i = 32 * w + rr + RPI * q;
+        t[x][q] = (i < rows_valid)
+                      ? *reinterpret_cast<const vec_t*>(M + cm_off(p_pad, I0 + i, J0 + 16 * x + VE * ch))
+                      : Tr<T>::vzero();
       }
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<v2d*>(s_out + (32 * w + rr + 8 * q) * RK_LD + 2 * ch) = t[x][q];
+      for (int q = 0; q < NQ; ++q) Tr<T>::lds_store(s_out + (32 * w + rr + RPI * q) * RK_LD + VE * ch, t[x][q]);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int y = 0; y < 2; ++y)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          acc[x][y][r] = -s_out[(32 * w + 16 * y + l15) * RK_LD + acc_row(l4, r)];
+          acc[x][y][r] = -s_out[(32 * w + 16 * y + l15) * RK_LD + Tr<T>::acc_row(l4, r)];
       __builtin_amdgcn_wave_barrier();
     }
   }
 
   for (int c = 0; c < nch; ++c) {
     __syncthreads();
-    rk_store<64>(rj, s_rkj, tid);
-    rk_store<128>(ri, s_rki, tid);
+    rk_store<T, 64>(rj, s_rkj, tid);
+    rk_store<T, 128>(ri, s_rki, tid);
     __syncthreads();
     if (c + 1 < nch) {
-      rk_load<64>(rj, srcJ + (c + 1) * chunk, CM_LD, tid, 64);
-      rk_load<128>(ri, srcI + (c + 1) * chunk, CM_LD, tid, rows_valid);
+      rk_load<T, 64>(rj, srcJ + (c + 1) * chunk, CM_LD, tid, 64);
+      rk_load<T, 128>(ri, srcI + (c + 1) * chunk, CM_LD, tid, rows_valid);
     }
     if (32 * w >= rows_valid) continue;  // half tile at the bottom: this wave's rows do not exist
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      double av[4], bv[2];
+      T av[4], bv[2];
 #pragma unroll
       for (int x = 0; x < 4; ++x) av[x] = s_rkj[(16 * x + l15) * RK_LD + 4 * kk + l4];
 #pragma unroll
@@ -311,21 +332,21 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
 #pragma unroll
       for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = mfma(av[x], bv[y], acc[x][y]);
+        for (int y = 0; y < 2; ++y) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
     }
   }
 
   __syncthreads();  // every wave is done with the operand tiles that L_JJ^-1 now overwrites
-  load_block64(s_dinv, Dinv + ((int64_t)mt * nblk + J) * 4096, tid);
+  load_block64<T>(s_dinv, Dinv + ((int64_t)mt * nblk + J) * 4096, tid);
   __syncthreads();
 
   // out^T[j'][i] = sum_k Dinv[j'][k] C[i][k] = sum_k (-Dinv[j'][k]) acc[k][i]
   // (Dinv lower triangular: k-blocks above j' vanish)
-  d4 outv[4][2];
+  acc_t outv[4][2];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
-    for (int y = 0; y < 2; ++y) outv[x][y] = d4_zero();
+    for (int y = 0; y < 2; ++y) outv[x][y] = Tr<T>::zero();
   if (32 * w < rows_valid) {
 #pragma unroll
     for (int xp = 0; xp < 4; ++xp)
@@ -333,21 +354,21 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
       for (int x = 0; x <= xp; ++x)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const double av = -s_dinv[(16 * xp + l15) * DI_LD + 16 * x + acc_row(l4, r)];
+          const T av = -s_dinv[(16 * xp + l15) * DI_LD + 16 * x + Tr<T>::acc_row(l4, r)];
 #pragma unroll
-          for (int y = 0; y < 2; ++y) outv[xp][y] = mfma(av, acc[x][y][r], outv[xp][y]);
+          for (int y = 0; y < 2; ++y) outv[xp][y] = Tr<T>::mfma(av, acc[x][y][r], outv[xp][y]);
         }
   }
 
-  // Store through the output buffer (128-B row segments) and, while each 16-column chunk of
+  // Store through the output buffer (contiguous row pieces) and, while each 16-column chunk of
   // L[I,J] is in LDS in operand layout, accumulate the symmetric updates of the tile's own two
   // diagonal blocks (lower tiles only).  Wave w -> sub-block sb = w >> 1; the 10 lower tiles of a
   // sub-block are split 5 / 5: tile rows {0, 3} for even waves, {1, 2} for odd ones.
-  d4 upd[2][4];
+  acc_t upd[2][4];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) upd[a][b] = d4_zero();
+    for (int b = 0; b < 4; ++b) upd[a][b] = Tr<T>::zero();
   const int sb = w >> 1;
   const int t1[2] = {(w & 1) ? 1 : 0, (w & 1) ? 2 : 3};
 #pragma unroll
@@ -357,20 +378,23 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        s_out[(32 * w + 16 * y + l15) * RK_LD + acc_row(l4, r)] = outv[xp][y][r];
+        s_out[(32 * w + 16 * y + l15) * RK_LD + Tr<T>::acc_row(l4, r)] = outv[xp][y][r];
     __syncthreads();
-    const int c = tid & 7, row = tid >> 3;
+    {
+      typedef RKRegs<T, 128> RR;
+      const int c = tid % RR::VPR, row = tid / RR::VPR;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int rr = row + 32 * q;
-      if (rr < rows_valid)
-        *reinterpret_cast<v2d*>(M + cm_off(p_pad, I0 + rr, J0 + 16 * xp + 2 * c)) =
-            *reinterpret_cast<const v2d*>(s_out + rr * RK_LD + 2 * c);
+      for (int q = 0; q < RR::NP; ++q) {
+        const int rr = row + RR::RPP * q;
+        if (rr < rows_valid)
+          *reinterpret_cast<vec_t*>(M + cm_off(p_pad, I0 + rr, J0 + 16 * xp + VE * c)) =
+              Tr<T>::lds_load(s_out + rr * RK_LD + VE * c);
+      }
     }
     if (64 * sb >= rows_valid) continue;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      double av[2], bv[4];
+      T av[2], bv[4];
 #pragma unroll
       for (int a = 0; a < 2; ++a) av[a] = s_out[(64 * sb + 16 * t1[a] + l15) * RK_LD + 4 * kk + l4];
 #pragma unroll
@@ -379,7 +403,7 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-          if (b <= t1[a]) upd[a][b] = mfma(av[a], bv[b], upd[a][b]);  // wave-uniform condition
+          if (b <= t1[a]) upd[a][b] = Tr<T>::mfma(av[a], bv[b], upd[a][b]);  // wave-uniform condition
     }
   }
   // A[I',I'] -= L[I',J] L[I',J]^T on the sub-block's diagonal tile (owned by this workgroup alone)
@@ -392,7 +416,7 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
         if (b > t1[a]) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 16 * t1[a] + acc_row(l4, r), col = 16 * b + l15;
+          const int row = 16 * t1[a] + Tr<T>::acc_row(l4, r), col = 16 * b + l15;
           if (col <= row) M[cm_off(p_pad, d0 + row, d0 + col)] -= upd[a][b][r];
         }
       }
@@ -404,19 +428,23 @@ __global__ __launch_bounds__(256, 3) void chol_panel_kernel(double* __restrict__
   if (tile == 0 && !(flags & 2)) {
     __threadfence_block();
     __syncthreads();  // the update above was written by waves 0 and 1; region A is free again
-    eliminate_block64(M, p_pad, I0, Dinv + ((int64_t)mt * nblk + J + 1) * 4096, diag0 + (int64_t)mt * p_pad,
-                      piv_tol, info, reinterpret_cast<ElimScratch*>(s_a), tid);
+    eliminate_block64<T>(M, p_pad, I0, Dinv + ((int64_t)mt * nblk + J + 1) * 4096,
+                         diag0 + (int64_t)mt * p_pad, piv_tol, info, reinterpret_cast<ElimScratch<T>*>(s_a), tid);
   }
 }
 
-hipError_t launch_chol_panel(double* A, double* Dinv, const double* diag0, double piv_tol, int32_t* info,
-                             int p_pad, int J, int n_mats, int flags, hipStream_t st) {
+hipError_t launch_chol_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
+                             int J, int n_mats, int flags, int f32, hipStream_t st) {
   const int nblk = p_pad / NB;
   if (p_pad % NB != 0 || J < 0 || J >= nblk - 1 || n_mats < 1) return hipErrorInvalidValue;
   const int rows_below = p_pad - (J + 1) * NB;
   dim3 grid(n_mats, (rows_below + 127) / 128);
-  hipLaunchKernelGGL(chol_panel_kernel, grid, dim3(256), 0, st, A, Dinv, diag0, piv_tol, info, p_pad, J, nblk,
-                     flags);
+  if (f32)
+    hipLaunchKernelGGL(chol_panel_kernel<float>, grid, dim3(256), 0, st, (float*)A, (float*)Dinv, diag0, piv_tol,
+                       info, p_pad, J, nblk, flags);
+  else
+    hipLaunchKernelGGL(chol_panel_kernel<double>, grid, dim3(256), 0, st, (double*)A, (double*)Dinv, diag0,
+                       piv_tol, info, p_pad, J, nblk, flags);
   return hipGetLastError();
 }
 
@@ -425,13 +453,17 @@ hipError_t launch_chol_panel(double* A, double* Dinv, const double* diag0, doubl
 // 64-row blocks top to bottom:  V[I] = L_II^-1 ( RHS[I] - sum_{K<I} L[I,K] V[K] ).
 //   tri  : RHS = L_t (Cholesky factor of the permuted test Gram), lower triangular, so a
 //          strip starts at its own diagonal block.
-//   rect : RHS = rows perm[i] of Ft (p x m), a plain row gather.
+//   rect : RHS = rows perm[i] of Ft (p x m, fp64), a plain row gather.
 // Strips are independent: no inter-workgroup traffic.
 // =====================================================================================
+template <typename T>
 __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
-  __shared__ __attribute__((aligned(16))) double s_rk[64 * RK_LD];
-  __shared__ __attribute__((aligned(16))) double s_kc[16 * KC_LD];
-  __shared__ __attribute__((aligned(16))) double s_dinv[64 * DI_LD];
+  typedef typename Tr<T>::acc_t acc_t;
+  typedef typename Tr<T>::vec_t vec_t;
+  constexpr int VE = Tr<T>::VE;
+  __shared__ __attribute__((aligned(16))) T s_rk[64 * RK_LD];
+  __shared__ __attribute__((aligned(16))) T s_kc[16 * KC_LD];
+  __shared__ __attribute__((aligned(16))) T s_dinv[64 * DI_LD];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -444,52 +476,54 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
   const int n_iblk = (p + NB - 1) / NB;
   const int64_t ldv = ldv_of(m_pad);
   const int64_t chunk = (int64_t)p_pad * 16;
-  const double* L = a.A + (int64_t)ord * p_pad * p_pad;   // chunk-major
-  const double* Lt = a.tri ? a.rhs + (int64_t)ord * p_pad * p_pad : nullptr;
+  const T* L = static_cast<const T*>(a.A) + (int64_t)ord * p_pad * p_pad;   // chunk-major
+  const T* Lt = a.tri ? static_cast<const T*>(a.rhs) + (int64_t)ord * p_pad * p_pad : nullptr;
   const int32_t* perm = a.tri ? nullptr : a.perms + (int64_t)ord * p;
-  double* V = a.V + (int64_t)ord * v_rows_of(p) * ldv;
+  T* V = static_cast<T*>(a.V) + (int64_t)ord * v_rows_of(p) * ldv;
+  const T* Dv = static_cast<const T*>(a.Dinv) + (int64_t)ord * nblk * 4096;
 
   const int ib0 = a.tri ? c0 / NB : 0;
   const int kstart = a.tri ? c0 : 0;
   if (a.tri) {
     // rows above the strip's first diagonal block are structurally zero; later kernels read them
-    for (int idx = tid; idx < ib0 * NB * 64; idx += 256) {
-      const int row = idx >> 6, c2 = idx & 63;
-      *reinterpret_cast<v2d*>(V + row * ldv + c0 + 2 * c2) = v2d{0.0, 0.0};
+    constexpr int VPR = 128 / VE;
+    for (int idx = tid; idx < ib0 * NB * VPR; idx += 256) {
+      const int row = idx / VPR, cv = idx % VPR;
+      *reinterpret_cast<vec_t*>(V + row * ldv + c0 + VE * cv) = Tr<T>::vzero();
     }
   }
 
   for (int ib = ib0; ib < n_iblk; ++ib) {
     const int I0 = ib * NB;
-    d4 acc[4][2];
+    acc_t acc[4][2];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
-      for (int y = 0; y < 2; ++y) acc[x][y] = d4_zero();
+      for (int y = 0; y < 2; ++y) acc[x][y] = Tr<T>::zero();
 
-    const double* srcL = L + cm_off(p_pad, I0, kstart);
-    const double* srcV = V + kstart * ldv + c0;
+    const T* srcL = L + cm_off(p_pad, I0, kstart);
+    const T* srcV = V + kstart * ldv + c0;
     const int nch = (I0 - kstart) / KCH;
-    RKRegs<64> rl = {};
-    KCRegs rv = {};
+    RKRegs<T, 64> rl = {};
+    KCRegs<T> rv = {};
     if (nch > 0) {
-      rk_load<64>(rl, srcL, CM_LD, tid, 64);
-      kc_load(rv, srcV, ldv, tid);
+      rk_load<T, 64>(rl, srcL, CM_LD, tid, 64);
+      kc_load<T>(rv, srcV, ldv, tid);
     }
     for (int c = 0; c < nch; ++c) {
       __syncthreads();
-      rk_store<64>(rl, s_rk, tid);
-      kc_store(rv, s_kc, tid);
+      rk_store<T, 64>(rl, s_rk, tid);
+      kc_store<T>(rv, s_kc, tid);
       __syncthreads();
       if (c + 1 < nch) {
-        rk_load<64>(rl, srcL + (c + 1) * chunk, CM_LD, tid, 64);
-        kc_load(rv, srcV + (c + 1) * KCH * ldv, ldv, tid);
+        rk_load<T, 64>(rl, srcL + (c + 1) * chunk, CM_LD, tid, 64);
+        kc_load<T>(rv, srcV + (c + 1) * KCH * ldv, ldv, tid);
       }
       // tri: V[k][c] = 0 for c > k, so columns c0+64.. (waves 2, 3) see only zeros while k < c0+64
       if (a.tri && w >= 2 && c < 4 && !(a.flags & 1)) continue;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        double av[4], bv[2];
+        T av[4], bv[2];
 #pragma unroll
         for (int x = 0; x < 4; ++x) av[x] = s_rk[(16 * x + l15) * RK_LD + 4 * kk + l4];
 #pragma unroll
@@ -497,57 +531,56 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
 #pragma unroll
         for (int x = 0; x < 4; ++x)
 #pragma unroll
-          for (int y = 0; y < 2; ++y) acc[x][y] = mfma(av[x], bv[y], acc[x][y]);
+          for (int y = 0; y < 2; ++y) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
       }
     }
 
     __syncthreads();  // s_dinv is still being read by slower waves of the previous block
-    load_block64(s_dinv, a.Dinv + ((int64_t)ord * nblk + ib) * 4096, tid);
+    load_block64<T>(s_dinv, Dv + (int64_t)ib * 4096, tid);
 
-    // C = RHS[I] - acc  (direct global reads: 16 lanes cover one 128-B row segment)
+    // C = RHS[I] - acc  (direct global reads: 16 lanes cover one contiguous row segment)
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = I0 + 16 * x + acc_row(l4, r);
+        const int i = I0 + 16 * x + Tr<T>::acc_row(l4, r);
 #pragma unroll
         for (int y = 0; y < 2; ++y) {
           const int c = c0 + 32 * w + 16 * y + l15;
-          double rv0 = 0.0;
+          T rv0 = (T)0;
           if (a.tri) {
             if (c < I0 + NB) rv0 = Lt[cm_off(p_pad, i, c)];
           } else {
-            if (i < p) rv0 = a.rhs[(int64_t)perm[i] * m_pad + c];
+            if (i < p) rv0 = (T)a.Ft[(int64_t)perm[i] * m_pad + c];
           }
           acc[x][y][r] = rv0 - acc[x][y][r];
         }
       }
     __syncthreads();
 
-    d4 outv[4][2];
+    acc_t outv[4][2];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
-      for (int y = 0; y < 2; ++y) outv[x][y] = d4_zero();
+      for (int y = 0; y < 2; ++y) outv[x][y] = Tr<T>::zero();
 #pragma unroll
     for (int xp = 0; xp < 4; ++xp)
 #pragma unroll
       for (int x = 0; x <= xp; ++x)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const double av = s_dinv[(16 * xp + l15) * DI_LD + 16 * x + acc_row(l4, r)];
+          const T av = s_dinv[(16 * xp + l15) * DI_LD + 16 * x + Tr<T>::acc_row(l4, r)];
 #pragma unroll
-          for (int y = 0; y < 2; ++y) outv[xp][y] = mfma(av, acc[x][y][r], outv[xp][y]);
+          for (int y = 0; y < 2; ++y) outv[xp][y] = Tr<T>::mfma(av, acc[x][y][r], outv[xp][y]);
         }
 
 #pragma unroll
     for (int xp = 0; xp < 4; ++xp)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = I0 + 16 * xp + acc_row(l4, r);
+        const int i = I0 + 16 * xp + Tr<T>::acc_row(l4, r);
 #pragma unroll
-        for (int y = 0; y < 2; ++y)
-          V[i * ldv + c0 + 32 * w + 16 * y + l15] = outv[xp][y][r];
+        for (int y = 0; y < 2; ++y) V[i * ldv + c0 + 32 * w + 16 * y + l15] = outv[xp][y][r];
       }
     // the next block's k-loop reads these rows back (written by other waves of this workgroup)
     __threadfence_block();
@@ -558,25 +591,33 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
 hipError_t launch_strip(const StripArgs& a, hipStream_t st) {
   if (a.p < 1 || a.p_pad % NB != 0 || a.m_pad % 128 != 0 || a.n_ord < 1) return hipErrorInvalidValue;
   if (a.tri && a.m_pad > a.p_pad + 127) return hipErrorInvalidValue;
-  if (!a.tri && a.perms == nullptr) return hipErrorInvalidValue;
+  if (a.tri ? (a.rhs == nullptr) : (a.perms == nullptr || a.Ft == nullptr)) return hipErrorInvalidValue;
   dim3 grid(a.n_ord, a.m_pad / 128);
-  hipLaunchKernelGGL(strip_kernel, grid, dim3(256), 0, st, a);
+  if (a.f32)
+    hipLaunchKernelGGL(strip_kernel<float>, grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(strip_kernel<double>, grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
 // =====================================================================================
-// probe: one MFMA, used by the unit test that pins the f64 operand / result lane maps
+// probe: one MFMA through the traits, used by the unit test that pins the operand / result lane
+// maps of v_mfma_f64_16x16x4_f64 and v_mfma_f32_16x16x4_f32
 // =====================================================================================
+template <typename T>
 __global__ void mfma_probe_kernel(const double* A, const double* B, double* D) {
   const int l = threadIdx.x, l15 = l & 15, l4 = l >> 4;
-  d4 acc = d4_zero();
-  acc = mfma(A[l15 * 4 + l4], B[l4 * 16 + l15], acc);
+  typename Tr<T>::acc_t acc = Tr<T>::zero();
+  acc = Tr<T>::mfma((T)A[l15 * 4 + l4], (T)B[l4 * 16 + l15], acc);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) D[acc_row(l4, r) * 16 + l15] = acc[r];
+  for (int r = 0; r < 4; ++r) D[Tr<T>::acc_row(l4, r) * 16 + l15] = (double)acc[r];
 }
 
-hipError_t launch_mfma_probe(const double* A, const double* B, double* D, hipStream_t st) {
-  hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, st, A, B, D);
+hipError_t launch_mfma_probe(const double* A, const double* B, double* D, int f32, hipStream_t st) {
+  if (f32)
+    hipLaunchKernelGGL(mfma_probe_kernel<float>, dim3(1), dim3(64), 0, st, A, B, D);
+  else
+    hipLaunchKernelGGL(mfma_probe_kernel<double>, dim3(1), dim3(64), 0, st, A, B, D);
   return hipGetLastError();
 }
 

@@ -18,6 +18,7 @@ namespace lsspa {
 // One wave per 64-column strip: lane = column, rows walked in order (the running N is a scan
 // down the rows).  Rows are taken 16 at a time: 16 independent coalesced loads, the scan in
 // registers, then the 16 per-row dot products are reduced through a small LDS tile.
+template <typename T>
 __global__ __launch_bounds__(256) void lift_partial_kernel(LiftArgs a) {
   __shared__ double s_E[4][16 * TT_LD];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -29,13 +30,13 @@ __global__ __launch_bounds__(256) void lift_partial_kernel(LiftArgs a) {
   const int p = a.p, p_pad = a.p_pad, m_pad = a.m_pad;
   const int n_iblk = (p + NB - 1) / NB;
   const int64_t ldv = ldv_of(m_pad);
-  const double* L = a.A + (int64_t)ord * p_pad * p_pad;   // chunk-major: row p is L[cm_off(p_pad, p, j)]
-  const double* V = a.V + (int64_t)ord * v_rows_of(p) * ldv;
+  const T* L = static_cast<const T*>(a.A) + (int64_t)ord * p_pad * p_pad;   // chunk-major: row p is L[cm_off(p_pad, p, j)]
+  const T* V = static_cast<const T*>(a.V) + (int64_t)ord * v_rows_of(p) * ldv;
   double* Pp = a.Ppart + ((int64_t)ord * nstrips + strip) * p_pad;
   const int c = cs + lane;
   double yt;
   if (a.tri)
-    yt = (c < p) ? a.At[(int64_t)ord * p_pad * p_pad + cm_off(p_pad, p, c)] : 0.0;
+    yt = (c < p) ? (double)static_cast<const T*>(a.At)[(int64_t)ord * p_pad * p_pad + cm_off(p_pad, p, c)] : 0.0;
   else
     yt = a.ytil[c];
   double* E = s_E[w];
@@ -50,8 +51,8 @@ __global__ __launch_bounds__(256) void lift_partial_kernel(LiftArgs a) {
     }
     double v[16];
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) v[jj] = (j0 + jj < p) ? V[(j0 + jj) * ldv + c] : 0.0;
-    const double zl = (j0 + r16 < p) ? L[cm_off(p_pad, p, j0 + r16)] : 0.0;  // lane r16 holds z[j0 + r16]
+    for (int jj = 0; jj < 16; ++jj) v[jj] = (j0 + jj < p) ? (double)V[(j0 + jj) * ldv + c] : 0.0;
+    const double zl = (j0 + r16 < p) ? (double)L[cm_off(p_pad, p, j0 + r16)] : 0.0;  // lane r16 holds z[j0 + r16]
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
       const double zj = __shfl(zl, jj, 64);
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256) void lift_partial_kernel(LiftArgs a) {
 }
 
 // lifts[sample][perm[j]] = mean over the sample's orderings of z_j * sum_strips P_j / |y|^2
+template <typename T>
 __global__ __launch_bounds__(256) void lift_finish_kernel(LiftArgs a) {
   const int sample = blockIdx.x;
   const int nstrips = a.m_pad / 64;
@@ -81,12 +83,12 @@ __global__ __launch_bounds__(256) void lift_finish_kernel(LiftArgs a) {
   for (int k = 0; k < a.per_sample; ++k) {
     const int ord = sample * a.per_sample + k;
     const int32_t* perm = a.perms + (int64_t)ord * p;
-    const double* Lm = a.A + (int64_t)ord * p_pad * p_pad;
+    const T* Lm = static_cast<const T*>(a.A) + (int64_t)ord * p_pad * p_pad;
     const double* Pp = a.Ppart + (int64_t)ord * nstrips * p_pad;
     for (int j = threadIdx.x; j < p; j += 256) {
       double s = 0.0;
       for (int t = 0; t < nstrips; ++t) s += Pp[(int64_t)t * p_pad + j];
-      const double val = Lm[cm_off(p_pad, p, j)] * s * wgt;
+      const double val = (double)Lm[cm_off(p_pad, p, j)] * s * wgt;
       const int f = perm[j];
       if (k == 0)
         out[f] = val;
@@ -101,10 +103,17 @@ hipError_t launch_lift(const LiftArgs& a, hipStream_t st) {
   if (a.p < 1 || a.p_pad % NB != 0 || a.m_pad % 128 != 0 || a.n_ord < 1 ||
       (a.per_sample != 1 && a.per_sample != 2) || a.n_ord % a.per_sample != 0 || !(a.y_norm_sq > 0.0))
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL(lift_partial_kernel, dim3(a.n_ord, (a.m_pad / 64 + 3) / 4), dim3(256), 0, st, a);
+  const dim3 g1(a.n_ord, (a.m_pad / 64 + 3) / 4), g2(a.n_ord / a.per_sample);
+  if (a.f32)
+    hipLaunchKernelGGL(lift_partial_kernel<float>, g1, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(lift_partial_kernel<double>, g1, dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(lift_finish_kernel, dim3(a.n_ord / a.per_sample), dim3(256), 0, st, a);
+  if (a.f32)
+    hipLaunchKernelGGL(lift_finish_kernel<float>, g2, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(lift_finish_kernel<double>, g2, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -236,32 +245,37 @@ hipError_t launch_stats_merge(const double* buf, double* state_n, double* mean, 
 //   for j = p-1 .. 0 :  theta_j = w_j / L[j][j] ;  w[0:j] -= theta_j * L[j][0:j]
 // One workgroup; one-off cost per problem.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void backsolve_kernel(const double* __restrict__ L,
-                                                         double* __restrict__ theta, int p, int p_pad) {
+template <typename T>
+__global__ __launch_bounds__(1024) void backsolve_kernel(const T* __restrict__ L, double* __restrict__ theta,
+                                                         int p, int p_pad) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* wv = reinterpret_cast<double*>(smem_raw);
   __shared__ double s_t;
   const int tid = threadIdx.x;
-  for (int i = tid; i < p; i += 1024) wv[i] = L[cm_off(p_pad, p, i)];
+  for (int i = tid; i < p; i += 1024) wv[i] = (double)L[cm_off(p_pad, p, i)];
   __syncthreads();
   for (int j = p - 1; j >= 0; --j) {
     if (tid == 0) {
-      const double t = wv[j] / L[cm_off(p_pad, j, j)];
+      const double t = wv[j] / (double)L[cm_off(p_pad, j, j)];
       s_t = t;
       theta[j] = t;
     }
     __syncthreads();
     const double t = s_t;
-    for (int i = tid; i < j; i += 1024) wv[i] -= t * L[cm_off(p_pad, j, i)];
+    for (int i = tid; i < j; i += 1024) wv[i] -= t * (double)L[cm_off(p_pad, j, i)];
     __syncthreads();
   }
 }
 
-hipError_t launch_backsolve(const double* A, double* theta, int p, int p_pad, hipStream_t st) {
+hipError_t launch_backsolve(const void* A, double* theta, int p, int p_pad, int f32, hipStream_t st) {
   if (p < 1 || p_pad <= p) return hipErrorInvalidValue;
   const size_t shmem = sizeof(double) * p;
   if (shmem > 60 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(backsolve_kernel, dim3(1), dim3(1024), shmem, st, A, theta, p, p_pad);
+  if (f32)
+    hipLaunchKernelGGL(backsolve_kernel<float>, dim3(1), dim3(1024), shmem, st, (const float*)A, theta, p, p_pad);
+  else
+    hipLaunchKernelGGL(backsolve_kernel<double>, dim3(1), dim3(1024), shmem, st, (const double*)A, theta, p,
+                       p_pad);
   return hipGetLastError();
 }
 

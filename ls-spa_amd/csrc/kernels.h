@@ -1,5 +1,10 @@
 // Host-side launchers of the LS-SPA HIP kernels.  Every launcher checks its shape
 // assumptions before launching (a faulting kernel can take the whole node down).
+//
+// The per-ordering kernels exist in two element types: fp64 (default; parity with the reference
+// to ~1e-15) and fp32 (work matrices, factors and V in float; Gram reduction, lift accumulation and
+// running statistics stay fp64).  `f32 != 0` selects the fp32 instantiation; the `void*` work
+// buffers then hold floats.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -7,46 +12,51 @@
 namespace lsspa {
 
 struct GatherArgs {
-  const double* S[2];      // source Gram matrices (train, test), row-major, stride ld_src
+  const double* S[2];      // source Gram matrices (train, test), fp64, row-major, stride ld_src
   const double* s[2];      // source right-hand sides (g, h)
   double aug[2];           // diagonal value of the augmented row
   int64_t ld_src;
   const int32_t* perms;    // [n_ord][p]
   int p, p_pad, n_ord, n_src;  // n_src = 1 (train only) or 2
-  double* A;               // [n_src * n_ord][p_pad][p_pad], lower triangles written
+  void* A;                 // [n_src * n_ord] chunk-major p_pad x p_pad matrices, lower triangles written
   double* diag0;           // [n_src * n_ord][p_pad]: the permuted diagonals before any update (pivot scale)
+  int f32;
 };
 hipError_t launch_gather(const GatherArgs& a, hipStream_t st);
 
-// one left-looking block step J of the batched Cholesky factorisation
-// diag0 / piv_tol: a pivot d counts as non-positive (LSSPA_INFO_NOT_PD) when d <= piv_tol * diag0
-hipError_t launch_chol_diag(double* A, double* Dinv, const double* diag0, double piv_tol, int32_t* info,
-                            int p_pad, int J, int n_mats, hipStream_t st);
-// panel step J; unless flags & 2, its tile-0 workgroups also factor diagonal block J + 1
-hipError_t launch_chol_panel(double* A, double* Dinv, const double* diag0, double piv_tol, int32_t* info,
-                             int p_pad, int J, int n_mats, int flags, hipStream_t st);
+// Blocked Cholesky.  diag0 / piv_tol: a pivot d counts as non-positive (LSSPA_INFO_NOT_PD) when
+// d <= piv_tol * diag0.  chol_diag factors diagonal block J stand-alone (only block 0 needs it);
+// panel step J computes L[I,J] for the tiles below and, unless flags & 2, its tile-0 workgroups
+// also factor diagonal block J + 1.
+hipError_t launch_chol_diag(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
+                            int J, int n_mats, int f32, hipStream_t st);
+hipError_t launch_chol_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
+                             int J, int n_mats, int flags, int f32, hipStream_t st);
 
 struct StripArgs {
-  const double* A;         // factored train matrices, [n_ord][p_pad][p_pad]
-  const double* Dinv;      // [n_mats][nblk][64][64]; the first n_ord entries belong to A
-  const double* rhs;       // tri: factored test matrices (same layout as A); rect: Ft [p][m_pad]
+  const void* A;           // factored train matrices
+  const void* Dinv;        // [n_mats][nblk][64][64]; the first n_ord entries belong to A
+  const void* rhs;         // tri: factored test matrices (same layout as A); rect: unused
+  const double* Ft;        // rect: transposed test factor [p][m_pad], fp64
   const int32_t* perms;    // rect only
-  double* V;               // [n_ord][n_iblk*64][m_pad]
+  void* V;                 // [n_ord][v_rows][m_pad + 32]
   int p, p_pad, m_pad, n_ord, tri;
   int flags;               // developer A/B switches
+  int f32;
 };
 hipError_t launch_strip(const StripArgs& a, hipStream_t st);
 
 struct LiftArgs {
-  const double* A;         // factored train matrices (row p holds z)
-  const double* At;        // tri: factored test matrices (row p holds y-tilde); rect: null
+  const void* A;           // factored train matrices (row p holds z)
+  const void* At;          // tri: factored test matrices (row p holds y-tilde); rect: null
   const double* ytil;      // rect: [m_pad]
-  const double* V;
+  const void* V;
   const int32_t* perms;    // [n_ord][p]
   double* Ppart;           // [n_ord][m_pad/64][p_pad]
   double* lifts;           // [n_samples][p]
   double y_norm_sq;
   int p, p_pad, m_pad, n_ord, per_sample, tri;  // per_sample = 1 or 2 orderings per sample
+  int f32;
 };
 hipError_t launch_lift(const LiftArgs& a, hipStream_t st);
 
@@ -57,8 +67,8 @@ hipError_t launch_stats_batch(const double* lifts, const double* mean, double* b
 hipError_t launch_stats_merge(const double* buf, double* state_n, double* mean, double* M2, int p,
                               hipStream_t st);
 
-// theta = L^-T z for the factor stored in A (identity ordering), single workgroup
-hipError_t launch_backsolve(const double* A, double* theta, int p, int p_pad, hipStream_t st);
+// theta = L^-T z for the factor stored in A (identity ordering), single workgroup; theta is fp64
+hipError_t launch_backsolve(const void* A, double* theta, int p, int p_pad, int f32, hipStream_t st);
 
 // Gram contraction  C = Z^T Z, Z = [X | y]  (rows n, P1 = p + 1 columns), fp64 MFMA, split over rows
 struct GramArgs {
@@ -79,7 +89,7 @@ hipError_t launch_gram(const GramArgs& a, hipStream_t st);
 hipError_t launch_gram_finalize(const double* C, int p, double scale, double reg, double* G, int64_t ldg,
                                 double* g, double* scalar_out, hipStream_t st);
 
-// debugging / unit tests: D = A(16x4) * B(4x16) on one wave
-hipError_t launch_mfma_probe(const double* A, const double* B, double* D, hipStream_t st);
+// unit test hook: D = A(16x4) * B(4x16) on one wave through Tr<T>::mfma / acc_row (fp64 or fp32)
+hipError_t launch_mfma_probe(const double* A, const double* B, double* D, int f32, hipStream_t st);
 
 }  // namespace lsspa

@@ -50,7 +50,10 @@ struct lsspa_ctx {
   // per-batch workspace
   int cap_ord = 0;      // orderings the workspace can hold
   int cap_samples = 0;  // samples the lifts buffer can hold
-  DevBuf<double> A, V, Dinv, Ppart, lifts, diag0;
+  int f32 = 0;          // element type of the per-ordering work matrices (0: double, 1: float)
+  DevBuf<char> A, V, Dinv;   // raw bytes: esz() per element
+  DevBuf<double> Ppart, lifts, diag0;
+  size_t esz() const { return f32 ? 4 : 8; }
   DevBuf<int32_t> perms_d, info_d;
   // pinned staging of the orderings: two buffers in turn, each guarded by the event of its last
   // H2D copy, so the host can prepare batch k+1 while the GPU still runs batch k (no stream sync)
@@ -230,8 +233,9 @@ size_t bytes_per_ordering(const lsspa_ctx* ctx) {
   const size_t pp = ctx->p_pad, nblk = pp / NB, n_iblk = (ctx->p + NB - 1) / NB;
   const size_t nm = ctx->tri ? 2 : 1;
   (void)n_iblk;
-  return nm * pp * pp * 8 + (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad) * 8 +
-         nm * nblk * 4096 * 8 + nm * pp * 8 +
+  const size_t es = ctx->esz();
+  return nm * pp * pp * es + (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad) * es +
+         nm * nblk * 4096 * es + nm * pp * 8 +
          (size_t)(ctx->m_pad / 64) * pp * 8 + (size_t)ctx->p * 4;
 }
 
@@ -258,10 +262,11 @@ int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
       dev_free(ctx->perms_d);
       const size_t pp = ctx->p_pad, nblk = pp / NB, n_iblk = (ctx->p + NB - 1) / NB;
       const size_t nm = ctx->tri ? 2 : 1;
-      TRY(dev_alloc(ctx, ctx->A, nm * cap * pp * pp));
+      const size_t es = ctx->esz();
+      TRY(dev_alloc(ctx, ctx->A, nm * cap * pp * pp * es));
       (void)n_iblk;
-      TRY(dev_alloc(ctx, ctx->V, (size_t)cap * (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad)));
-      TRY(dev_alloc(ctx, ctx->Dinv, nm * cap * nblk * 4096));
+      TRY(dev_alloc(ctx, ctx->V, (size_t)cap * (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad) * es));
+      TRY(dev_alloc(ctx, ctx->Dinv, nm * cap * nblk * 4096 * es));
       TRY(dev_alloc(ctx, ctx->diag0, nm * cap * pp));
       TRY(dev_alloc(ctx, ctx->Ppart, (size_t)cap * (ctx->m_pad / 64) * pp));
       TRY(dev_alloc(ctx, ctx->perms_d, (size_t)cap * ctx->p));
@@ -314,21 +319,22 @@ int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
     ga.n_src = n_src;
     ga.A = ctx->A.ptr;
     ga.diag0 = ctx->diag0.ptr;
+    ga.f32 = ctx->f32;
     HIPCHK(launch_gather(ga, ctx->stream));
   }
   const bool fused = !(ctx->flags & 2);  // panel step J also factors diagonal block J + 1
   // a pivot below ~p ulps of its feature's own variance is numerically zero (collinear feature)
-  const double piv_tol = 16.0 * (double)p * 2.220446049250313e-16;
+  const double piv_tol = 16.0 * (double)p * (ctx->f32 ? 1.1920929e-07 : 2.220446049250313e-16);
   for (int J = 0; J < nblk; ++J) {
     if (J == 0 || !fused) {
       ProfScope ps(ctx, LSSPA_K_CHOL_DIAG);
       HIPCHK(launch_chol_diag(ctx->A.ptr, ctx->Dinv.ptr, ctx->diag0.ptr, piv_tol, ctx->info_d.ptr, p_pad, J,
-                              n_mats, ctx->stream));
+                              n_mats, ctx->f32, ctx->stream));
     }
     if (J + 1 < nblk) {
       ProfScope ps(ctx, LSSPA_K_CHOL_PANEL);
       HIPCHK(launch_chol_panel(ctx->A.ptr, ctx->Dinv.ptr, ctx->diag0.ptr, piv_tol, ctx->info_d.ptr, p_pad, J,
-                               n_mats, ctx->flags, ctx->stream));
+                               n_mats, ctx->flags, ctx->f32, ctx->stream));
     }
   }
   {
@@ -336,7 +342,9 @@ int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
     StripArgs sa;
     sa.A = ctx->A.ptr;
     sa.Dinv = ctx->Dinv.ptr;
-    sa.rhs = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * p_pad : ctx->Ft.ptr;
+    sa.rhs = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * p_pad * ctx->esz() : nullptr;
+    sa.Ft = ctx->tri ? nullptr : ctx->Ft.ptr;
+    sa.f32 = ctx->f32;
     sa.perms = ctx->perms_d.ptr;
     sa.V = ctx->V.ptr;
     sa.p = p;
@@ -351,7 +359,8 @@ int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
     ProfScope ps(ctx, LSSPA_K_LIFT);
     LiftArgs la;
     la.A = ctx->A.ptr;
-    la.At = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * p_pad : nullptr;
+    la.At = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * p_pad * ctx->esz() : nullptr;
+    la.f32 = ctx->f32;
     la.ytil = ctx->tri ? nullptr : ctx->ytil.ptr;
     la.V = ctx->V.ptr;
     la.perms = ctx->perms_d.ptr;
@@ -769,6 +778,18 @@ int lsspa_get_gram(lsspa_ctx* ctx, double* G, double* g, double* H, double* h) {
   return LSSPA_OK;
 }
 
+// device -> host copy of `count` work-matrix elements starting at element offset `off`, as doubles
+static int fetch_elems(lsspa_ctx* ctx, const char* base, size_t off, size_t count, double* dst) {
+  if (!ctx->f32) {
+    HIPCHK(hipMemcpy(dst, base + off * 8, count * 8, hipMemcpyDeviceToHost));
+    return LSSPA_OK;
+  }
+  std::vector<float> tmp(count);
+  HIPCHK(hipMemcpy(tmp.data(), base + off * 4, count * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < count; ++i) dst[i] = (double)tmp[i];
+  return LSSPA_OK;
+}
+
 // factor the identity ordering into workspace slot 0 (lifts into lifts_d row 0)
 static int factor_identity(lsspa_ctx* ctx, const int32_t* perm_or_null) {
   const int p = ctx->p;
@@ -797,7 +818,7 @@ int lsspa_full_fit(lsspa_ctx* ctx, double* theta, double* r_squared, int32_t* in
   if (theta) {
     DevBuf<double> th;
     TRY(dev_alloc(ctx, th, (size_t)p));
-    hipError_t e = launch_backsolve(ctx->A.ptr, th.ptr, p, ctx->p_pad, ctx->stream);
+    hipError_t e = launch_backsolve(ctx->A.ptr, th.ptr, p, ctx->p_pad, ctx->f32, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(theta, th.ptr, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     dev_free(th);
@@ -821,7 +842,7 @@ int lsspa_get_factors(lsspa_ctx* ctx, double* R_tr, double* q_tr, double* F_te, 
   const size_t mat = (size_t)ppad * ppad;       // chunk-major factor matrices (tiles.h: cm_off)
   TRY(factor_identity(ctx, nullptr));
   std::vector<double> L(mat);
-  HIPCHK(hipMemcpy(L.data(), ctx->A.ptr, L.size() * 8, hipMemcpyDeviceToHost));
+  TRY(fetch_elems(ctx, ctx->A.ptr, 0, mat, L.data()));
   if (R_tr)
     for (int a = 0; a < p; ++a)
       for (int b = 0; b < p; ++b) R_tr[(size_t)a * p + b] = (b >= a) ? L[cm_off(ppad, b, a)] : 0.0;
@@ -830,7 +851,7 @@ int lsspa_get_factors(lsspa_ctx* ctx, double* R_tr, double* q_tr, double* F_te, 
   if (ctx->tri) {
     if (F_te || q_te) {
       // slot layout of run_orderings: the test matrices follow the n_ord = 1 train matrices
-      HIPCHK(hipMemcpy(L.data(), ctx->A.ptr + mat, L.size() * 8, hipMemcpyDeviceToHost));
+      TRY(fetch_elems(ctx, ctx->A.ptr, mat, mat, L.data()));
       if (F_te)
         for (int a = 0; a < p; ++a)
           for (int b = 0; b < p; ++b) F_te[(size_t)a * p + b] = (b >= a) ? L[cm_off(ppad, b, a)] : 0.0;
@@ -983,14 +1004,26 @@ int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags) {
   return LSSPA_OK;
 }
 
-int lsspa_mfma_probe(lsspa_ctx* ctx, const double* A16x4, const double* B4x16, double* D16x16) {
+int lsspa_set_precision(lsspa_ctx* ctx, int32_t dtype) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (dtype != LSSPA_F64 && dtype != LSSPA_F32) return ctx->fail(LSSPA_ERR_ARG, "dtype");
+  HIPCHK(hipSetDevice(ctx->device));
+  if ((dtype == LSSPA_F32) != (ctx->f32 != 0)) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->f32 = dtype == LSSPA_F32;
+    ctx->cap_ord = 0;   // the workspace is re-created for the new element size on demand
+  }
+  return LSSPA_OK;
+}
+
+int lsspa_mfma_probe(lsspa_ctx* ctx, const double* A16x4, const double* B4x16, double* D16x16, int32_t dtype) {
   if (!ctx || !A16x4 || !B4x16 || !D16x16) return LSSPA_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   DevBuf<double> buf;
   TRY(dev_alloc(ctx, buf, 64 + 64 + 256));
   hipError_t e = hipMemcpy(buf.ptr, A16x4, 64 * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(buf.ptr + 64, B4x16, 64 * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = launch_mfma_probe(buf.ptr, buf.ptr + 64, buf.ptr + 128, ctx->stream);
+  if (e == hipSuccess) e = launch_mfma_probe(buf.ptr, buf.ptr + 64, buf.ptr + 128, dtype == LSSPA_F32, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e == hipSuccess) e = hipMemcpy(D16x16, buf.ptr + 128, 256 * 8, hipMemcpyDeviceToHost);
   dev_free(buf);
@@ -1013,16 +1046,22 @@ int lsspa_debug_factor(lsspa_ctx* ctx, const int32_t* perm, double* L, double* L
   TRY(factor_identity(ctx, perm));
   const size_t ldv = (size_t)ldv_of(ctx->m_pad), mp = ctx->m_pad;
   // the device matrices are chunk-major; hand them out dense row-major
-  auto unpack = [&](const double* dev, double* dst) -> int {
+  auto unpack = [&](size_t mat_index, double* dst) -> int {
     std::vector<double> tmp(pp * pp);
-    HIPCHK(hipMemcpy(tmp.data(), dev, pp * pp * 8, hipMemcpyDeviceToHost));
+    TRY(fetch_elems(ctx, ctx->A.ptr, mat_index * pp * pp, pp * pp, tmp.data()));
     for (size_t r = 0; r < pp; ++r)
       for (size_t c = 0; c < pp; ++c) dst[r * pp + c] = tmp[cm_off((int)pp, (int)r, (int)c)];
     return LSSPA_OK;
   };
-  if (L) TRY(unpack(ctx->A.ptr, L));
-  if (Lt && ctx->tri) TRY(unpack(ctx->A.ptr + pp * pp, Lt));
-  if (V) HIPCHK(hipMemcpy2D(V, mp * 8, ctx->V.ptr, ldv * 8, mp * 8, n_iblk * NB, hipMemcpyDeviceToHost));
+  if (L) TRY(unpack(0, L));
+  if (Lt && ctx->tri) TRY(unpack(1, Lt));
+  if (V) {
+    const size_t rows = n_iblk * NB;
+    std::vector<double> tmp(rows * ldv);
+    TRY(fetch_elems(ctx, ctx->V.ptr, 0, rows * ldv, tmp.data()));
+    for (size_t r = 0; r < rows; ++r)
+      for (size_t c = 0; c < mp; ++c) V[r * mp + c] = tmp[r * ldv + c];
+  }
   return LSSPA_OK;
 }
 

@@ -1,17 +1,19 @@
 // Tile-level building blocks shared by the LS-SPA kernels (gfx950 / CDNA4 only).
 //
-// All dense inner products run on the fp64 matrix pipe, v_mfma_f64_16x16x4_f64:
-// one wave computes a 16x16 tile of D = A*B + C with K = 4 per instruction.
-//   A operand : one double per lane, lane l holds A[i = l & 15][k = l >> 4]
-//   B operand : one double per lane, lane l holds B[k = l >> 4][j = l & 15]
-//   C/D       : four doubles per lane, register r of lane l holds
-//               D[row = (l >> 4) + 4 r][col = l & 15]
-// (cdna_hip_programming.md section 3, "f64 MFMA does NOT use these maps").
+// All dense inner products run on the matrix pipe, one wave per 16x16 tile with K = 4 per
+// instruction: v_mfma_f64_16x16x4_f64 (fp64 path) or v_mfma_f32_16x16x4_f32 (fp32 path).
+//   A operand : one element per lane, lane l holds A[i = l & 15][k = l >> 4]
+//   B operand : one element per lane, lane l holds B[k = l >> 4][j = l & 15]
+//   C/D       : four elements per lane, register r of lane l holds
+//                 f64:  D[row = (l >> 4) + 4 r][col = l & 15]
+//                 f32:  D[row = 4 (l >> 4) + r][col = l & 15]
+// (cdna_hip_programming.md section 3; the f64 map differs from every other dtype).  Both maps are
+// wrapped in Tr<T>::acc_row, and every use below goes through it.
 //
-// Consequence used throughout: register r of an accumulator tile is, as it stands,
-// the B operand of k-step r of a following product that sums over the tile's ROW
-// index (k = 4 r + (l >> 4)).  The triangular solves "X = Dinv * C" therefore take
-// C straight from the accumulators, with no LDS round trip.
+// Consequence used throughout: register r of an accumulator tile is, as it stands, the B operand
+// of one k-step of a following product that sums over the tile's ROW index -- the step whose k
+// values are acc_row(l >> 4, r).  The triangular solves "X = Dinv * C" therefore take C straight
+// from the accumulators, with no LDS round trip; the A operand is read at the matching k.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,114 +21,172 @@
 namespace lsspa {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));  // 16-byte staging unit
+typedef double v2d __attribute__((ext_vector_type(2)));  // 16-byte staging unit, fp64
+typedef float f4 __attribute__((ext_vector_type(4)));    // 16-byte staging unit / accumulator, fp32
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int NB = 64;        // factorisation block (diagonal blocks are NB x NB)
 constexpr int KCH = 16;       // k-chunk staged per main-loop iteration
-constexpr int RK_LD = 18;     // LDS row stride (doubles) of a [rows][16 k] tile: 144 B, 16-B aligned,
-                              // conflict-free for the (row = l&15, k = l>>4) fragment read
-constexpr int KC_LD = 144;    // LDS row stride (doubles) of a [16 k][128 cols] tile: +16 doubles puts
-                              // the two k rows of a 32-lane group on disjoint bank halves
-constexpr int DI_LD = 66;     // LDS row stride of a 64 x 64 block read as an A operand
-constexpr int TT_LD = 65;     // LDS row stride of the in-LDS elimination tiles (column walks)
+// LDS row strides, in ELEMENTS, the same numbers for both element sizes:
+constexpr int RK_LD = 18;     // [rows][16 k] tile: conflict-free for the (row = l&15, k = l>>4) fragment
+                              // read (fp64: 144-B rows, 16-B aligned; fp32: 72-B rows, 8-B aligned)
+constexpr int KC_LD = 144;    // [16 k][128 cols] tile: +16 puts the two k rows of a 32-lane group on
+                              // disjoint bank halves
+constexpr int DI_LD = 66;     // 64 x 64 block read as an A operand
+constexpr int TT_LD = 65;     // small reduction tiles walked by column
+
 // Layout of the per-ordering work matrices in HBM: CHUNK-MAJOR.  A p_pad x p_pad matrix is stored as
-// p_pad/16 column chunks of 16 columns; inside a chunk the rows follow each other (128 B per row):
+// p_pad/16 column chunks of 16 columns; inside a chunk the rows follow each other:
 //     element (r, c)  ->  ((c >> 4) * p_pad + r) * 16 + (c & 15)
-// Every operand tile the factorisation kernels stage -- R rows x 16 k -- is then ONE contiguous
-// R * 128-byte block (8-16 KB) instead of R separate 128-byte row segments 8 KB apart, which is what
-// a row-major matrix gives and what held the k-loops at ~3.9 TB/s.
-// The tile loaders below take it as a row-major tile with row stride CM_LD = 16.
+// Every operand tile the factorisation kernels stage -- R rows x 16 k -- is then ONE contiguous block
+// instead of R separate row segments a full row apart.  The tile loaders below take it as a row-major
+// tile with row stride CM_LD = 16.
 constexpr int CM_LD = 16;
 __host__ __device__ inline int64_t cm_off(int p_pad, int r, int c) {
   return ((int64_t)(c >> 4) * p_pad + r) * 16 + (c & 15);
 }
-// V (solve result) stays row-major: its tiles are 16 rows x 1 KB.  32 extra doubles per row keep a
-// tile's rows from landing on the same few memory channels (m_pad is a multiple of 128).
+// V (solve result) stays row-major: its tiles are 16 rows x 128 columns.  32 extra elements per row
+// keep a tile's rows from landing on the same few memory channels (m_pad is a multiple of 128).
 constexpr int LD_PAD = 32;
 __host__ __device__ inline int64_t ldv_of(int m_pad) { return (int64_t)m_pad + LD_PAD; }
-// rows of a V matrix: the ordering's row blocks rounded up to the 128-row strip step
+// rows of a V matrix: the ordering's row blocks rounded up to 128
 __host__ __device__ inline int64_t v_rows_of(int p) { return (int64_t)((p + 127) / 128) * 128; }
-
-__device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
-// row of an accumulator element inside its 16 x 16 tile
-__device__ __forceinline__ int acc_row(int l4, int r) { return l4 + 4 * r; }
 
 // Note on v_mfma_f64_4x4x4_4b_f64: it issues every 16.5 cycles (32 flop/clk/SIMD, 70-76 TFLOP/s in
 // tools/mfma_bench3.hip / mfma_bench4.hip) against ~99 cycles per 2048-flop 16x16x4 instruction
 // (47 TFLOP/s), and a 16x16x4 step can be built from four of them (lane maps probed in
 // tools/mfma_probe4.hip: lane l = 16 q + 4 g + t holds A_g[i=t][k=q], B_g[k=q][j=t], D_g[i=q][j=t];
 // CBSZ/ABID broadcast is ignored for f64).  Panel and strip kernels written that way (git history:
-// "Experimental 4x4x4-MFMA kernel variants") were correct but not faster in situ -- 12 LDS operand
-// reads per 32 MFMAs instead of 6 per 8, lane rotations in the solve stage, lower occupancy -- so
-// the 16x16x4 form is kept for now.
-__device__ __forceinline__ d4 d4_zero() {
-  d4 z = {0.0, 0.0, 0.0, 0.0};
-  return z;
-}
+// "Experimental 4x4x4-MFMA kernel variants") were correct but not faster in situ: the k-loops are
+// bound by their load -> LDS -> barrier pipeline, not by MFMA issue.
 
-// ---- register staging of a [R rows][16 k] tile (R = 64 or 128), 256 threads ----
-template <int R>
+// ---- per-element-type traits ---------------------------------------------------------------------
+template <typename T>
+struct Tr;
+
+template <>
+struct Tr<double> {
+  typedef d4 acc_t;
+  typedef v2d vec_t;
+  static constexpr int VE = 2;  // elements per 16 bytes
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int acc_row(int l4, int r) { return l4 + 4 * r; }
+  static __device__ __forceinline__ acc_t zero() {
+    acc_t z = {0.0, 0.0, 0.0, 0.0};
+    return z;
+  }
+  static __device__ __forceinline__ vec_t vzero() {
+    vec_t z = {0.0, 0.0};
+    return z;
+  }
+  // LDS addresses of staged vectors are 16-byte aligned for fp64 (all strides are even)
+  static __device__ __forceinline__ void lds_store(double* p, vec_t v) { *reinterpret_cast<vec_t*>(p) = v; }
+  static __device__ __forceinline__ vec_t lds_load(const double* p) { return *reinterpret_cast<const vec_t*>(p); }
+};
+
+template <>
+struct Tr<float> {
+  typedef f4 acc_t;
+  typedef f4 vec_t;
+  static constexpr int VE = 4;
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int acc_row(int l4, int r) { return 4 * l4 + r; }
+  static __device__ __forceinline__ acc_t zero() {
+    acc_t z = {0.f, 0.f, 0.f, 0.f};
+    return z;
+  }
+  static __device__ __forceinline__ vec_t vzero() { return zero(); }
+  // fp32 tile rows are 72 B / 264 B apart: staged vectors are only 8-byte aligned in LDS
+  static __device__ __forceinline__ void lds_store(float* p, vec_t v) {
+    f2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    *reinterpret_cast<f2*>(p) = lo;
+    *reinterpret_cast<f2*>(p + 2) = hi;
+  }
+  static __device__ __forceinline__ vec_t lds_load(const float* p) {
+    const f2 lo = *reinterpret_cast<const f2*>(p), hi = *reinterpret_cast<const f2*>(p + 2);
+    vec_t v = {lo[0], lo[1], hi[0], hi[1]};
+    return v;
+  }
+};
+
+// ---- register staging of a [R rows][16 k] tile (R = 64 or 128), 256 threads --------------------
+template <typename T, int R>
 struct RKRegs {
-  v2d v[R / 32];
+  static constexpr int VPR = 16 / Tr<T>::VE;   // 16-byte vectors per row: 8 (fp64) / 4 (fp32)
+  static constexpr int RPP = 256 / VPR;        // rows per pass of the workgroup: 32 / 64
+  static constexpr int NP = R / RPP;           // passes
+  typename Tr<T>::vec_t v[NP];
 };
 
-template <int R>
-__device__ __forceinline__ void rk_load(RKRegs<R>& r, const double* __restrict__ src, int64_t ld,
-                                        int tid, int rows_valid) {
-  const int c = tid & 7, row = tid >> 3;
+template <typename T, int R>
+__device__ __forceinline__ void rk_load(RKRegs<T, R>& r, const T* __restrict__ src, int64_t ld, int tid,
+                                        int rows_valid) {
+  typedef RKRegs<T, R> RR;
+  const int c = tid % RR::VPR, row = tid / RR::VPR;
 #pragma unroll
-  for (int q = 0; q < R / 32; ++q) {
-    const int rr = row + 32 * q;
+  for (int q = 0; q < RR::NP; ++q) {
+    const int rr = row + RR::RPP * q;
     if (rr < rows_valid)
-      r.v[q] = *reinterpret_cast<const v2d*>(src + (int64_t)rr * ld + 2 * c);
+      r.v[q] = *reinterpret_cast<const typename Tr<T>::vec_t*>(src + (int64_t)rr * ld + Tr<T>::VE * c);
     else
-      r.v[q] = v2d{0.0, 0.0};
+      r.v[q] = Tr<T>::vzero();
   }
 }
 
-template <int R>
-__device__ __forceinline__ void rk_store(const RKRegs<R>& r, double* lds, int tid) {
-  const int c = tid & 7, row = tid >> 3;
+template <typename T, int R>
+__device__ __forceinline__ void rk_store(const RKRegs<T, R>& r, T* lds, int tid) {
+  typedef RKRegs<T, R> RR;
+  const int c = tid % RR::VPR, row = tid / RR::VPR;
 #pragma unroll
-  for (int q = 0; q < R / 32; ++q)
-    *reinterpret_cast<v2d*>(lds + (row + 32 * q) * RK_LD + 2 * c) = r.v[q];
+  for (int q = 0; q < RR::NP; ++q) Tr<T>::lds_store(lds + (row + RR::RPP * q) * RK_LD + Tr<T>::VE * c, r.v[q]);
 }
 
-// ---- register staging of a [16 k][128 cols] tile, 256 threads ----
+// ---- register staging of a [16 k][128 cols] tile, 256 threads -----------------------------------
+template <typename T>
 struct KCRegs {
-  v2d v0, v1, v2, v3;
+  static constexpr int VPR = 128 / Tr<T>::VE;  // vectors per k row: 64 / 32
+  static constexpr int RPP = 256 / VPR;        // k rows per pass: 4 / 8
+  static constexpr int NP = 16 / RPP;          // passes: 4 / 2
+  typename Tr<T>::vec_t v[NP];
 };
 
-__device__ __forceinline__ void kc_load(KCRegs& r, const double* __restrict__ src, int64_t ld, int tid) {
-  const int c = tid & 63, k = tid >> 6;
-  const double* s = src + (int64_t)k * ld + 2 * c;
-  r.v0 = *reinterpret_cast<const v2d*>(s);
-  r.v1 = *reinterpret_cast<const v2d*>(s + 4 * ld);
-  r.v2 = *reinterpret_cast<const v2d*>(s + 8 * ld);
-  r.v3 = *reinterpret_cast<const v2d*>(s + 12 * ld);
-}
-
-__device__ __forceinline__ void kc_store(const KCRegs& r, double* lds, int tid) {
-  const int c = tid & 63, k = tid >> 6;
-  double* d = lds + k * KC_LD + 2 * c;
-  *reinterpret_cast<v2d*>(d) = r.v0;
-  *reinterpret_cast<v2d*>(d + 4 * KC_LD) = r.v1;
-  *reinterpret_cast<v2d*>(d + 8 * KC_LD) = r.v2;
-  *reinterpret_cast<v2d*>(d + 12 * KC_LD) = r.v3;
-}
-
-// copy a dense 64 x 64 block (row-major, ld 64) from global into LDS with stride DI_LD
-template <int NT = 256>
-__device__ __forceinline__ void load_block64(double* lds, const double* __restrict__ g, int tid) {
+template <typename T>
+__device__ __forceinline__ void kc_load(KCRegs<T>& r, const T* __restrict__ src, int64_t ld, int tid) {
+  typedef KCRegs<T> KR;
+  const int c = tid % KR::VPR, k = tid / KR::VPR;
 #pragma unroll
-  for (int q = 0; q < 2048 / NT; ++q) {
-    const int idx = tid + NT * q;  // 16-byte piece index, 2048 in all
-    const int row = idx >> 5, c2 = idx & 31;
-    *reinterpret_cast<v2d*>(lds + row * DI_LD + 2 * c2) =
-        *reinterpret_cast<const v2d*>(g + row * 64 + 2 * c2);
+  for (int q = 0; q < KR::NP; ++q)
+    r.v[q] = *reinterpret_cast<const typename Tr<T>::vec_t*>(src + (int64_t)(k + KR::RPP * q) * ld + Tr<T>::VE * c);
+}
+
+template <typename T>
+__device__ __forceinline__ void kc_store(const KCRegs<T>& r, T* lds, int tid) {
+  typedef KCRegs<T> KR;
+  const int c = tid % KR::VPR, k = tid / KR::VPR;
+#pragma unroll
+  for (int q = 0; q < KR::NP; ++q) Tr<T>::lds_store(lds + (k + KR::RPP * q) * KC_LD + Tr<T>::VE * c, r.v[q]);
+}
+
+// copy a dense 64 x 64 block (row-major, ld 64) from global into LDS with stride DI_LD, 256 threads
+template <typename T>
+__device__ __forceinline__ void load_block64(T* lds, const T* __restrict__ g, int tid) {
+  constexpr int VE = Tr<T>::VE, VPR = 64 / VE, NV = 4096 / VE;
+#pragma unroll
+  for (int q = 0; q < NV / 256; ++q) {
+    const int idx = tid + 256 * q;
+    const int row = idx / VPR, cv = idx % VPR;
+    Tr<T>::lds_store(lds + row * DI_LD + VE * cv,
+                     *reinterpret_cast<const typename Tr<T>::vec_t*>(g + row * 64 + VE * cv));
   }
 }
+
+// fp64 helpers kept for the Gram kernel (always fp64 accumulation)
+__device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return Tr<double>::mfma(a, b, c); }
+__device__ __forceinline__ int acc_row(int l4, int r) { return Tr<double>::acc_row(l4, r); }
+__device__ __forceinline__ d4 d4_zero() { return Tr<double>::zero(); }
 
 }  // namespace lsspa

@@ -170,7 +170,7 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
 def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_size=2 ** 8,
            tolerance=1e-2, seed=42, perms=None, antithetical=True, return_attribution_history=False, *,
            method=None, num_batches=None, return_history=None, device=0, error_estimator="reference",
-           _engine=None, _comm=None):
+           precision="float64", _engine=None, _comm=None):
     """Estimates the Shapley attribution of the out-of-sample R^2 of a least-squares fit.
 
     Positional parameters, defaults and behaviour follow cvxgrp/ls-spa
@@ -182,6 +182,9 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
     device:  GPU index.
     error_estimator:  'reference' (host, same generator call order as the reference) or
         'lowrank' (same distribution, O(n p) instead of an O(p^3) factorisation).
+    precision:  'float64' (default, the reference's arithmetic) or 'float32' for the per-ordering
+        factorisation work (about half the time; lifts agree to ~1e-5 on well-conditioned data;
+        the Gram reduction, lift accumulation and statistics stay float64).
     """
     X_train, X_test = np.array(X_train), np.array(X_test)
     y_train, y_test = np.array(y_train), np.array(y_test)
@@ -202,6 +205,8 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         from ._engine import HipEngine
         engine = HipEngine(device)
     try:
+        if precision != "float64" or getattr(engine, "precision", "float64") != "float64":
+            engine.set_precision(precision)
         engine.load_data(X_train, X_test, y_train, y_test, reg)
         attribution, feat_err, total_err, err_hist, history, _ = run_estimator(
             engine, p, max_samples=max_samples, batch_size=batch_size, tolerance=tolerance, seed=seed,

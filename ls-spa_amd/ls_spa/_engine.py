@@ -50,6 +50,7 @@ class HipEngine:
         self.m = 0
         self.tri = False
         self.y_norm_sq = float("nan")
+        self.precision = "float64"
         if stream is not None:
             self._check(self._lib.lsspa_set_stream(self._h, C.c_void_p(int(stream))))
 
@@ -199,11 +200,19 @@ class HipEngine:
     def set_flags(self, flags: int):
         self._check(self._lib.lsspa_set_flags(self._h, int(flags)))
 
-    def mfma_probe(self, A, B):
+    def set_precision(self, dtype):
+        """'float64' (default) or 'float32' for the per-ordering factorisation work."""
+        name = np.dtype(dtype).name
+        if name not in ("float64", "float32"):
+            raise ValueError("precision must be float64 or float32")
+        self._check(self._lib.lsspa_set_precision(self._h, N.F32 if name == "float32" else N.F64))
+        self.precision = name
+
+    def mfma_probe(self, A, B, f32=False):
         A = np.ascontiguousarray(A, dtype=np.float64)
         B = np.ascontiguousarray(B, dtype=np.float64)
         D = np.empty((16, 16))
-        self._check(self._lib.lsspa_mfma_probe(self._h, N.dptr(A), N.dptr(B), N.dptr(D)))
+        self._check(self._lib.lsspa_mfma_probe(self._h, N.dptr(A), N.dptr(B), N.dptr(D), int(bool(f32))))
         return D
 
     def debug_factor(self, perm):

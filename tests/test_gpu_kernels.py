@@ -15,12 +15,14 @@ def problem(seed, p, n, m):
     return Xa, Xe, Xa @ w + rng.standard_normal(n), Xe @ w + rng.standard_normal(m)
 
 
-def test_mfma_f64_lane_maps(engine):
-    """Pins the operand / result lane maps of v_mfma_f64_16x16x4_f64 with asymmetric data."""
+@pytest.mark.parametrize("f32", [False, True])
+def test_mfma_lane_maps(engine, f32):
+    """Pins the operand / result lane maps of v_mfma_f64_16x16x4_f64 and v_mfma_f32_16x16x4_f32
+    (they differ in the result rows) with asymmetric small-integer data (exact in both types)."""
     rng = np.random.default_rng(1)
     A = rng.integers(-8, 9, (16, 4)).astype(np.float64)
     B = rng.integers(-8, 9, (4, 16)).astype(np.float64)
-    D = engine.mfma_probe(A, B)
+    D = engine.mfma_probe(A, B, f32=f32)
     np.testing.assert_array_equal(D, A @ B)
 
 
@@ -94,3 +96,34 @@ def test_full_fit_and_stats(engine):
     assert cnt == len(all_l)
     np.testing.assert_allclose(mean, all_l.mean(0), rtol=0, atol=1e-14)
     np.testing.assert_allclose(cov, np.cov(all_l, rowvar=False, bias=True), rtol=0, atol=1e-15)
+
+
+# ---------------------------------------------------------------- fp32 mode
+@pytest.mark.parametrize("p,n,m,anti,reg", [(12, 60, 50, True, 0.0), (100, 400, 300, True, 0.0),
+                                            (200, 500, 260, False, 1e-2), (70, 300, 40, True, 0.0),
+                                            (257, 900, 700, True, 1e-2)])
+def test_fp32_lift_batch_vs_oracle(engine, p, n, m, anti, reg):
+    """fp32 work matrices (fp64 Gram reduction, fp64 lift accumulation): stated tolerance 1e-4 absolute
+    on well-conditioned data (SURVEY.md 8c for the fp32 configuration); observed ~1e-6."""
+    Xa, Xe, ya, ye = problem(5, p, n, m)
+    red = O.reduce(Xa, Xe, ya, ye, reg)
+    yy = float(ye @ ye)
+    rng = np.random.default_rng(2)
+    perms = np.array([rng.permutation(p) for _ in range(9)])
+    want = np.array([O.sample_lift(*red, yy, o, anti) for o in perms])
+    engine.set_precision("float32")
+    try:
+        engine.load_data(Xa, Xe, ya, ye, reg)
+        got = engine.run_batch(perms, anti, want_lifts=True, accumulate=False)
+        theta, r2, info = engine.full_fit()
+    finally:
+        engine.set_precision("float64")
+    assert info == 0
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)
+    assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max() * p)
+    G = Xa.T @ Xa / n + reg * np.eye(p)
+    np.testing.assert_allclose(theta, np.linalg.solve(G, Xa.T @ ya / n), rtol=2e-3, atol=2e-4)
+    # and the fp64 path is untouched after switching back
+    engine.load_data(Xa, Xe, ya, ye, reg)
+    np.testing.assert_allclose(engine.run_batch(perms, anti, want_lifts=True, accumulate=False), want,
+                               rtol=0, atol=1e-11)

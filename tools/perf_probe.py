@@ -18,6 +18,8 @@ ya = Xa @ th + torch.randn(N, dtype=torch.float64, device=dev)
 ye = Xe @ th + torch.randn(N, dtype=torch.float64, device=dev)
 torch.cuda.synchronize()
 eng = HipEngine(0)
+if os.environ.get("LSSPA_F32") == "1":
+    eng.set_precision("float32")
 eng.profile(True)
 t0 = time.perf_counter()
 eng.load_device_data(Xa.data_ptr(), p, ya.data_ptr(), N, Xe.data_ptr(), p, ye.data_ptr(), N, p, 0.0)
