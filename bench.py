@@ -27,6 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "ls-spa_amd"))
 import numpy as np  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix = vector peak (vendor sheet)
+FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
 
 
@@ -38,6 +39,8 @@ def parse():
     ap.add_argument("--p", type=int, default=1000)
     ap.add_argument("--rows", type=int, default=100000)
     ap.add_argument("--batch-size", type=int, default=128)
+    ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
+                    help="element type of the per-ordering factorisation work (BASELINE C3 is f64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ttt", action="store_true", help="skip the time-to-tolerance run")
     return ap.parse_args()
@@ -150,6 +153,10 @@ def main():
     torch.cuda.synchronize()
 
     eng = HipEngine(local, stream=eng_stream)
+    if args.dtype == "f32":
+        eng.set_precision("float32")
+    peak_tf = FP32_PEAK_TFLOPS if args.dtype == "f32" else FP64_PEAK_TFLOPS
+    esz = 4 if args.dtype == "f32" else 8
     eng.profile(True)
     t0 = time.perf_counter()
     eng.load_device_data(Xa.data_ptr(), p, ya.data_ptr(), rows, Xe.data_ptr(), p, ye.data_ptr(), rows, p, 0.0)
@@ -226,23 +233,26 @@ def main():
                     traffic = rec.get("hbm_bytes_per_launch", {}).get(dom)
             except Exception:
                 traffic = None
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic,
+        if args.dtype == "f32":
+            traffic = None   # the committed PMC summary was collected on the f64 path
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak_tf,
+                    "unit": "TFLOP/s", "frac": ach / peak_tf, "traffic": traffic,
                     "algorithmic_flops_per_launch": flops, "avg_launch_ms": per_class[dom]["avg_launch_ms"],
                     "traffic_gbps": (traffic / (per_class[dom]["avg_launch_ms"] * 1e-3) / 1e9) if traffic else None,
                     "note": "peak = vendor fp64 matrix/vector figure; v_mfma_f64_16x16x4 sustains 47.8 TFLOP/s "
                             "on this chip (tools/mfma_bench.hip); the kernel's k-loop is co-limited by operand "
                             "traffic (DESIGN.md section 5)"}
-        g_bytes = 2.0 * p * p * 8 * n_ord           # 2 p^2 s bytes per ordering
+        g_bytes = 2.0 * p * p * esz * n_ord         # 2 p^2 s bytes per ordering
         g_ach = g_bytes / (per_class["gather"]["avg_launch_ms"] * 1e-3) / 1e9
         gram_flops = 2.0 * rows * (p + 1) * (p + 2) / 2   # (N + M)(p + 1)(p + 2), both sides -> per launch
         gram_ach = gram_flops / ((gram_ms / max(gram_n, 1)) * 1e-3) / 1e12
         out = {
             "metric": "orderings_per_sec", "value": value, "unit": "orderings/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"C3 p={p} N=M={rows} method=argsort batch_size={B} antithetical "
-                                   f"(={n_ord} orderings/step/GPU) fp64", "p": p, "N": rows, "M": rows,
+                                   f"(={n_ord} orderings/step/GPU) {'fp64' if args.dtype == 'f64' else 'fp32 work / fp64 accumulation'}",
+                       "p": p, "N": rows, "M": rows,
                        "batch_size": B, "orderings_per_step_per_gpu": n_ord, "path": "tri" if eng.tri else "rect"},
             "roofline": roofline,
             "roofline_gather": {"bound": "hbm", "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -127,3 +127,30 @@ def test_fp32_lift_batch_vs_oracle(engine, p, n, m, anti, reg):
     engine.load_data(Xa, Xe, ya, ye, reg)
     np.testing.assert_allclose(engine.run_batch(perms, anti, want_lifts=True, accumulate=False), want,
                                rtol=0, atol=1e-11)
+
+
+# ---------------------------------------------------------------- block-boundary shapes
+@pytest.mark.parametrize("p", [1, 2, 9, 63, 64, 65, 127, 128, 129, 191, 192])
+@pytest.mark.parametrize("m_rel", ["tri", "rect"])
+def test_block_boundary_shapes(engine, p, m_rel):
+    """p around the 64 / 128 tile edges (p_pad = round_up(p + 1, 64) changes at p = 63/64, the strip
+    count at 128/129, an odd block count at 65..128), both device paths."""
+    n = max(3 * p, 40)
+    m = n if m_rel == "tri" else max(p - 3, 1)
+    if m_rel == "rect" and p == 1:
+        pytest.skip("M < p impossible for p = 1")
+    Xa, Xe, ya, ye = problem(50 + p, p, n, m)
+    engine.load_data(Xa, Xe, ya, ye, 0.0)
+    assert engine.tri == (m >= p)
+    red = O.reduce(Xa, Xe, ya, ye, 0.0)
+    yy = float(ye @ ye)
+    rng = np.random.default_rng(p)
+    perms = np.array([np.arange(p), np.arange(p)[::-1]] + [rng.permutation(p) for _ in range(3)])
+    for anti in (False, True):
+        got = engine.run_batch(perms, anti, want_lifts=True, accumulate=False)
+        want = np.array([O.sample_lift(*red, yy, o, anti) for o in perms])
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)
+    theta, r2, info = engine.full_fit()
+    assert info == 0
+    np.testing.assert_allclose(theta, np.linalg.lstsq(Xa, ya, rcond=None)[0], rtol=1e-8, atol=1e-10)
+    assert abs(r2 - want[0].sum()) < 1e-10      # every ordering's lifts sum to the full-model R^2

@@ -252,3 +252,40 @@ def test_full_size_properties(p, N):
             np.testing.assert_allclose(got, O.ordering_lift(R, F, q, qt, eng.y_norm_sq, o), **LIFT_TOL)
     finally:
         eng.close()
+
+
+def test_c5_shape_fp32_vs_fp64():
+    """BASELINE config 5's shape (p = 5000, reg = 1e-2, argsort, fp32) at reduced N: the fp32 path
+    against the fp64 path (itself parity-checked above) on the same orderings, plus the sum-to-R^2
+    invariant.  Stated fp32 tolerance: 1e-4 absolute per lift."""
+    import torch
+    from scipy.stats.qmc import Sobol
+    from ls_spa._engine import HipEngine
+    p, N = 5000, 12000
+    torch.manual_seed(1)
+    dev = torch.device("cuda:0")
+    Xa = torch.randn(N, p, dtype=torch.float32, device=dev)
+    Xe = torch.randn(N, p, dtype=torch.float32, device=dev)
+    w = torch.randn(p, dtype=torch.float32, device=dev) / 70.0
+    ya = Xa @ w + torch.randn(N, dtype=torch.float32, device=dev)
+    ye = Xe @ w + torch.randn(N, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    perms = np.argsort(Sobol(p, seed=42).random(4), axis=1)
+    eng = HipEngine(0)
+    try:
+        out = {}
+        for prec in ("float64", "float32"):
+            eng.set_precision(prec)
+            eng.load_device_data(Xa.data_ptr(), p, ya.data_ptr(), N, Xe.data_ptr(), p, ye.data_ptr(), N, p, 1e-2,
+                                 f32=True)
+            theta, r2, info = eng.full_fit()
+            assert info == 0
+            out[prec] = (eng.run_batch(perms, True, want_lifts=True, accumulate=False), theta, r2)
+        l64, th64, r64 = out["float64"]
+        l32, th32, r32 = out["float32"]
+        np.testing.assert_allclose(l64.sum(1), r64, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(l32, l64, rtol=0, atol=1e-4)
+        assert abs(r32 - r64) < 1e-4
+        np.testing.assert_allclose(th32, th64, rtol=0, atol=1e-4)
+    finally:
+        eng.close()
