@@ -294,6 +294,21 @@ def main():
                                                 "seconds_incl_reduction": ttt + reduce_ms * 1e-3,
                                                 "samples_at_stop": int(n_stop), "overall_error": float(total_err),
                                                 "error_estimator": "lowrank (host numpy, O(1024 n p))"}
+        # and with the same thin form evaluated on the GPU (lift vectors stay in HBM; with several ranks the
+        # partial draws are summed by one extra all-reduce per check)
+        for rep in range(2):   # first pass allocates the history / draws buffers
+            barrier()
+            t0 = time.perf_counter()
+            _, _, total_err, _, _, n_stop = run_estimator(
+                eng, p, max_samples=B * 128, batch_size=B, tolerance=1e-2, seed=42, perms=None, antithetical=True,
+                return_attribution_history=False, method="argsort", error_estimator="device", comm=comm)
+            barrier()
+            ttt = time.perf_counter() - t0
+        if out is not None:
+            out["time_to_tolerance_device"] = {"seconds_sampling_loop": ttt,
+                                               "seconds_incl_reduction": ttt + reduce_ms * 1e-3,
+                                               "samples_at_stop": int(n_stop), "overall_error": float(total_err),
+                                               "error_estimator": "device (thin form, HIP kernels)"}
 
     if out is not None and world == 1 and not args.no_cpu_baseline:
         G, g, H, h = eng.gram()

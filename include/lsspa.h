@@ -98,6 +98,32 @@ int lsspa_stats_pending(lsspa_ctx* ctx, void** device_ptr, int64_t* count);
 int lsspa_stats_merge(lsspa_ctx* ctx);
 /* n samples, mean [p], biased covariance [p][p] (may be NULL) */
 int lsspa_stats_get(lsspa_ctx* ctx, int64_t* n, double* mean, double* cov_biased);
+/* checkpoint / resume: overwrite the running statistics with (n, mean [p], biased covariance [p][p]) as
+ * lsspa_stats_get returned them; the pending buffer is cleared.  (The reference keeps these in three Python
+ * locals, ls_spa/ls_spa.py:190-192, and cannot resume.) */
+int lsspa_stats_set(lsspa_ctx* ctx, int64_t n, const double* mean, const double* cov_biased);
+
+/* a5 -- device-side replacement of error_estimates (ls_spa/ls_spa.py:321-341) in its thin form:
+ * 1024 draws x = Xi (L - 1 mean^T) / sqrt(n (n - 1)) with L the [n][p] lift vectors of all samples so far, which
+ * has the covariance C_unbiased / n the reference samples from, without any p x p factorisation.
+ *   lsspa_history_enable : keep every accumulated sample's lift vector in HBM (capacity = rows allocated up front,
+ *                          grown geometrically when exceeded; 0 switches the history off and frees it).
+ *                          lsspa_stats_reset / lsspa_reduce / lsspa_set_reduced empty the history.
+ *   lsspa_history_get    : copy it out ([count][p], host); lifts may be NULL to query the count
+ *   lsspa_history_append : push rows back in (resume)
+ *   lsspa_error_draws    : xi is host fp64 [1024][ld_xi], standard normals; its first n_local columns go with this
+ *                          context's n_local history rows, in order.  n_total is the sample count over all ranks
+ *                          (== n_local on one GPU).  The centring uses the merged running mean.
+ *   lsspa_error_buffer   : device pointer / element count of the draws, the all-reduce(SUM) target between
+ *                          lsspa_error_draws and lsspa_error_quantiles when the samples are spread over ranks
+ *   lsspa_error_quantiles: feature_errors [p] = 0.95-quantile of |x_a| over the draws, overall_error = the same
+ *                          quantile of ||x||_2 (numpy's default linear interpolation) */
+int lsspa_history_enable(lsspa_ctx* ctx, int64_t capacity);
+int lsspa_history_get(lsspa_ctx* ctx, int64_t* count, double* lifts);
+int lsspa_history_append(lsspa_ctx* ctx, const double* lifts, int64_t rows);
+int lsspa_error_draws(lsspa_ctx* ctx, const double* xi, int64_t ld_xi, int64_t n_local, int64_t n_total);
+int lsspa_error_buffer(lsspa_ctx* ctx, void** device_ptr, int64_t* count);
+int lsspa_error_quantiles(lsspa_ctx* ctx, double* feature_errors, double* overall_error);
 
 /* per-kernel-class HIP-event timing on the context's stream */
 #define LSSPA_K_GATHER 0
@@ -107,7 +133,8 @@ int lsspa_stats_get(lsspa_ctx* ctx, int64_t* n, double* mean, double* cov_biased
 #define LSSPA_K_LIFT 4
 #define LSSPA_K_STATS 5
 #define LSSPA_K_GRAM 6
-#define LSSPA_K_COUNT 7
+#define LSSPA_K_ERROR 7
+#define LSSPA_K_COUNT 8
 int lsspa_profile_enable(lsspa_ctx* ctx, int32_t on);
 int lsspa_profile_get(lsspa_ctx* ctx, int32_t kernel_class, double* total_ms, int64_t* launches);
 int lsspa_profile_reset(lsspa_ctx* ctx);

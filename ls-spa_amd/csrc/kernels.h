@@ -89,6 +89,16 @@ hipError_t launch_gram(const GramArgs& a, hipStream_t st);
 hipError_t launch_gram_finalize(const double* C, int p, double scale, double reg, double* G, int64_t ldg,
                                 double* g, double* scalar_out, hipStream_t st);
 
+// Device-side error estimator.  launch_error_draws: draws[d][a] = sum_k Xi[d][k] (H[k][a] - mean[a]) * scale for
+// the 1024 draws d (Xi [1024][ldxi], H [n_pad][ldh], both zero-padded to n_pad samples, n_pad a multiple of 16;
+// ldh and ldd cover ceil(p/128)*128 columns).  launch_error_quantiles: out[a] = 0.95-quantile of |draws[:, a]|,
+// out[p] = 0.95-quantile of the row 2-norms (norms [1024] is a workspace).
+constexpr int ERR_DRAWS = 1024;
+hipError_t launch_error_draws(const double* Xi, int ldxi, const double* H, int ldh, int n_pad,
+                              const double* mean, double scale, int p, double* draws, int ldd, hipStream_t st);
+hipError_t launch_error_quantiles(const double* draws, int ldd, int p, double* norms, double* out,
+                                  hipStream_t st);
+
 // unit test hook: D = A(16x4) * B(4x16) on one wave through Tr<T>::mfma / acc_row (fp64 or fp32)
 hipError_t launch_mfma_probe(const double* A, const double* B, double* D, int f32, hipStream_t st);
 

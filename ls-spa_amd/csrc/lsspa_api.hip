@@ -66,6 +66,10 @@ struct lsspa_ctx {
   // running statistics
   DevBuf<double> mean, M2, pend, state_n;
   bool pend_dirty = false;
+  // history of lift vectors + device-side error estimator
+  DevBuf<double> hist, xi_d, draws, err_out;
+  int64_t hist_cap = 0, hist_n = 0;
+  int ldh() const { return ((p + 127) / 128) * 128; }
   int flags = 0;
 
   // profiling
@@ -215,6 +219,9 @@ int set_dims(lsspa_ctx* ctx, int p, int m, int tri) {
   // the workspace depends on p: drop it, it is re-created on demand
   ctx->cap_ord = 0;
   ctx->cap_samples = 0;
+  // so does the lift history (row stride): it has to be enabled again for the new problem
+  ctx->hist_cap = 0;
+  ctx->hist_n = 0;
   return LSSPA_OK;
 }
 
@@ -226,6 +233,31 @@ int stats_reset(lsspa_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->state_n.ptr, 0, sizeof(double) * 8, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->info_d.ptr, 0, sizeof(int32_t) * 8, ctx->stream));
   ctx->pend_dirty = false;
+  ctx->hist_n = 0;
+  return LSSPA_OK;
+}
+
+// append rows [rows][p] (device or host, row stride p) to the history
+int hist_append(lsspa_ctx* ctx, const double* src, int64_t rows, hipMemcpyKind kind) {
+  const size_t ldh = ctx->ldh();
+  if (ctx->hist_n + rows > ctx->hist_cap) {
+    // grow geometrically; the capacity given to lsspa_history_enable is only the first allocation
+    const int64_t cap = std::max<int64_t>(2 * ctx->hist_cap, ctx->hist_n + rows);
+    const int64_t cap_rows = ((cap + KCH - 1) / KCH) * KCH;
+    DevBuf<double> bigger;
+    TRY(dev_alloc(ctx, bigger, (size_t)cap_rows * ldh));
+    HIPCHK(hipMemsetAsync(bigger.ptr, 0, bigger.count * 8, ctx->stream));
+    if (ctx->hist_n > 0)
+      HIPCHK(hipMemcpyAsync(bigger.ptr, ctx->hist.ptr, (size_t)ctx->hist_n * ldh * 8, hipMemcpyDeviceToDevice,
+                            ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->hist);
+    ctx->hist = bigger;
+    ctx->hist_cap = cap;
+  }
+  HIPCHK(hipMemcpy2DAsync(ctx->hist.ptr + (size_t)ctx->hist_n * ldh, ldh * 8, src, (size_t)ctx->p * 8,
+                          (size_t)ctx->p * 8, (size_t)rows, kind, ctx->stream));
+  ctx->hist_n += rows;
   return LSSPA_OK;
 }
 
@@ -482,6 +514,7 @@ int lsspa_destroy(lsspa_ctx* ctx) {
   dev_free(ctx->ytil); dev_free(ctx->scal); dev_free(ctx->A); dev_free(ctx->V); dev_free(ctx->Dinv);
   dev_free(ctx->Ppart); dev_free(ctx->lifts); dev_free(ctx->diag0); dev_free(ctx->perms_d); dev_free(ctx->info_d);
   dev_free(ctx->mean); dev_free(ctx->M2); dev_free(ctx->pend); dev_free(ctx->state_n);
+  dev_free(ctx->hist); dev_free(ctx->xi_d); dev_free(ctx->draws); dev_free(ctx->err_out);
   for (int b = 0; b < 2; ++b) {
     if (ctx->perms_h[b]) (void)hipHostFree(ctx->perms_h[b]);
     if (ctx->perms_ev[b]) (void)hipEventDestroy(ctx->perms_ev[b]);
@@ -901,6 +934,7 @@ int lsspa_lift_batch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t an
     HIPCHK(launch_stats_batch(ctx->lifts.ptr, ctx->mean.ptr, ctx->pend.ptr, B, p, ctx->pend_dirty ? 1 : 0,
                               ctx->stream));
     ctx->pend_dirty = true;
+    if (ctx->hist_cap > 0) TRY(hist_append(ctx, ctx->lifts.ptr, B, hipMemcpyDeviceToDevice));
   }
   if (lifts_out) {
     HIPCHK(hipMemcpyAsync(lifts_out, ctx->lifts.ptr, sizeof(double) * (size_t)B * p, hipMemcpyDeviceToHost,
@@ -965,6 +999,124 @@ int lsspa_stats_get(lsspa_ctx* ctx, int64_t* n, double* mean, double* cov_biased
     const double inv = 1.0 / nd;
     for (size_t i = 0; i < p * p; ++i) cov_biased[i] *= inv;
   }
+  return LSSPA_OK;
+}
+
+int lsspa_stats_set(lsspa_ctx* ctx, int64_t n, const double* mean, const double* cov_biased) {
+  if (!ctx || !mean || !cov_biased || n < 0) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t p = ctx->p;
+  std::vector<double> m2(p * p);
+  for (size_t i = 0; i < p * p; ++i) m2[i] = cov_biased[i] * (double)n;
+  double st[8] = {(double)n, 0, 0, 0, 0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(ctx->state_n.ptr, st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->mean.ptr, mean, p * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->M2.ptr, m2.data(), p * p * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->pend.ptr, 0, sizeof(double) * ((size_t)1 + p + p * p), ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // m2 / st are stack and heap temporaries
+  ctx->pend_dirty = false;
+  return LSSPA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int lsspa_history_enable(lsspa_ctx* ctx, int64_t capacity) {
+  if (!ctx || capacity < 0) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->hist_n = 0;
+  ctx->hist_cap = 0;
+  if (capacity == 0) {
+    dev_free(ctx->hist);
+    return LSSPA_OK;
+  }
+  const int64_t rows = ((capacity + KCH - 1) / KCH) * KCH;   // the draws kernel reads whole 16-row chunks
+  TRY(dev_alloc(ctx, ctx->hist, (size_t)rows * ctx->ldh()));
+  // zero once: padding columns and the rows of a partial last chunk are read (times a zero of Xi)
+  HIPCHK(hipMemsetAsync(ctx->hist.ptr, 0, ctx->hist.count * 8, ctx->stream));
+  TRY(dev_alloc(ctx, ctx->draws, (size_t)ERR_DRAWS * ctx->ldh()));
+  TRY(dev_alloc(ctx, ctx->err_out, (size_t)ctx->p + 1 + ERR_DRAWS));
+  HIPCHK(hipMemsetAsync(ctx->draws.ptr, 0, ctx->draws.count * 8, ctx->stream));
+  ctx->hist_cap = capacity;
+  return LSSPA_OK;
+}
+
+int lsspa_history_get(lsspa_ctx* ctx, int64_t* count, double* lifts) {
+  if (!ctx || !count) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  *count = ctx->hist_n;
+  if (lifts && ctx->hist_n > 0) {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpy2DAsync(lifts, (size_t)ctx->p * 8, ctx->hist.ptr, (size_t)ctx->ldh() * 8, (size_t)ctx->p * 8,
+                            (size_t)ctx->hist_n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return LSSPA_OK;
+}
+
+int lsspa_history_append(lsspa_ctx* ctx, const double* lifts, int64_t rows) {
+  if (!ctx || rows < 0 || (rows > 0 && !lifts)) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  if (ctx->hist_cap == 0) return ctx->fail(LSSPA_ERR_STATE, "history is not enabled");
+  if (rows == 0) return LSSPA_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  TRY(hist_append(ctx, lifts, rows, hipMemcpyHostToDevice));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LSSPA_OK;
+}
+
+int lsspa_error_draws(lsspa_ctx* ctx, const double* xi, int64_t ld_xi, int64_t n_local, int64_t n_total) {
+  if (!ctx || n_local < 0 || n_total < n_local || (n_local > 0 && (!xi || ld_xi < n_local)))
+    return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  if (ctx->hist_cap == 0) return ctx->fail(LSSPA_ERR_STATE, "history is not enabled");
+  if (n_local != ctx->hist_n)
+    return ctx->fail(LSSPA_ERR_ARG, "n_local must equal the number of lift vectors in this context's history");
+  if (ctx->pend_dirty) return ctx->fail(LSSPA_ERR_STATE, "merge the pending batch first: the mean is stale");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int ldh = ctx->ldh();
+  if (n_local == 0) {   // a rank without samples contributes zeros to the all-reduce
+    HIPCHK(hipMemsetAsync(ctx->draws.ptr, 0, ctx->draws.count * 8, ctx->stream));
+    return LSSPA_OK;
+  }
+  const int64_t n_pad = ((n_local + KCH - 1) / KCH) * KCH;
+  TRY(dev_alloc(ctx, ctx->xi_d, (size_t)ERR_DRAWS * n_pad));
+  if (n_pad != n_local) HIPCHK(hipMemsetAsync(ctx->xi_d.ptr, 0, (size_t)ERR_DRAWS * n_pad * 8, ctx->stream));
+  HIPCHK(hipMemcpy2DAsync(ctx->xi_d.ptr, (size_t)n_pad * 8, xi, (size_t)ld_xi * 8, (size_t)n_local * 8, ERR_DRAWS,
+                          hipMemcpyHostToDevice, ctx->stream));
+  const double nt = (double)n_total;
+  const double scale = 1.0 / sqrt(nt * (nt - 1.0));   // inf for n_total = 1, as numpy's division gives
+  ProfScope ps(ctx, LSSPA_K_ERROR);
+  HIPCHK(launch_error_draws(ctx->xi_d.ptr, (int)n_pad, ctx->hist.ptr, ldh, (int)n_pad, ctx->mean.ptr, scale,
+                            ctx->p, ctx->draws.ptr, ldh, ctx->stream));
+  return LSSPA_OK;
+}
+
+int lsspa_error_buffer(lsspa_ctx* ctx, void** device_ptr, int64_t* count) {
+  if (!ctx || !device_ptr || !count) return LSSPA_ERR_ARG;
+  if (ctx->hist_cap == 0) return ctx->fail(LSSPA_ERR_STATE, "history is not enabled");
+  *device_ptr = ctx->draws.ptr;
+  *count = (int64_t)ERR_DRAWS * ctx->ldh();
+  return LSSPA_OK;
+}
+
+int lsspa_error_quantiles(lsspa_ctx* ctx, double* feature_errors, double* overall_error) {
+  if (!ctx || !feature_errors || !overall_error) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  if (ctx->hist_cap == 0) return ctx->fail(LSSPA_ERR_STATE, "history is not enabled");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int p = ctx->p;
+  {
+    ProfScope ps(ctx, LSSPA_K_ERROR);
+    HIPCHK(launch_error_quantiles(ctx->draws.ptr, ctx->ldh(), p, ctx->err_out.ptr + p + 1, ctx->err_out.ptr,
+                                  ctx->stream));
+  }
+  std::vector<double> out((size_t)p + 1);
+  HIPCHK(hipMemcpyAsync(out.data(), ctx->err_out.ptr, ((size_t)p + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::copy(out.begin(), out.begin() + p, feature_errors);
+  *overall_error = out[p];
   return LSSPA_OK;
 }
 

@@ -46,9 +46,16 @@ class TorchComm:
         return torch.as_tensor(buf, device="cuda")  # zero-copy view through __cuda_array_interface__
 
     def allreduce_pending(self, engine):
+        self._allreduce(engine, engine.pending_buffer)
+
+    def allreduce_draws(self, engine):
+        """Sum the ranks' partial error-estimator draws (device-side estimator, 1024 x p fp64)."""
+        self._allreduce(engine, engine.draws_buffer)
+
+    def _allreduce(self, engine, get_buffer):
         if self.world == 1 and not self._force:
             return
-        t = self._as_tensor(engine.pending_buffer())
+        t = self._as_tensor(get_buffer())
         if not self._on_gpu:
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
             return

@@ -47,6 +47,9 @@ class _Comm:
     def allreduce_pending(self, engine):
         return None
 
+    def allreduce_draws(self, engine):
+        return None
+
     def gather_lifts(self, local, counts):
         return local
 
@@ -96,6 +99,11 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
     estimate = p >= 9
     keep_lifts = return_attribution_history or error_estimator == "lowrank"
     engine.reset_stats()
+    on_device = error_estimator == "device" and estimate
+    if on_device:
+        first = batch_size if max_samples >= _NO_CAP else max_samples
+        engine.history_enable(max(16, -(-first // comm.world)))
+    local_idx = []   # global sample numbers of this rank's history rows, in order
     feat_err, total_err = np.zeros(p), 0.0
     err_hist, hist_parts, lift_parts = [], [], []
     hist_sum = np.zeros(p)
@@ -109,6 +117,13 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
             if error_estimator == "lowrank":
                 centred = np.concatenate(lift_parts) - mean
                 feat_err, total_err = error_estimates_lowrank(rng, centred, n)
+            elif on_device:
+                # same generator call as 'lowrank'; each rank multiplies the columns of its own samples
+                xi = rng.standard_normal((2 ** 10, n))
+                mine_idx = np.concatenate(local_idx) if local_idx else np.zeros(0, dtype=np.int64)
+                engine.error_draws(xi if len(mine_idx) == n else xi[:, mine_idx], n)
+                comm.allreduce_draws(engine)
+                feat_err, total_err = engine.error_quantiles()
             else:
                 _, _, cov_b = engine.stats(want_cov=True)
                 feat_err, total_err = error_estimates(rng, cov_b * n / (n - 1) / n)
@@ -128,6 +143,8 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
         local = None
         if len(mine):
             local = engine.run_batch(mine, antithetical, want_lifts=keep_lifts, accumulate=True)
+            if on_device:
+                local_idx.append(np.arange(i + comm.rank, i + n_new, comm.world))
         comm.allreduce_pending(engine)
         engine.merge()
         if keep_lifts:
@@ -180,8 +197,10 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
     num_batches:  if given, ``max_samples = batch_size * num_batches`` (README dialect).
     return_history:  alias of ``return_attribution_history``.
     device:  GPU index.
-    error_estimator:  'reference' (host, same generator call order as the reference) or
-        'lowrank' (same distribution, O(n p) instead of an O(p^3) factorisation).
+    error_estimator:  'reference' (host, same generator call order as the reference),
+        'lowrank' (same distribution, O(n p) instead of an O(p^3) factorisation, on the host) or
+        'device' (the low-rank form on the GPU: the lift vectors never leave HBM; same numbers as
+        'lowrank' for the same seed up to summation order).
     precision:  'float64' (default, the reference's arithmetic) or 'float32' for the per-ordering
         factorisation work (about half the time; lifts agree to ~1e-5 on well-conditioned data;
         the Gram reduction, lift accumulation and statistics stay float64).
@@ -196,8 +215,8 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         return_attribution_history = bool(return_history)
     if num_batches is not None:
         max_samples = int(batch_size) * int(num_batches)
-    if error_estimator not in ("reference", "lowrank"):
-        raise ValueError("error_estimator must be 'reference' or 'lowrank'")
+    if error_estimator not in ("reference", "lowrank", "device"):
+        raise ValueError("error_estimator must be 'reference', 'lowrank' or 'device'")
 
     engine = _engine
     owns = engine is None

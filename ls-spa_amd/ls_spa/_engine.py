@@ -182,6 +182,55 @@ class HipEngine:
         self._check(self._lib.lsspa_stats_get(self._h, C.byref(n), N.dptr(mean), N.dptr(cov)))
         return n.value, mean, cov
 
+    def set_stats(self, n: int, mean, cov_biased):
+        """Restore running statistics saved from ``stats()`` (checkpoint / resume)."""
+        mean = np.ascontiguousarray(mean, dtype=np.float64)
+        cov = np.ascontiguousarray(cov_biased, dtype=np.float64)
+        if mean.shape != (self.p,) or cov.shape != (self.p, self.p):
+            raise ValueError("mean / covariance shapes do not match the loaded problem")
+        self._check(self._lib.lsspa_stats_set(self._h, int(n), N.dptr(mean), N.dptr(cov)))
+
+    # ---- lift history + device-side error estimator ---------------------------------------
+    def history_enable(self, capacity: int):
+        self._check(self._lib.lsspa_history_enable(self._h, int(capacity)))
+
+    def history_count(self) -> int:
+        n = C.c_int64()
+        self._check(self._lib.lsspa_history_get(self._h, C.byref(n), None))
+        return n.value
+
+    def history(self):
+        """All accumulated samples' lift vectors, (count, p)."""
+        out = np.empty((self.history_count(), self.p))
+        n = C.c_int64()
+        self._check(self._lib.lsspa_history_get(self._h, C.byref(n), N.dptr(out)))
+        return out
+
+    def history_append(self, lifts):
+        lifts = np.ascontiguousarray(lifts, dtype=np.float64)
+        if lifts.ndim != 2 or lifts.shape[1] != self.p:
+            raise ValueError("lifts must be (rows, p)")
+        self._check(self._lib.lsspa_history_append(self._h, N.dptr(lifts), lifts.shape[0]))
+
+    def error_draws(self, xi_local, n_total: int):
+        """xi_local: (1024, n_local) standard normals for this engine's history rows."""
+        xi_local = np.ascontiguousarray(xi_local, dtype=np.float64)
+        if xi_local.ndim != 2 or xi_local.shape[0] != 1024:
+            raise ValueError("xi must be (1024, n_local)")
+        nl = xi_local.shape[1]
+        self._check(self._lib.lsspa_error_draws(self._h, N.dptr(xi_local) if nl else None, max(nl, 1), nl,
+                                                int(n_total)))
+
+    def draws_buffer(self) -> DeviceArrayView:
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        self._check(self._lib.lsspa_error_buffer(self._h, C.byref(ptr), C.byref(cnt)))
+        return DeviceArrayView(ptr.value, cnt.value, self)
+
+    def error_quantiles(self):
+        feat, tot = np.empty(self.p), C.c_double()
+        self._check(self._lib.lsspa_error_quantiles(self._h, N.dptr(feat), C.byref(tot)))
+        return feat, tot.value
+
     # ---- profiling / test hooks ---------------------------------------------------------
     def profile(self, on: bool):
         self._check(self._lib.lsspa_profile_enable(self._h, int(on)))

@@ -14,7 +14,7 @@ OK = 0
 F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
 INFO_NOT_PD = 1
-KERNEL_CLASSES = ("gather", "chol_diag", "chol_panel", "strip", "lift", "stats", "gram")
+KERNEL_CLASSES = ("gather", "chol_diag", "chol_panel", "strip", "lift", "stats", "gram", "error")
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.normpath(os.path.join(_PKG_DIR, "..", "lib", "liblsspa_hip.so"))
@@ -51,6 +51,13 @@ SIGNATURES = {
     "lsspa_stats_pending": (C.c_int, [_vp, C.POINTER(_vp), _pi64]),
     "lsspa_stats_merge": (C.c_int, [_vp]),
     "lsspa_stats_get": (C.c_int, [_vp, _pi64, _pd, _pd]),
+    "lsspa_stats_set": (C.c_int, [_vp, _i64, _pd, _pd]),
+    "lsspa_history_enable": (C.c_int, [_vp, _i64]),
+    "lsspa_history_get": (C.c_int, [_vp, _pi64, _pd]),
+    "lsspa_history_append": (C.c_int, [_vp, _pd, _i64]),
+    "lsspa_error_draws": (C.c_int, [_vp, _pd, _i64, _i64, _i64]),
+    "lsspa_error_buffer": (C.c_int, [_vp, C.POINTER(_vp), _pi64]),
+    "lsspa_error_quantiles": (C.c_int, [_vp, _pd, _pd]),
     "lsspa_profile_enable": (C.c_int, [_vp, _i32]),
     "lsspa_profile_get": (C.c_int, [_vp, _i32, _pd, _pi64]),
     "lsspa_profile_reset": (C.c_int, [_vp]),

@@ -26,6 +26,7 @@ class OracleEngine:
         p = self.p
         self._n, self._mean, self._M2 = 0, np.zeros(p), np.zeros((p, p))
         self._pend = np.zeros(1 + p + p * p)
+        self._hist = [] if getattr(self, "_hist_on", False) else None
 
     def run_batch(self, perms, antithetical, want_lifts=False, accumulate=True):
         perms = np.asarray(perms)
@@ -37,6 +38,8 @@ class OracleEngine:
             self._pend[0] += len(D)
             self._pend[1:1 + p] += D.sum(0)
             self._pend[1 + p:] += (D.T @ D).ravel()
+            if self._hist is not None:
+                self._hist.append(lifts)
         return lifts if want_lifts else None
 
     def pending_buffer(self):
@@ -57,6 +60,39 @@ class OracleEngine:
     def stats(self, want_cov=True):
         cov = self._M2 / self._n if (want_cov and self._n) else (self._M2.copy() if want_cov else None)
         return self._n, self._mean.copy(), cov
+
+    def set_stats(self, n, mean, cov_biased):
+        self._n, self._mean, self._M2 = int(n), np.array(mean, dtype=float), np.array(cov_biased) * n
+        self._pend[:] = 0
+
+    # lift history + thin-form error estimator (mirrors lsspa_history_* / lsspa_error_*)
+    def history_enable(self, capacity):
+        self._hist_on = capacity > 0
+        self._hist = [] if self._hist_on else None
+        self._draws = np.zeros(1024 * self.p)
+
+    def history(self):
+        return np.concatenate(self._hist) if self._hist else np.zeros((0, self.p))
+
+    def history_count(self):
+        return len(self.history())
+
+    def history_append(self, lifts):
+        self._hist.append(np.array(lifts, dtype=float))
+
+    def error_draws(self, xi_local, n_total):
+        H = self.history()
+        assert xi_local.shape == (1024, len(H))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            d = (xi_local @ (H - self._mean)) / np.sqrt(n_total * (n_total - 1.0)) if len(H) else 0.0
+        self._draws[:] = np.broadcast_to(d, (1024, self.p)).ravel()
+
+    def draws_buffer(self):
+        return self._draws
+
+    def error_quantiles(self):
+        d = self._draws.reshape(1024, self.p)
+        return np.quantile(np.abs(d), 0.95, axis=0), float(np.quantile(np.linalg.norm(d, axis=1), 0.95))
 
     def full_fit(self):
         R, F, q, qt = self._red

@@ -26,8 +26,13 @@ def _worker(rank, world, port, out_dir):
     eng = OracleEngine()
     res = ls_spa(*d, perms=g["perms64"][:50], batch_size=16, tolerance=0.0,
                  return_attribution_history=True, _engine=eng, _comm=TorchComm())
+    # thin-form estimator with the samples spread over the ranks: partial draws + one all-reduce
+    eng2 = OracleEngine()
+    dev = ls_spa(*d, perms=g["perms64"][:50], batch_size=16, tolerance=0.0, error_estimator="device",
+                 _engine=eng2, _comm=TorchComm())
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), attribution=res.attribution,
-             history=res.attribution_history, err=res.error_history, calls=np.array(eng.calls))
+             history=res.attribution_history, err=res.error_history, calls=np.array(eng.calls),
+             dev_err=dev.error_history, dev_feat=dev.attribution_errors, dev_rows=eng2.history_count())
     dist.destroy_process_group()
 
 
@@ -51,4 +56,11 @@ def test_two_ranks_match_single_process(tmp_path):
     # both ranks take identical decisions and split every chunk
     np.testing.assert_array_equal(r0["err"], r1["err"])
     assert list(r0["calls"]) == [8, 8, 8, 1] and list(r1["calls"]) == [8, 8, 8, 1]
+    # device-form estimator: each rank held half of the lift vectors, result equals the host low-rank form
+    low = ls_spa(*d, perms=g["perms64"][:50], batch_size=16, tolerance=0.0, error_estimator="lowrank",
+                 _engine=OracleEngine())
+    for r in (r0, r1):
+        np.testing.assert_allclose(r["dev_err"], low.error_history, rtol=1e-10)
+        np.testing.assert_allclose(r["dev_feat"], low.attribution_errors, rtol=1e-10)
+        assert int(r["dev_rows"]) == 25
     # and the reference itself agrees (fixture made from it on the first 48... full 64 run differs)

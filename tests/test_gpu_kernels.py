@@ -154,3 +154,86 @@ def test_block_boundary_shapes(engine, p, m_rel):
     assert info == 0
     np.testing.assert_allclose(theta, np.linalg.lstsq(Xa, ya, rcond=None)[0], rtol=1e-8, atol=1e-10)
     assert abs(r2 - want[0].sum()) < 1e-10      # every ordering's lifts sum to the full-model R^2
+
+
+# ---------------------------------------------------------------- lift history, device-side error estimator
+@pytest.mark.parametrize("p,n_batches,bsz", [(12, 3, 7), (100, 2, 16), (130, 5, 13), (300, 1, 9)])
+def test_history_and_error_estimator(engine, p, n_batches, bsz):
+    """The thin-form estimator on the device against the same arithmetic in numpy, same Xi.
+    Sample counts that are not multiples of the 16-row chunk, p across the 128-column tile edge."""
+    Xa, Xe, ya, ye = problem(8, p, 3 * p + 20, 2 * p + 11)
+    engine.load_data(Xa, Xe, ya, ye, 0.0)
+    engine.history_enable(16)   # smaller than what follows: the history has to grow
+    rng = np.random.default_rng(4)
+    lifts = []
+    for _ in range(n_batches):
+        perms = np.array([rng.permutation(p) for _ in range(bsz)])
+        lifts.append(engine.run_batch(perms, True, want_lifts=True, accumulate=True))
+        engine.merge()
+    lifts = np.concatenate(lifts)
+    n = len(lifts)
+    assert engine.history_count() == n
+    np.testing.assert_array_equal(engine.history(), lifts)
+    _, mean, _ = engine.stats(want_cov=False)
+    xi = rng.standard_normal((1024, n))
+    engine.error_draws(xi, n)
+    feat, tot = engine.error_quantiles()
+    draws = (xi @ (lifts - mean)) / np.sqrt(n * (n - 1.0))
+    np.testing.assert_allclose(feat, np.quantile(np.abs(draws), 0.95, axis=0), rtol=1e-10, atol=1e-18)
+    np.testing.assert_allclose(tot, np.quantile(np.linalg.norm(draws, axis=1), 0.95), rtol=1e-11)
+    # a second estimate after more samples reuses the buffers
+    perms = np.array([rng.permutation(p) for _ in range(5)])
+    more = engine.run_batch(perms, True, want_lifts=True, accumulate=True)
+    with pytest.raises(Exception, match="merge"):
+        engine.error_draws(rng.standard_normal((1024, n + 5)), n + 5)
+    engine.merge()
+    lifts = np.concatenate([lifts, more])
+    n = len(lifts)
+    _, mean, _ = engine.stats(want_cov=False)
+    xi = rng.standard_normal((1024, n))
+    engine.error_draws(xi, n)
+    feat, tot = engine.error_quantiles()
+    draws = (xi @ (lifts - mean)) / np.sqrt(n * (n - 1.0))
+    np.testing.assert_allclose(feat, np.quantile(np.abs(draws), 0.95, axis=0), rtol=1e-10, atol=1e-18)
+    np.testing.assert_allclose(tot, np.quantile(np.linalg.norm(draws, axis=1), 0.95), rtol=1e-11)
+    with pytest.raises(Exception, match="n_local"):
+        engine.error_draws(xi[:, :-1], n)
+    engine.reset_stats()
+    assert engine.history_count() == 0
+    engine.history_enable(0)
+
+
+def test_stats_checkpoint_resume(engine):
+    """lsspa_stats_set + lsspa_history_append: stop after two batches, restore into a fresh problem
+    load, continue -- same statistics as the uninterrupted run."""
+    p = 60
+    Xa, Xe, ya, ye = problem(9, p, 200, 150)
+    rng = np.random.default_rng(5)
+    batches = [np.array([rng.permutation(p) for _ in range(8)]) for _ in range(3)]
+    engine.load_data(Xa, Xe, ya, ye, 0.01)
+    engine.history_enable(64)
+    for b in batches:
+        engine.run_batch(b, True, accumulate=True)
+        engine.merge()
+    n_ref, mean_ref, cov_ref = engine.stats()
+    hist_ref = engine.history()
+
+    engine.load_data(Xa, Xe, ya, ye, 0.01)
+    engine.history_enable(64)
+    for b in batches[:2]:
+        engine.run_batch(b, True, accumulate=True)
+        engine.merge()
+    saved = engine.stats()
+    saved_hist = engine.history()
+    engine.load_data(Xa, Xe, ya, ye, 0.01)     # "new process"
+    engine.history_enable(8)
+    engine.set_stats(*saved)
+    engine.history_append(saved_hist)
+    engine.run_batch(batches[2], True, accumulate=True)
+    engine.merge()
+    n, mean, cov = engine.stats()
+    assert n == n_ref == 24
+    np.testing.assert_allclose(mean, mean_ref, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(cov, cov_ref, rtol=0, atol=1e-16)
+    np.testing.assert_array_equal(engine.history(), hist_ref)
+    engine.history_enable(0)

@@ -289,3 +289,17 @@ def test_c5_shape_fp32_vs_fp64():
         np.testing.assert_allclose(th32, th64, rtol=0, atol=1e-4)
     finally:
         eng.close()
+
+
+def test_device_error_estimator_end_to_end():
+    """ls_spa(error_estimator='device') against 'lowrank' (host) on the product path: same generator
+    consumption, so the same stopping index and error history up to summation order."""
+    d = O.correlated_workload(np.random.default_rng(21), 100, 2000, 1500)
+    kw = dict(max_samples=512, batch_size=64, tolerance=2e-2, seed=7)
+    low = ls_spa(*d, error_estimator="lowrank", **kw)
+    dev = ls_spa(*d, error_estimator="device", **kw)
+    assert len(dev.error_history) == len(low.error_history) >= 1
+    np.testing.assert_allclose(dev.error_history, low.error_history, rtol=1e-9)
+    np.testing.assert_allclose(dev.attribution_errors, low.attribution_errors, rtol=1e-9)
+    np.testing.assert_allclose(dev.attribution, low.attribution, rtol=0, atol=1e-14)
+    assert dev.overall_error == dev.error_history[-1]

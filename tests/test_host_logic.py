@@ -108,6 +108,22 @@ def test_lowrank_estimator_matches_distribution():
 
 
 # ---------------------------------------------------------------- samplers
+def test_device_estimator_path_equals_lowrank(golden):
+    """'device' consumes the generator exactly like 'lowrank' and returns the same numbers (test double)."""
+    g = golden("p12")
+    d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+    kw = dict(perms=g["perms64"][:40], batch_size=16, tolerance=0.0)
+    low = pkg.ls_spa(*d, error_estimator="lowrank", _engine=OracleEngine(), **kw)
+    eng = OracleEngine()
+    dev = pkg.ls_spa(*d, error_estimator="device", _engine=eng, **kw)
+    np.testing.assert_allclose(dev.error_history, low.error_history, rtol=1e-12)
+    np.testing.assert_allclose(dev.attribution_errors, low.attribution_errors, rtol=1e-12)
+    np.testing.assert_allclose(dev.attribution, low.attribution, rtol=0, atol=1e-15)
+    assert eng.history_count() == 40
+    with pytest.raises(ValueError, match="error_estimator"):
+        pkg.ls_spa(*d, error_estimator="gpu", _engine=OracleEngine(), **kw)
+
+
 def test_samplers_match_fixtures(golden):
     g = golden("samplers_p12")
     np.testing.assert_allclose(S.helmert_rows(12), g["U"], atol=1e-15)
