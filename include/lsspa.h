@@ -56,6 +56,19 @@ int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const vo
                  const void* X_test, int64_t ld_test, const void* y_test, int64_t M, int32_t p, double reg,
                  int32_t dtype, int32_t location);
 
+/* a1, rows spread over several GPUs: every rank reduces the rows it holds,
+ *   lsspa_reduce_partial : unscaled Gram sums of n_local training rows and m_local test rows.  M_total is the
+ *                          test-row count over all ranks; if M_total < p the test rows ARE the test factor and
+ *                          every rank has to pass all of them (m_local == M_total).  n_local / m_local may be 0.
+ *   lsspa_reduce_buffer  : device pointer / element count (fp64) of the sums -- the all-reduce(SUM) target
+ *   lsspa_reduce_finish  : G, g, H, h from the summed buffers with the global N; the context is then in the
+ *                          same state as after lsspa_reduce on the stacked rows (up to summation order). */
+int lsspa_reduce_partial(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const void* y_train,
+                         int64_t n_local, const void* X_test, int64_t ld_test, const void* y_test,
+                         int64_t m_local, int64_t M_total, int32_t p, int32_t dtype, int32_t location);
+int lsspa_reduce_buffer(lsspa_ctx* ctx, void** device_ptr, int64_t* count);
+int lsspa_reduce_finish(lsspa_ctx* ctx, int64_t N_total, double reg);
+
 /* Load an already reduced problem (host pointers) -- the inputs square_shapley takes
  * (ls_spa/ls_spa.py:256-258) in Gram form.  G [p][p], g [p]; aug_train >= g^T G^-1 g.
  * tri != 0: H [p][p], h [p] (test Gram);  tri == 0: Ft [p][m] (transposed test factor), ytil [m]. */

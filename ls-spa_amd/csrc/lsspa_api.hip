@@ -68,6 +68,9 @@ struct lsspa_ctx {
   bool pend_dirty = false;
   // history of lift vectors + device-side error estimator
   DevBuf<double> hist, xi_d, draws, err_out;
+  // row-sharded reduction in progress: summed Gram buffers [2][P1pad][P1pad]
+  DevBuf<double> Cred;
+  bool reduce_open = false;
   int64_t hist_cap = 0, hist_n = 0;
   int ldh() const { return ((p + 127) / 128) * 128; }
   int flags = 0;
@@ -514,6 +517,7 @@ int lsspa_destroy(lsspa_ctx* ctx) {
   dev_free(ctx->ytil); dev_free(ctx->scal); dev_free(ctx->A); dev_free(ctx->V); dev_free(ctx->Dinv);
   dev_free(ctx->Ppart); dev_free(ctx->lifts); dev_free(ctx->diag0); dev_free(ctx->perms_d); dev_free(ctx->info_d);
   dev_free(ctx->mean); dev_free(ctx->M2); dev_free(ctx->pend); dev_free(ctx->state_n);
+  dev_free(ctx->Cred);
   dev_free(ctx->hist); dev_free(ctx->xi_d); dev_free(ctx->draws); dev_free(ctx->err_out);
   for (int b = 0; b < 2; ++b) {
     if (ctx->perms_h[b]) (void)hipHostFree(ctx->perms_h[b]);
@@ -547,13 +551,13 @@ int lsspa_synchronize(lsspa_ctx* ctx) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// C (device, [P1pad][P1pad], P1pad = round_up(p + 1, 128)) = [X | y]^T [X | y] over the n rows given
 static int gram_side(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, int64_t ld, int p, int is_f32,
-                     double scale, double reg, double* G, double* g, double* scalar_out) {
+                     double* C_out) {
   const int n_split = gram_default_split(n, p);
-  const int P1pad = round_up(p + 1, 128);
   DevBuf<double> slabs, C;
+  C.ptr = C_out;
   int rc = dev_alloc(ctx, slabs, gram_workspace_bytes(p, n_split) / sizeof(double));
-  if (rc == LSSPA_OK) rc = dev_alloc(ctx, C, (size_t)P1pad * P1pad);
   if (rc == LSSPA_OK) {
     ProfScope ps(ctx, LSSPA_K_GRAM);
     GramArgs ga;
@@ -568,7 +572,6 @@ static int gram_side(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, in
     ga.C = C.ptr;
     ga.accumulate = 0;
     hipError_t e = launch_gram(ga, ctx->stream);
-    if (e == hipSuccess) e = launch_gram_finalize(C.ptr, p, scale, reg, G, ctx->p_pad, g, scalar_out, ctx->stream);
     if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "gram launch", e);
   }
   if (rc == LSSPA_OK) {
@@ -576,7 +579,6 @@ static int gram_side(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, in
     if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "gram sync", e);
   }
   dev_free(slabs);
-  dev_free(C);
   return rc;
 }
 
@@ -585,9 +587,8 @@ static int gram_side(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, in
 // Grams accumulate in C in chunk order.  The caller's array is pinned in place for the duration
 // (hipHostRegister) when the runtime allows it, so the copies are true DMA.
 static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, int64_t ld, int p,
-                              int is_f32, double scale, double reg, double* G, double* g, double* scalar_out) {
+                              int is_f32, double* C_out) {
   const size_t es = is_f32 ? 4 : 8;
-  const int P1pad = round_up(p + 1, 128);
   int64_t rows = (((int64_t)96 << 20) / ((int64_t)p * (int64_t)es) / 16) * 16;   // ~96 MB chunks
   rows = std::max<int64_t>(1024, std::min<int64_t>(rows, ((n + 15) / 16) * 16));
   const int n_split = gram_default_split(rows, p);
@@ -597,8 +598,8 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
   hipStream_t cs = nullptr;
   hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
   bool reg_x = false, reg_y = false;
+  C.ptr = C_out;
   int rc = dev_alloc(ctx, slabs, gram_workspace_bytes(p, n_split) / sizeof(double));
-  if (rc == LSSPA_OK) rc = dev_alloc(ctx, C, (size_t)P1pad * P1pad);
   hipError_t e = hipSuccess;
   if (rc == LSSPA_OK) {
     for (int b = 0; b < 2 && e == hipSuccess; ++b) {
@@ -650,7 +651,6 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
       }
       if (e == hipSuccess) e = hipEventRecord(consumed[b], ctx->stream);
     }
-    if (e == hipSuccess) e = launch_gram_finalize(C.ptr, p, scale, reg, G, ctx->p_pad, g, scalar_out, ctx->stream);
     if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "streamed gram", e);
   }
   hipError_t es1 = hipStreamSynchronize(ctx->stream);
@@ -668,39 +668,29 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
     if (consumed[b]) (void)hipEventDestroy(consumed[b]);
   }
   dev_free(slabs);
-  dev_free(C);
   return rc;
 }
 
-int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const void* y_train, int64_t N,
-                 const void* X_test, int64_t ld_test, const void* y_test, int64_t M, int32_t p, double reg,
-                 int32_t dtype, int32_t location) {
-  if (!ctx) return LSSPA_ERR_ARG;
-  if (!X_train || !y_train || !X_test || !y_test) return ctx->fail(LSSPA_ERR_ARG, "NULL data pointer");
-  if (p < 1 || N < p || M < 1 || ld_train < p || ld_test < p)
-    return ctx->fail(LSSPA_ERR_ARG, "need 1 <= p <= N, M >= 1, ld >= p");
-  if (dtype != LSSPA_F64 && dtype != LSSPA_F32) return ctx->fail(LSSPA_ERR_ARG, "dtype");
-  if (location != LSSPA_HOST && location != LSSPA_DEVICE) return ctx->fail(LSSPA_ERR_ARG, "location");
-  if (!(reg >= 0.0)) return ctx->fail(LSSPA_ERR_ARG, "reg must be >= 0");
-  HIPCHK(hipSetDevice(ctx->device));
-  const int tri = (M >= p) ? 1 : 0;
-  if (!tri && M > (1 << 20)) return ctx->fail(LSSPA_ERR_ARG, "M too large for rect mode");
-  TRY(set_dims(ctx, p, tri ? p : (int)M, tri));
+// The local part of the reduction: unscaled Gram sums of this context's rows into ctx->Cred
+// ([2][P1pad][P1pad]: train, test), or -- rect mode, test side -- the transposed test factor.
+static int reduce_rows(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const void* y_train, int64_t N,
+                       const void* X_test, int64_t ld_test, const void* y_test, int64_t M, int32_t p,
+                       int32_t dtype, int32_t location, int tri) {
   const size_t es = dtype == LSSPA_F32 ? 4 : 8;
-
-  // host data: one side at a time through a temporary device copy
+  const int is_f32 = dtype == LSSPA_F32;
+  const size_t c_elems = (size_t)round_up(p + 1, 128) * round_up(p + 1, 128);
+  TRY(dev_alloc(ctx, ctx->Cred, 2 * c_elems));
+  HIPCHK(hipMemsetAsync(ctx->Cred.ptr, 0, 2 * c_elems * 8, ctx->stream));
   auto side = [&](const void* X, const void* y, int64_t n, int64_t ld, bool train) -> int {
+    if (n == 0) return LSSPA_OK;   // a rank without rows on this side contributes zeros
+    double* C = ctx->Cred.ptr + (train ? 0 : c_elems);
+    if (location == LSSPA_HOST && (train || tri)) return gram_side_streamed(ctx, X, y, n, ld, p, is_f32, C);
+    if (train || tri) return gram_side(ctx, X, y, n, ld, p, is_f32, C);
+    // rect mode: F = X_test as it stands (M < p rows), stored transposed; ||y_test||^2 on the side
     const void *dX = X, *dy = y;
     void *tX = nullptr, *ty = nullptr;
     int64_t dld = ld;
     int rc = LSSPA_OK;
-    if (location == LSSPA_HOST && (train || tri)) {
-      if (train)
-        return gram_side_streamed(ctx, X, y, n, ld, p, dtype == LSSPA_F32, 1.0 / (double)n, reg, ctx->G.ptr,
-                                  ctx->g.ptr, ctx->scal.ptr + 0);
-      return gram_side_streamed(ctx, X, y, n, ld, p, dtype == LSSPA_F32, 1.0, 0.0, ctx->H.ptr, ctx->h.ptr,
-                                ctx->scal.ptr + 1);
-    }
     if (location == LSSPA_HOST) {
       hipError_t e = hipMalloc(&tX, (size_t)n * p * es);
       if (e == hipSuccess) e = hipMalloc(&ty, (size_t)n * es);
@@ -717,29 +707,20 @@ int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const vo
       dld = p;
     }
     if (rc == LSSPA_OK) {
-      if (train) {
-        rc = gram_side(ctx, dX, dy, n, dld, p, dtype == LSSPA_F32, 1.0 / (double)n, reg, ctx->G.ptr,
-                       ctx->g.ptr, ctx->scal.ptr + 0);
-      } else if (tri) {
-        rc = gram_side(ctx, dX, dy, n, dld, p, dtype == LSSPA_F32, 1.0, 0.0, ctx->H.ptr, ctx->h.ptr,
-                       ctx->scal.ptr + 1);
-      } else {
-        const int64_t total = (int64_t)p * ctx->m_pad;
-        const int grid = (int)std::min<int64_t>((total + 255) / 256, 2048);
-        if (dtype == LSSPA_F32)
-          hipLaunchKernelGGL(transpose_test_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream,
-                             (const float*)dX, (const float*)dy, n, dld, p, ctx->m_pad, ctx->Ft.ptr,
-                             ctx->ytil.ptr);
-        else
-          hipLaunchKernelGGL(transpose_test_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream,
-                             (const double*)dX, (const double*)dy, n, dld, p, ctx->m_pad, ctx->Ft.ptr,
-                             ctx->ytil.ptr);
-        hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->ytil.ptr, ctx->m_pad,
-                           ctx->scal.ptr + 1);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "test factor kernels", e);
-      }
+      const int64_t total = (int64_t)p * ctx->m_pad;
+      const int grid = (int)std::min<int64_t>((total + 255) / 256, 2048);
+      if (is_f32)
+        hipLaunchKernelGGL(transpose_test_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)dX,
+                           (const float*)dy, n, dld, p, ctx->m_pad, ctx->Ft.ptr, ctx->ytil.ptr);
+      else
+        hipLaunchKernelGGL(transpose_test_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream,
+                           (const double*)dX, (const double*)dy, n, dld, p, ctx->m_pad, ctx->Ft.ptr,
+                           ctx->ytil.ptr);
+      hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->ytil.ptr, ctx->m_pad,
+                         ctx->scal.ptr + 1);
+      hipError_t e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "test factor kernels", e);
     }
     if (tX) (void)hipFree(tX);
     if (ty) (void)hipFree(ty);
@@ -747,14 +728,90 @@ int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const vo
   };
   TRY(side(X_train, y_train, N, ld_train, true));
   TRY(side(X_test, y_test, M, ld_test, false));
+  return LSSPA_OK;
+}
+
+// G = C_train / N + reg I, g, (tri) H = C_test, h, ||y_test||^2 from the summed Gram buffers
+static int reduce_finalize(lsspa_ctx* ctx, int64_t N_total, double reg) {
+  const int p = ctx->p;
+  const size_t c_elems = (size_t)round_up(p + 1, 128) * round_up(p + 1, 128);
+  {
+    ProfScope ps(ctx, LSSPA_K_GRAM);
+    HIPCHK(launch_gram_finalize(ctx->Cred.ptr, p, 1.0 / (double)N_total, reg, ctx->G.ptr, ctx->p_pad, ctx->g.ptr,
+                                ctx->scal.ptr + 0, ctx->stream));
+    if (ctx->tri)
+      HIPCHK(launch_gram_finalize(ctx->Cred.ptr + c_elems, p, 1.0, 0.0, ctx->H.ptr, ctx->p_pad, ctx->h.ptr,
+                                  ctx->scal.ptr + 1, ctx->stream));
+  }
   double sc[2];
-  HIPCHK(hipMemcpy(sc, ctx->scal.ptr, sizeof sc, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpyAsync(sc, ctx->scal.ptr, sizeof sc, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->aug_train = sc[0];
   ctx->y_norm_sq = sc[1];
   if (!(ctx->y_norm_sq > 0.0)) return ctx->fail(LSSPA_ERR_ARG, "y_test is identically zero (or NaN)");
   TRY(stats_reset(ctx));
   ctx->have_problem = true;
+  ctx->reduce_open = false;
+  dev_free(ctx->Cred);
   return LSSPA_OK;
+}
+
+int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const void* y_train, int64_t N,
+                 const void* X_test, int64_t ld_test, const void* y_test, int64_t M, int32_t p, double reg,
+                 int32_t dtype, int32_t location) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!X_train || !y_train || !X_test || !y_test) return ctx->fail(LSSPA_ERR_ARG, "NULL data pointer");
+  if (p < 1 || N < p || M < 1 || ld_train < p || ld_test < p)
+    return ctx->fail(LSSPA_ERR_ARG, "need 1 <= p <= N, M >= 1, ld >= p");
+  if (dtype != LSSPA_F64 && dtype != LSSPA_F32) return ctx->fail(LSSPA_ERR_ARG, "dtype");
+  if (location != LSSPA_HOST && location != LSSPA_DEVICE) return ctx->fail(LSSPA_ERR_ARG, "location");
+  if (!(reg >= 0.0)) return ctx->fail(LSSPA_ERR_ARG, "reg must be >= 0");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int tri = (M >= p) ? 1 : 0;
+  if (!tri && M > (1 << 20)) return ctx->fail(LSSPA_ERR_ARG, "M too large for rect mode");
+  TRY(set_dims(ctx, p, tri ? p : (int)M, tri));
+  TRY(reduce_rows(ctx, X_train, ld_train, y_train, N, X_test, ld_test, y_test, M, p, dtype, location, tri));
+  return reduce_finalize(ctx, N, reg);
+}
+
+int lsspa_reduce_partial(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const void* y_train,
+                         int64_t n_local, const void* X_test, int64_t ld_test, const void* y_test,
+                         int64_t m_local, int64_t M_total, int32_t p, int32_t dtype, int32_t location) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (n_local < 0 || m_local < 0 || M_total < 1 || m_local > M_total || p < 1)
+    return ctx->fail(LSSPA_ERR_ARG, "need n_local >= 0, 0 <= m_local <= M_total, p >= 1");
+  if ((n_local > 0 && (!X_train || !y_train || ld_train < p)) || (m_local > 0 && (!X_test || !y_test || ld_test < p)))
+    return ctx->fail(LSSPA_ERR_ARG, "NULL data pointer or ld < p");
+  if (dtype != LSSPA_F64 && dtype != LSSPA_F32) return ctx->fail(LSSPA_ERR_ARG, "dtype");
+  if (location != LSSPA_HOST && location != LSSPA_DEVICE) return ctx->fail(LSSPA_ERR_ARG, "location");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int tri = (M_total >= p) ? 1 : 0;
+  if (!tri && m_local != M_total)
+    return ctx->fail(LSSPA_ERR_ARG, "M_total < p: the test rows are the factor itself, pass all of them on every rank");
+  if (!tri && M_total > (1 << 20)) return ctx->fail(LSSPA_ERR_ARG, "M too large for rect mode");
+  TRY(set_dims(ctx, p, tri ? p : (int)M_total, tri));
+  TRY(reduce_rows(ctx, X_train, ld_train, y_train, n_local, X_test, ld_test, y_test, m_local, p, dtype, location,
+                  tri));
+  ctx->reduce_open = true;
+  return LSSPA_OK;
+}
+
+int lsspa_reduce_buffer(lsspa_ctx* ctx, void** device_ptr, int64_t* count) {
+  if (!ctx || !device_ptr || !count) return LSSPA_ERR_ARG;
+  if (!ctx->reduce_open) return ctx->fail(LSSPA_ERR_STATE, "no partial reduction in progress");
+  *device_ptr = ctx->Cred.ptr;
+  const int64_t P1pad = round_up(ctx->p + 1, 128);
+  *count = 2 * P1pad * P1pad;
+  return LSSPA_OK;
+}
+
+int lsspa_reduce_finish(lsspa_ctx* ctx, int64_t N_total, double reg) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->reduce_open) return ctx->fail(LSSPA_ERR_STATE, "no partial reduction in progress");
+  if (N_total < ctx->p) return ctx->fail(LSSPA_ERR_ARG, "need N_total >= p");
+  if (!(reg >= 0.0)) return ctx->fail(LSSPA_ERR_ARG, "reg must be >= 0");
+  HIPCHK(hipSetDevice(ctx->device));
+  return reduce_finalize(ctx, N_total, reg);
 }
 
 int lsspa_set_reduced(lsspa_ctx* ctx, int32_t p, const double* G, const double* g, double aug_train,

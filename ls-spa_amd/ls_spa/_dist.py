@@ -52,6 +52,16 @@ class TorchComm:
         """Sum the ranks' partial error-estimator draws (device-side estimator, 1024 x p fp64)."""
         self._allreduce(engine, engine.draws_buffer)
 
+    def allreduce_reduction(self, engine):
+        """Sum the ranks' Gram sums (row-sharded reduction)."""
+        self._allreduce(engine, engine.reduce_buffer)
+
+    def sum_ints(self, values):
+        t = self._torch.tensor([int(v) for v in values], dtype=self._torch.int64,
+                               device="cuda" if self._on_gpu else "cpu")
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
+        return [int(v) for v in t.cpu().tolist()]
+
     def _allreduce(self, engine, get_buffer):
         if self.world == 1 and not self._force:
             return

@@ -50,6 +50,12 @@ class _Comm:
     def allreduce_draws(self, engine):
         return None
 
+    def allreduce_reduction(self, engine):
+        return None
+
+    def sum_ints(self, values):
+        return [int(v) for v in values]
+
     def gather_lifts(self, local, counts):
         return local
 
@@ -187,7 +193,7 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
 def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_size=2 ** 8,
            tolerance=1e-2, seed=42, perms=None, antithetical=True, return_attribution_history=False, *,
            method=None, num_batches=None, return_history=None, device=0, error_estimator="reference",
-           precision="float64", _engine=None, _comm=None):
+           precision="float64", row_sharded=False, _engine=None, _comm=None):
     """Estimates the Shapley attribution of the out-of-sample R^2 of a least-squares fit.
 
     Positional parameters, defaults and behaviour follow cvxgrp/ls-spa
@@ -204,6 +210,10 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
     precision:  'float64' (default, the reference's arithmetic) or 'float32' for the per-ordering
         factorisation work (about half the time; lifts agree to ~1e-5 on well-conditioned data;
         the Gram reduction, lift accumulation and statistics stay float64).
+    row_sharded:  several ranks only (``_comm``).  False: every rank passes the whole data set.
+        True: the four arrays are this rank's ROWS of the training and test sets; the ranks reduce
+        their rows and sum the Gram matrices with one all-reduce.  'train': only the training rows are
+        sharded, every rank passes all test rows (needed when there are fewer than p test rows).
     """
     X_train, X_test = np.array(X_train), np.array(X_test)
     y_train, y_test = np.array(y_train), np.array(y_test)
@@ -226,7 +236,11 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
     try:
         if precision != "float64" or getattr(engine, "precision", "float64") != "float64":
             engine.set_precision(precision)
-        engine.load_data(X_train, X_test, y_train, y_test, reg)
+        if row_sharded:
+            engine.load_data_sharded(X_train, X_test, y_train, y_test, reg, _comm or _Comm(),
+                                     shard_test=row_sharded != "train")
+        else:
+            engine.load_data(X_train, X_test, y_train, y_test, reg)
         attribution, feat_err, total_err, err_hist, history, _ = run_estimator(
             engine, p, max_samples=max_samples, batch_size=batch_size, tolerance=tolerance, seed=seed,
             perms=perms, antithetical=antithetical, return_attribution_history=return_attribution_history,
@@ -240,8 +254,12 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
             G, g, _, _ = engine.gram()
             theta = _min_norm_theta(G, g)
             yy = engine.y_norm_sq
-            pred = X_test.astype(np.float64) @ theta
-            r_squared = float((2.0 * (pred @ y_test) - pred @ pred) / yy)
+            if engine.tri:      # from the Gram side: also right when the test rows are sharded
+                _, _, H, h = engine.gram()
+                r_squared = float((2.0 * (h @ theta) - theta @ H @ theta) / yy)
+            else:
+                pred = X_test.astype(np.float64) @ theta
+                r_squared = float((2.0 * (pred @ y_test) - pred @ pred) / yy)
     finally:
         if owns:
             engine.close()

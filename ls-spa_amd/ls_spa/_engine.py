@@ -99,6 +99,45 @@ class HipEngine:
             float(reg), N.F32 if dt == np.float32 else N.F64, N.HOST))
         self._refresh_dims()
 
+    def load_data_sharded(self, X_train, X_test, y_train, y_test, reg: float, comm, shard_test: bool = True):
+        """Row-sharded reduction: the arrays are THIS rank's rows; one all-reduce of the Gram sums
+        (2 (p+1)^2 fp64, padded) replaces moving the rows.  shard_test=False: every rank passes all the
+        test rows (required when there are fewer than p of them) and rank 0 alone contributes them."""
+        dt = np.float32 if (X_train.dtype == np.float32 and X_test.dtype == np.float32) else np.float64
+        Xa = np.ascontiguousarray(X_train, dtype=dt)
+        Xe = np.ascontiguousarray(X_test, dtype=dt)
+        ya = np.ascontiguousarray(y_train, dtype=dt)
+        ye = np.ascontiguousarray(y_test, dtype=dt)
+        n_loc, p = Xa.shape
+        m_loc = Xe.shape[0]
+        n_tot, m_sum = comm.sum_ints([n_loc, m_loc])
+        m_tot = m_sum if shard_test else m_loc
+        if not shard_test and m_tot >= p and comm.rank != 0:
+            m_loc = 0   # replicated test rows enter the Gram sum once
+        self._check(self._lib.lsspa_reduce_partial(
+            self._h, Xa.ctypes.data, p, ya.ctypes.data, n_loc, Xe.ctypes.data, p, ye.ctypes.data, m_loc, m_tot, p,
+            N.F32 if dt == np.float32 else N.F64, N.HOST))
+        comm.allreduce_reduction(self)
+        self._check(self._lib.lsspa_reduce_finish(self._h, int(n_tot), float(reg)))
+        self._refresh_dims()
+        return n_tot, m_tot
+
+    def reduce_partial_device(self, X_train_ptr, ld_train, y_train_ptr, n_local, X_test_ptr, ld_test, y_test_ptr,
+                              m_local, m_total, p, f32=False):
+        """Device-pointer form of the first step (rows already in HBM)."""
+        self._check(self._lib.lsspa_reduce_partial(
+            self._h, C.c_void_p(X_train_ptr), ld_train, C.c_void_p(y_train_ptr), n_local, C.c_void_p(X_test_ptr),
+            ld_test, C.c_void_p(y_test_ptr), m_local, m_total, p, N.F32 if f32 else N.F64, N.DEVICE))
+
+    def reduce_buffer(self) -> DeviceArrayView:
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        self._check(self._lib.lsspa_reduce_buffer(self._h, C.byref(ptr), C.byref(cnt)))
+        return DeviceArrayView(ptr.value, cnt.value, self)
+
+    def reduce_finish(self, n_total: int, reg: float):
+        self._check(self._lib.lsspa_reduce_finish(self._h, int(n_total), float(reg)))
+        self._refresh_dims()
+
     def load_device_data(self, X_train_ptr, ld_train, y_train_ptr, n, X_test_ptr, ld_test, y_test_ptr, m_rows,
                          p, reg, f32=False):
         """Same, from device pointers (e.g. torch tensors' data_ptr())."""

@@ -40,6 +40,9 @@ SIGNATURES = {
     "lsspa_set_stream": (C.c_int, [_vp, _vp]),
     "lsspa_synchronize": (C.c_int, [_vp]),
     "lsspa_reduce": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _dbl, _i32, _i32]),
+    "lsspa_reduce_partial": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32]),
+    "lsspa_reduce_buffer": (C.c_int, [_vp, C.POINTER(_vp), _pi64]),
+    "lsspa_reduce_finish": (C.c_int, [_vp, _i64, _dbl]),
     "lsspa_set_reduced": (C.c_int, [_vp, _i32, _pd, _pd, _dbl, _i32, _pd, _pd, _i32, _pd, _pd, _dbl]),
     "lsspa_get_problem": (C.c_int, [_vp, _pi32, _pi32, _pi32, _pd]),
     "lsspa_get_gram": (C.c_int, [_vp, _pd, _pd, _pd, _pd]),

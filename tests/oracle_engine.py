@@ -22,6 +22,39 @@ class OracleEngine:
         self.y_norm_sq = float(np.linalg.norm(ye) ** 2)
         self.reset_stats()
 
+    def load_data_sharded(self, Xa, Xe, ya, ye, reg, comm, shard_test=True):
+        """Gram sums of this rank's rows, one all-reduce, factors from the summed Gram (Cholesky)."""
+        Xa, Xe, ya, ye = (np.asarray(a, dtype=np.float64) for a in (Xa, Xe, ya, ye))
+        p = Xa.shape[1]
+        n_tot, m_sum = comm.sum_ints([len(Xa), len(Xe)])
+        m_tot = m_sum if shard_test else len(Xe)
+        Za, Ze = np.column_stack([Xa, ya]), np.column_stack([Xe, ye])
+        if not shard_test and comm.rank != 0:
+            Ze = Ze[:0]
+        self._cred = np.concatenate([(Za.T @ Za).ravel(), (Ze.T @ Ze).ravel()])
+        comm.allreduce_reduction(self)
+        Ca, Ce = self._cred.reshape(2, p + 1, p + 1)
+        G = Ca[:p, :p] / n_tot + reg * np.eye(p)
+        R = np.linalg.cholesky(G).T
+        q = np.linalg.solve(R.T, Ca[:p, p] / n_tot)
+        if m_tot >= p:
+            F = np.linalg.cholesky(Ce[:p, :p]).T
+            qt = np.linalg.solve(F.T, Ce[:p, p])
+            self.y_norm_sq = float(Ce[p, p])
+        else:
+            F, qt = Xe, ye
+            self.y_norm_sq = float(ye @ ye)
+        self._red = (R, F, q, qt)
+        self.p, self.m, self.tri = p, F.shape[0], m_tot >= p
+        self.reset_stats()
+
+    def reduce_buffer(self):
+        return self._cred
+
+    def gram(self):
+        R, F, q, qt = self._red
+        return R.T @ R, R.T @ q, F.T @ F, F.T @ qt
+
     def reset_stats(self):
         p = self.p
         self._n, self._mean, self._M2 = 0, np.zeros(p), np.zeros((p, p))

@@ -30,6 +30,13 @@ def _worker(rank, world, port, out_dir):
     eng2 = OracleEngine()
     dev = ls_spa(*d, perms=g["perms64"][:50], batch_size=16, tolerance=0.0, error_estimator="device",
                  _engine=eng2, _comm=TorchComm())
+    # row-sharded reduction: this rank holds every second row of both sets
+    eng3 = OracleEngine()
+    shard = ls_spa(d[0][rank::world], d[1][rank::world], d[2][rank::world], d[3][rank::world],
+                   perms=g["perms64"][:20], batch_size=16, tolerance=0.0, row_sharded=True,
+                   _engine=eng3, _comm=TorchComm())
+    np.savez(os.path.join(out_dir, f"s{rank}.npz"), attribution=shard.attribution, theta=shard.theta,
+             r2=shard.r_squared)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), attribution=res.attribution,
              history=res.attribution_history, err=res.error_history, calls=np.array(eng.calls),
              dev_err=dev.error_history, dev_feat=dev.attribution_errors, dev_rows=eng2.history_count())
@@ -63,4 +70,11 @@ def test_two_ranks_match_single_process(tmp_path):
         np.testing.assert_allclose(r["dev_err"], low.error_history, rtol=1e-10)
         np.testing.assert_allclose(r["dev_feat"], low.attribution_errors, rtol=1e-10)
         assert int(r["dev_rows"]) == 25
+    # row-sharded reduction: same attribution as the run on the stacked rows
+    full = ls_spa(*d, perms=g["perms64"][:20], batch_size=16, tolerance=0.0, _engine=OracleEngine())
+    for rk in (0, 1):
+        s = np.load(tmp_path / f"s{rk}.npz")
+        np.testing.assert_allclose(s["attribution"], full.attribution, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(s["theta"], full.theta, rtol=1e-9)
+        assert abs(float(s["r2"]) - full.r_squared) < 1e-11
     # and the reference itself agrees (fixture made from it on the first 48... full 64 run differs)

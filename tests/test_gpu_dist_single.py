@@ -72,5 +72,74 @@ def test_pending_buffer_is_a_zero_copy_device_tensor_and_allreduce_runs(golden):
         b = ls_spa(*d, perms=g["perms64"], batch_size=16, tolerance=0.0, return_attribution_history=True)
         np.testing.assert_array_equal(a.attribution, b.attribution)
         np.testing.assert_array_equal(a.attribution_history, b.attribution_history)
+        # row-sharded reduction and the device-side estimator through the collective path (forced, world of 1)
+        cf = TorchComm(force_collective=True)
+        c = ls_spa(*d, perms=g["perms64"], batch_size=16, tolerance=0.0, row_sharded=True,
+                   error_estimator="device", _comm=cf)
+        e = ls_spa(*d, perms=g["perms64"], batch_size=16, tolerance=0.0, error_estimator="lowrank")
+        np.testing.assert_allclose(c.attribution, b.attribution, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(c.theta, b.theta, rtol=1e-12)
+        np.testing.assert_allclose(c.error_history, e.error_history, rtol=1e-9)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("p,n,m,shard_test", [(40, 333, 211, True), (130, 700, 90, False), (100, 400, 300, False)])
+def test_row_sharded_reduction_two_engines_one_gpu(p, n, m, shard_test):
+    """Two contexts play two ranks: each reduces its rows, the Gram sums are added the way the
+    all-reduce would (through zero-copy torch views of lsspa_reduce_buffer), both finish -- same
+    reduced problem as one context on the stacked rows."""
+    import torch
+    from ls_spa._engine import HipEngine
+    rng = np.random.default_rng(3)
+    Xa, Xe = rng.standard_normal((n, p)), rng.standard_normal((m, p))
+    w = rng.standard_normal(p)
+    ya, ye = Xa @ w + rng.standard_normal(n), Xe @ w + rng.standard_normal(m)
+    ref = HipEngine(0)
+    ref.load_data(Xa, Xe, ya, ye, 0.05)
+    G0, g0, H0, h0 = ref.gram()
+    cut_a, cut_e = n // 3, m // 2
+    parts = [(Xa[:cut_a], ya[:cut_a], Xe[:cut_e], ye[:cut_e]), (Xa[cut_a:], ya[cut_a:], Xe[cut_e:], ye[cut_e:])]
+    engs = [HipEngine(0), HipEngine(0)]
+    keep = []
+    for rank, (eng, (xa, y1, xe, y2)) in enumerate(zip(engs, parts)):
+        if not shard_test:              # replicated test rows; only "rank 0" adds them when m >= p
+            xe, y2 = Xe, ye
+            m_loc = m if (m < p or rank == 0) else 0
+        else:
+            m_loc = len(xe)
+        arrs = [np.ascontiguousarray(a) for a in (xa, y1, xe, y2)]
+        keep.append(arrs)
+        eng._check(eng._lib.lsspa_reduce_partial(eng._h, arrs[0].ctypes.data, p, arrs[1].ctypes.data, len(xa),
+                                                 arrs[2].ctypes.data, p, arrs[3].ctypes.data, m_loc, m, p, 0, 0))
+    eng0, eng1 = engs
+    eng0.synchronize(), eng1.synchronize()
+    t0 = torch.as_tensor(eng0.reduce_buffer(), device="cuda")
+    t1 = torch.as_tensor(eng1.reduce_buffer(), device="cuda")
+    t0 += t1
+    t1.copy_(t0)
+    torch.cuda.synchronize()
+    for eng in engs:
+        eng.reduce_finish(n, 0.05)
+        G, g_, H, h = eng.gram()
+        np.testing.assert_allclose(G, G0, rtol=1e-13, atol=1e-14)
+        np.testing.assert_allclose(g_, g0, rtol=1e-12, atol=1e-14)
+        assert eng.tri == ref.tri and abs(eng.y_norm_sq - ref.y_norm_sq) <= 1e-12 * ref.y_norm_sq
+        if ref.tri:
+            np.testing.assert_allclose(H, H0, rtol=1e-13, atol=1e-12)
+            np.testing.assert_allclose(h, h0, rtol=1e-12, atol=1e-12)
+    perms = np.array([rng.permutation(p) for _ in range(6)])
+    want = ref.run_batch(perms, True, want_lifts=True, accumulate=False)
+    for eng in engs:
+        got = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-11)
+        eng.close()
+    ref.close()
+    with pytest.raises(Exception):
+        e3 = HipEngine(0)
+        try:   # fewer than p test rows cannot be sharded
+            e3._check(e3._lib.lsspa_reduce_partial(e3._h, keep[0][0].ctypes.data, p, keep[0][1].ctypes.data, 10,
+                                                   keep[0][2].ctypes.data, p, keep[0][3].ctypes.data, 3, p - 1, p,
+                                                   0, 0))
+        finally:
+            e3.close()
