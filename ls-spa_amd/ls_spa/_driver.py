@@ -21,6 +21,8 @@ README-dialect keywords (README.md:96-106) are accepted on top: ``method``,
 """
 from __future__ import annotations
 
+import json
+import os
 import warnings
 
 import numpy as np
@@ -70,10 +72,46 @@ def _min_norm_theta(G, g):
     return Q @ coef
 
 
+_CKPT_VERSION = 1
+
+
+def _ckpt_path(path, comm):
+    return path if comm.world == 1 else f"{path}.rank{comm.rank}"
+
+
+def _save_checkpoint(path, comm, state):
+    """Atomic write (temp file + rename) of the estimator state; one file per rank."""
+    target = _ckpt_path(path, comm)
+    tmp = target + ".tmp.npz"
+    np.savez(tmp, **state)
+    os.replace(tmp, target)
+
+
+def _load_checkpoint(path, comm, expect):
+    target = _ckpt_path(path, comm)
+    if not os.path.exists(target):
+        return None
+    with np.load(target, allow_pickle=False) as z:
+        st = {k: z[k] for k in z.files}
+    if int(st["version"]) != _CKPT_VERSION:
+        raise ValueError(f"checkpoint {target}: unsupported version {int(st['version'])}")
+    for key, want in expect.items():
+        have = st[key].item() if st[key].shape == () else st[key]
+        if str(have) != str(want):
+            raise ValueError(f"checkpoint {target} was written with {key}={have}, this run has {key}={want}")
+    return st
+
+
 def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms, antithetical,
-                  return_attribution_history, method, error_estimator, comm=None, chunk_cap=None):
+                  return_attribution_history, method, error_estimator, comm=None, chunk_cap=None,
+                  checkpoint=None):
     """The sampling loop on an engine whose problem is already loaded.  Returns
-    (attribution, attribution_errors, overall_error, error_history, attribution_history, n)."""
+    (attribution, attribution_errors, overall_error, error_history, attribution_history, n).
+
+    checkpoint: path of a state file.  Written after every error check (sample count, running mean and
+    covariance, generator state, error history, the lift history the thin-form estimators need); if it
+    exists when the call starts, the run continues from it -- the orderings, the estimator's draws and
+    therefore every later number are those of the uninterrupted run."""
     comm = comm or _Comm()
     rng = np.random.default_rng(seed)
     never_stop = False
@@ -116,6 +154,39 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
     i, pending, stop = 0, False, False
     mean = np.zeros(p)
     cov = None
+
+    ident = {"p": p, "seed": seed, "method": str(method), "batch_size": batch_size,
+             "antithetical": bool(antithetical), "error_estimator": error_estimator, "world": comm.world}
+    if checkpoint is not None:
+        if return_attribution_history:
+            raise ValueError("checkpoint= cannot be combined with return_attribution_history")
+        st = _load_checkpoint(checkpoint, comm, ident)
+        if st is not None:
+            i = int(st["n"])
+            mean = st["mean"]
+            engine.set_stats(i, mean, st["cov_biased"])
+            rng.bit_generator.state = json.loads(str(st["rng_state"]))
+            source.skip(i)
+            err_hist = [float(v) for v in st["error_history"]]
+            feat_err, total_err = st["feature_errors"], float(st["overall_error"])
+            if error_estimator == "lowrank":
+                lift_parts.append(st["lifts"])
+            elif on_device:
+                engine.history_append(st["lifts"])
+                local_idx.append(st["local_idx"])
+            if (i >= max_samples or (estimate and err_hist and total_err < tolerance and not never_stop)):
+                stop = True   # the saved run had already finished
+
+    def save_now(n):
+        state = dict(ident, version=_CKPT_VERSION, n=n, rng_state=json.dumps(rng.bit_generator.state),
+                     error_history=np.array(err_hist), feature_errors=feat_err, overall_error=total_err)
+        _, state["mean"], state["cov_biased"] = engine.stats(want_cov=True)
+        if error_estimator == "lowrank":
+            state["lifts"] = np.concatenate(lift_parts) if lift_parts else np.zeros((0, p))
+        elif on_device:
+            state["lifts"] = engine.history()
+            state["local_idx"] = np.concatenate(local_idx) if local_idx else np.zeros(0, dtype=np.int64)
+        _save_checkpoint(checkpoint, comm, state)
 
     def estimate_now(n):
         nonlocal feat_err, total_err
@@ -176,6 +247,8 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
             _, mean, _ = engine.stats(want_cov=False)
             estimate_now(i)
             pending = False
+            if checkpoint is not None:
+                save_now(i)
             if total_err < tolerance and not never_stop:
                 break
         if i >= max_samples:
@@ -193,7 +266,7 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
 def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_size=2 ** 8,
            tolerance=1e-2, seed=42, perms=None, antithetical=True, return_attribution_history=False, *,
            method=None, num_batches=None, return_history=None, device=0, error_estimator="reference",
-           precision="float64", row_sharded=False, _engine=None, _comm=None):
+           precision="float64", row_sharded=False, checkpoint=None, _engine=None, _comm=None):
     """Estimates the Shapley attribution of the out-of-sample R^2 of a least-squares fit.
 
     Positional parameters, defaults and behaviour follow cvxgrp/ls-spa
@@ -210,6 +283,8 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
     precision:  'float64' (default, the reference's arithmetic) or 'float32' for the per-ordering
         factorisation work (about half the time; lifts agree to ~1e-5 on well-conditioned data;
         the Gram reduction, lift accumulation and statistics stay float64).
+    checkpoint:  path of a state file, written after every error check and resumed from if it exists
+        (same data, seed and sampler required); with several ranks every rank keeps ``<path>.rank<r>``.
     row_sharded:  several ranks only (``_comm``).  False: every rank passes the whole data set.
         True: the four arrays are this rank's ROWS of the training and test sets; the ranks reduce
         their rows and sum the Gram matrices with one all-reduce.  'train': only the training rows are
@@ -244,7 +319,7 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         attribution, feat_err, total_err, err_hist, history, _ = run_estimator(
             engine, p, max_samples=max_samples, batch_size=batch_size, tolerance=tolerance, seed=seed,
             perms=perms, antithetical=antithetical, return_attribution_history=return_attribution_history,
-            method=method, error_estimator=error_estimator, comm=_comm)
+            method=method, error_estimator=error_estimator, comm=_comm, checkpoint=checkpoint)
         theta, r_squared, info = engine.full_fit()
         if info or engine.info():
             warnings.warn("a permuted Gram matrix was not numerically positive definite; the attribution "

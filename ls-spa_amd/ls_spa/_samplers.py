@@ -31,6 +31,15 @@ class OrderingSource:
     def take(self, count):  # pragma: no cover - interface
         raise NotImplementedError
 
+    def skip(self, count):
+        """Advance past ``count`` orderings already consumed before a checkpoint.  Default: draw and
+        discard (exact for every deterministic source); subclasses do better where they can."""
+        while count > 0:
+            got = len(self.take(min(count, 4096)))
+            if got == 0:
+                break
+            count -= got
+
 
 class IterableSource(OrderingSource):
     """Any iterable of length-p index sequences (generator, list, ndarray rows, an object
@@ -64,6 +73,10 @@ class RandomSource(OrderingSource):
             return np.empty((0, self._p), dtype=np.int64)
         return np.stack([self._rng.permutation(self._p) for _ in range(n)])
 
+    def skip(self, count):
+        # the orderings came out of the shared generator, whose state the checkpoint restores
+        self._left -= int(min(count, self._left))
+
 
 class ArgsortSource(OrderingSource):
     def __init__(self, p, seed, limit):
@@ -81,6 +94,15 @@ class ArgsortSource(OrderingSource):
         if n <= 0:
             return np.empty((0, self._p), dtype=np.int64)
         return np.argsort(self._points(n), axis=1)
+
+    def skip(self, count):
+        n = int(min(count, self._left))
+        self._left -= n
+        if n > 0:
+            self._fast_forward(n)
+
+    def _fast_forward(self, n):
+        self._qmc.fast_forward(n)
 
 
 class PermutohedronSource(ArgsortSource):
@@ -100,6 +122,13 @@ class PermutohedronSource(ArgsortSource):
         pts = self._points(n)
         pts = pts / np.linalg.norm(pts, axis=1, keepdims=True)
         return np.argsort(pts @ self._basis, axis=1)
+
+    def _fast_forward(self, n):
+        # MultivariateNormalQMC has no fast_forward of its own: drawing n points advances the underlying
+        # Sobol stream by exactly n
+        left = n
+        while left > 0:
+            left -= len(self._points(min(left, 4096)))
 
 
 def exact_source(p):

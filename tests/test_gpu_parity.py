@@ -303,3 +303,34 @@ def test_device_error_estimator_end_to_end():
     np.testing.assert_allclose(dev.attribution_errors, low.attribution_errors, rtol=1e-9)
     np.testing.assert_allclose(dev.attribution, low.attribution, rtol=0, atol=1e-14)
     assert dev.overall_error == dev.error_history[-1]
+
+
+@pytest.mark.parametrize("estimator", ["reference", "device"])
+def test_checkpoint_resume_on_the_product_path(tmp_path, estimator):
+    """Interrupt the HIP-backed run in its third batch and resume from the state file: the result is the
+    uninterrupted run's (lsspa_stats_set / lsspa_history_append restore the device state)."""
+    from ls_spa._engine import HipEngine
+
+    class Dies(HipEngine):
+        calls = 0
+
+        def run_batch(self, *a, **k):
+            self.calls += 1
+            if self.calls == 3:
+                raise KeyboardInterrupt
+            return super().run_batch(*a, **k)
+
+    d = O.gaussian_workload(30, 400, 300, seed=4)
+    kw = dict(max_samples=160, batch_size=32, tolerance=0.0, seed=3, method="argsort", error_estimator=estimator)
+    full = ls_spa(*d, **kw)
+    ck = str(tmp_path / "run.npz")
+    eng = Dies(0)
+    with pytest.raises(KeyboardInterrupt):
+        ls_spa(*d, checkpoint=ck, _engine=eng, **kw)
+    eng.close()
+    with np.load(ck) as z:
+        assert int(z["n"]) == 64
+    res = ls_spa(*d, checkpoint=ck, **kw)
+    np.testing.assert_allclose(res.attribution, full.attribution, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(res.error_history, full.error_history, rtol=1e-8)
+    assert len(res.error_history) == len(full.error_history) == 6   # 32, 64, 96, 128, 159, 160

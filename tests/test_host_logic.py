@@ -124,6 +124,39 @@ def test_device_estimator_path_equals_lowrank(golden):
         pkg.ls_spa(*d, error_estimator="gpu", _engine=OracleEngine(), **kw)
 
 
+@pytest.mark.parametrize("method,estimator", [(None, "reference"), ("argsort", "lowrank"),
+                                              ("permutohedron", "device"), ("random", "device")])
+def test_checkpoint_resume_continues_the_same_run(golden, tmp_path, method, estimator):
+    """Kill the run in its fourth batch, resume: orderings, estimator draws and every number equal the
+    uninterrupted run (generator state, QMC position, running moments and lift history restored)."""
+    class Dies(OracleEngine):
+        def run_batch(self, *a, **k):
+            if len(self.calls) == 3:
+                raise KeyboardInterrupt
+            return super().run_batch(*a, **k)
+
+    g = golden("p12")
+    d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+    kw = dict(batch_size=16, tolerance=0.0, seed=11, method=method, error_estimator=estimator)
+    full = pkg.ls_spa(*d, max_samples=112, _engine=OracleEngine(), **kw)
+    ck = str(tmp_path / "state.npz")
+    with pytest.raises(KeyboardInterrupt):
+        pkg.ls_spa(*d, max_samples=112, checkpoint=ck, _engine=Dies(), **kw)
+    with np.load(ck) as z:
+        assert int(z["n"]) == 48 and len(z["error_history"]) == 3
+    second = pkg.ls_spa(*d, max_samples=112, checkpoint=ck, _engine=OracleEngine(), **kw)
+    np.testing.assert_allclose(second.attribution, full.attribution, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(second.error_history, full.error_history, rtol=1e-9)
+    np.testing.assert_allclose(second.attribution_errors, full.attribution_errors, rtol=1e-9)
+    # a finished run resumes to itself without sampling again
+    eng = OracleEngine()
+    third = pkg.ls_spa(*d, max_samples=112, checkpoint=ck, _engine=eng, **kw)
+    assert eng.calls == []
+    np.testing.assert_allclose(third.attribution, full.attribution, rtol=0, atol=1e-14)
+    with pytest.raises(ValueError, match="seed"):
+        pkg.ls_spa(*d, max_samples=112, checkpoint=ck, _engine=OracleEngine(), **dict(kw, seed=12))
+
+
 def test_samplers_match_fixtures(golden):
     g = golden("samplers_p12")
     np.testing.assert_allclose(S.helmert_rows(12), g["U"], atol=1e-15)
