@@ -126,8 +126,10 @@ struct ElimScratch {
 template <typename T>
 __device__ __forceinline__ void eliminate_block64(T* __restrict__ M, int p_pad, int r0, T* __restrict__ Dg,
                                                   const double* __restrict__ diag0, double piv_tol,
-                                                  int32_t* __restrict__ info, ElimScratch<T>* sc, int tid) {
-  const int ty = tid >> 4, tx = tid & 15;
+                                                  int32_t* __restrict__ info, ElimScratch<T>* sc, int tid,
+                                                  const bool active = true) {
+  // workgroups larger than 256 threads: the extra threads only keep the barriers company
+  const int ty = active ? tid >> 4 : 0, tx = active ? tid & 15 : 0;
   T Tm[4][4], Y[4][4];
   if (tid == 0) sc->bad = 0;
 #pragma unroll
@@ -135,7 +137,7 @@ __device__ __forceinline__ void eliminate_block64(T* __restrict__ M, int p_pad, 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int row = ty + 16 * a, col = tx + 16 * c;
-      Tm[a][c] = (col <= row) ? M[cm_off(p_pad, r0 + row, r0 + col)] : (T)0;
+      Tm[a][c] = (col <= row && active) ? M[cm_off(p_pad, r0 + row, r0 + col)] : (T)0;
       Y[a][c] = (row == col) ? (T)1 : (T)0;
     }
 
@@ -145,11 +147,11 @@ __device__ __forceinline__ void eliminate_block64(T* __restrict__ M, int p_pad, 
     for (int kk = 0; kk < 16; ++kk) {
       const int k = 16 * kc + kk;
       const int buf = k & 1;
-      if (tx == kk) {
+      if (tx == kk && active) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) sc->col[buf][ty + 16 * a] = Tm[a][kc];
       }
-      if (ty == kk) {
+      if (ty == kk && active) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) sc->row[buf][tx + 16 * c] = Y[kc][c];
         if (tx == kk) sc->piv[buf] = Tm[kc][kc];
@@ -203,8 +205,10 @@ __device__ __forceinline__ void eliminate_block64(T* __restrict__ M, int p_pad, 
       if (col < row) lv = Tm[a][c] * sc->dd[col];
       if (col == row) lv = (T)1 / sc->dd[col];
       if (col <= row) xv = Y[a][c] * sc->dd[row];
-      M[cm_off(p_pad, r0 + row, r0 + col)] = lv;
-      Dg[row * 64 + col] = xv;
+      if (active) {
+        M[cm_off(p_pad, r0 + row, r0 + col)] = lv;
+        Dg[row * 64 + col] = xv;
+      }
     }
   if (tid == 0 && sc->bad) atomicOr(&info[0], 1);
 }
@@ -588,15 +592,634 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
   }
 }
 
+// copy the 64 x 64 block at (r0, c0) of a chunk-major matrix into LDS with stride DI_LD, 256 threads;
+// neg != 0 stores the negated block
+template <typename T, int NT = 256>
+__device__ __forceinline__ void load_block64_cm(T* lds, const T* __restrict__ A, int p_pad, int r0, int c0,
+                                                int tid, bool neg) {
+  typedef typename Tr<T>::vec_t vec_t;
+  constexpr int VE = Tr<T>::VE, VPR = 64 / VE, NV = 4096 / VE;
+#pragma unroll
+  for (int q = 0; q < NV / NT; ++q) {
+    const int idx = tid + NT * q;
+    const int row = idx / VPR, cv = idx % VPR;
+    vec_t v = *reinterpret_cast<const vec_t*>(A + cm_off(p_pad, r0 + row, c0 + VE * cv));
+    if (neg) v = -v;
+    Tr<T>::lds_store(lds + row * DI_LD + VE * cv, v);
+  }
+}
+
+// =====================================================================================
+// Two-level factorisation: panels of TWO block columns (128 wide).
+//   chol_panel2, step Jo : for a 128-row tile I below the panel, one k-loop over the columns left of
+//        the panel accumulates  C = A[I, J:J+2] - sum_{K<J} L[I,K] L[J:J+2,K]^T  for both block
+//        columns at once (16 flop per operand byte instead of 10.7), then, on the accumulators,
+//            X1 = C1 L11^-T ;  C2 -= X1 L21^T ;  X2 = C2 L22^-T
+//        (transposed, as in the one-level kernel: the accumulators are the B operand), then the
+//        symmetric update of the tile's own 128 x 128 diagonal block while L[I, J:J+2] passes
+//        through LDS for its store.  Tile 0 -- the next panel's diagonal block -- then factors it.
+//   factor_diag128 : L11, L11^-1 by the carried-identity elimination; L21 = A21 L11^-T and
+//        A22 -= L21 L21^T on the matrix pipe; L22, L22^-1 by the elimination again.
+// Half as many dependent launches as the one-level scheme, two thirds of its operand traffic.
+// =====================================================================================
+// lower tiles (ti >= tj) of the 8 x 8 grid of 16 x 16 tiles of a 128 x 128 block; wave w owns 9 of them
+__constant__ unsigned char kSyrkTi[36] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5,
+                                          5, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7, 7};
+__constant__ unsigned char kSyrkTj[36] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2,
+                                          3, 4, 5, 0, 1, 2, 3, 4, 5, 6, 0, 1, 2, 3, 4, 5, 6, 7};
+
+// acc[4 h + xp][y] <- sign * sum_{x <= xp} D[xp][x] acc[4 h + x][y]  (D lower triangular, 64 x 64 in LDS),
+// one column tile y at a time so that only four extra tiles are live
+template <typename T>
+__device__ __forceinline__ void tri_mult_inplace(typename Tr<T>::acc_t (&acc)[8][2], const int half,
+                                                 const T* s_d, const T sign, const int l15, const int l4) {
+  typedef typename Tr<T>::acc_t acc_t;
+#pragma unroll
+  for (int y = 0; y < 2; ++y) {
+    acc_t t[4];
+#pragma unroll
+    for (int xp = 0; xp < 4; ++xp) t[xp] = Tr<T>::zero();
+#pragma unroll
+    for (int xp = 0; xp < 4; ++xp) {
+#pragma unroll
+      for (int x = 0; x <= xp; ++x)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const T av = sign * s_d[(16 * xp + l15) * DI_LD + 16 * x + Tr<T>::acc_row(l4, r)];
+          t[xp] = Tr<T>::mfma(av, acc[4 * half + x][y][r], t[xp]);
+        }
+      __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every LDS read to the top
+    }
+#pragma unroll
+    for (int xp = 0; xp < 4; ++xp) acc[4 * half + xp][y] = t[xp];
+  }
+}
+
+// acc[4 + xp][y] += sum_x S[xp][x] acc[x][y]   (S a full 64 x 64 block in LDS)
+template <typename T>
+__device__ __forceinline__ void full_mult_lower_half(typename Tr<T>::acc_t (&acc)[8][2], const T* s_d,
+                                                     const int l15, const int l4) {
+#pragma unroll
+  for (int xp = 0; xp < 4; ++xp) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const T av = s_d[(16 * xp + l15) * DI_LD + 16 * x + Tr<T>::acc_row(l4, r)];
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[4 + xp][y] = Tr<T>::mfma(av, acc[x][y][r], acc[4 + xp][y]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Factor the 128 x 128 diagonal block at (r0, r0) in place; inverses of its two 64 x 64 diagonal
+// factors to Dg[0..4095] and Dg[4096..8191].  NT threads (the first 256 work); s_a: >= 64 * DI_LD
+// elements of LDS.
+template <typename T, int NT = 256>
+__device__ __forceinline__ void factor_diag128(T* __restrict__ M, int p_pad, int r0, T* __restrict__ Dg,
+                                               const double* __restrict__ diag0, double piv_tol,
+                                               int32_t* __restrict__ info, T* s_a, int tid) {
+  typedef typename Tr<T>::acc_t acc_t;
+  const int lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const bool active = tid < 256;
+  eliminate_block64<T>(M, p_pad, r0, Dg, diag0, piv_tol, info, reinterpret_cast<ElimScratch<T>*>(s_a), tid,
+                       active);
+  __threadfence_block();
+  __syncthreads();
+  // L21^T = L11^-1 A21^T : wave w < 4 owns rows i = 16 w + l15 of A21; the tile loaded as
+  // (k = 16 x + acc_row, i) is the B operand
+  load_block64<T, NT>(s_a, Dg, tid);
+  acc_t c[4], o[4];
+  if (active) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        c[x][r] = M[cm_off(p_pad, r0 + NB + 16 * w + l15, r0 + 16 * x + Tr<T>::acc_row(l4, r))];
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int xp = 0; xp < 4; ++xp) {
+      o[xp] = Tr<T>::zero();
+#pragma unroll
+      for (int x = 0; x <= xp; ++x)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          o[xp] = Tr<T>::mfma(s_a[(16 * xp + l15) * DI_LD + 16 * x + Tr<T>::acc_row(l4, r)], c[x][r], o[xp]);
+    }
+  }
+  __syncthreads();   // L11^-1 has been read by everyone; the region now takes L21 in operand layout
+  if (active) {
+#pragma unroll
+    for (int xp = 0; xp < 4; ++xp)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_a[(16 * w + l15) * DI_LD + 16 * xp + Tr<T>::acc_row(l4, r)] = o[xp][r];
+  }
+  __syncthreads();
+  // store L21 (contiguous 16-column row pieces in the chunk-major layout)
+  {
+    constexpr int VE = Tr<T>::VE, VPR = 64 / VE, NV = 4096 / VE;
+#pragma unroll
+    for (int q = 0; q < NV / NT; ++q) {
+      const int idx = tid + NT * q;
+      const int row = idx / VPR, cv = idx % VPR;
+      *reinterpret_cast<typename Tr<T>::vec_t*>(M + cm_off(p_pad, r0 + NB + row, r0 + VE * cv)) =
+          Tr<T>::lds_load(s_a + row * DI_LD + VE * cv);
+    }
+  }
+  // A22 -= L21 L21^T, lower 16 x 16 tiles of the 4 x 4 grid: 10 tiles over the NT / 64 waves
+#pragma unroll
+  for (int q = 0; q < (10 + NT / 64 - 1) / (NT / 64); ++q) {
+    const int t = w + (NT / 64) * q;
+    if (t >= 10) break;
+    const int ti = kSyrkTi[t], tj = kSyrkTj[t];
+    acc_t u = Tr<T>::zero();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+      u = Tr<T>::mfma(s_a[(16 * ti + l15) * DI_LD + 4 * kk + l4], s_a[(16 * tj + l15) * DI_LD + 4 * kk + l4], u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * ti + Tr<T>::acc_row(l4, r), col = 16 * tj + l15;
+      if (col <= row) M[cm_off(p_pad, r0 + NB + row, r0 + NB + col)] -= u[r];
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  eliminate_block64<T>(M, p_pad, r0 + NB, Dg + 4096, diag0, piv_tol, info,
+                       reinterpret_cast<ElimScratch<T>*>(s_a), tid, active);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void chol_diag2_kernel(T* __restrict__ A, T* __restrict__ Dinv,
+                                                            const double* __restrict__ diag0, double piv_tol,
+                                                            int32_t* __restrict__ info, int p_pad, int Jo,
+                                                            int nblk) {
+  __shared__ __attribute__((aligned(16))) T s_a[64 * DI_LD];
+  static_assert(sizeof(ElimScratch<T>) <= sizeof(T) * 64 * DI_LD, "elimination scratch must fit");
+  const int mt = blockIdx.x;
+  T* M = A + (int64_t)mt * p_pad * p_pad;
+  factor_diag128<T>(M, p_pad, Jo * 128, Dinv + ((int64_t)mt * nblk + 2 * Jo) * 4096,
+                    diag0 + (int64_t)mt * p_pad, piv_tol, info, s_a, threadIdx.x);
+}
+
+// Workgroup of NT threads (NT / 64 waves): wave w owns tile rows RW w .. RW w + RW - 1 (RW = 128 / waves)
+// for all 128 panel columns, i.e. 8 x YT accumulator tiles.
+template <typename T, int NT>
+__global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict__ A, T* __restrict__ Dinv,
+                                                                 const double* __restrict__ diag0,
+                                                                 double piv_tol, int32_t* __restrict__ info,
+                                                                 int p_pad, int Jo, int nblk) {
+  typedef typename Tr<T>::acc_t acc_t;
+  typedef typename Tr<T>::vec_t vec_t;
+  constexpr int VE = Tr<T>::VE;
+  constexpr int NW = NT / 64;          // waves
+  constexpr int RW = 128 / NW;         // tile rows per wave: 32 / 16
+  constexpr int YT = RW / 16;          // 16-row accumulator tiles per wave and panel column block: 2 / 1
+  constexpr int NU = (36 + NW - 1) / NW;   // diagonal-update tiles per wave: 9 / 5
+  // Region A: the two 128 x 16 operand tiles of the main loop; afterwards the 64 x 64 blocks of the
+  // two-level solve and the elimination scratch.  Region B: output staging tile.
+  __shared__ __attribute__((aligned(16))) T s_a[2 * 128 * RK_LD];
+  __shared__ __attribute__((aligned(16))) T s_b[128 * RK_LD];
+  static_assert(2 * 128 * RK_LD >= 64 * DI_LD, "a 64 x 64 block must fit region A");
+  static_assert(sizeof(ElimScratch<T>) <= sizeof(T) * 64 * DI_LD, "elimination scratch must fit region A");
+  T* const s_rkj = s_a;
+  T* const s_rki = s_a + 128 * RK_LD;
+  T* const s_dinv = s_a;
+  T* const s_out = s_b;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int mt = blockIdx.x;     // matrix: fastest in dispatch order, so the tile-0 workgroups start first
+  const int tile = blockIdx.y;
+  T* M = A + (int64_t)mt * p_pad * p_pad;
+  const int J0 = Jo * 128;
+  const int I0 = J0 + 128 + tile * 128;
+
+  const T* srcJ = M + cm_off(p_pad, J0, 0);
+  const T* srcI = M + cm_off(p_pad, I0, 0);
+  const int64_t chunk = (int64_t)p_pad * 16;
+  const int nch = J0 / KCH;
+  RKRegs<T, 128, NT> rj = {}, ri = {};
+  if (nch > 0) {
+    rk_load<T, 128, NT>(rj, srcJ, CM_LD, tid, 128);
+    rk_load<T, 128, NT>(ri, srcI, CM_LD, tid, 128);
+  }
+
+  // acc[x][y][r] <-> (panel column j = 16 x + acc_row(l4, r), tile row i = RW w + 16 y + l15); holds -C^T.
+  // Each wave stages its own rows through its slice of the output buffer (coalesced reads, no
+  // workgroup barrier).
+  acc_t acc[8][YT];
+  {
+    constexpr int VPR = 16 / VE;        // 16-byte vectors per 16-column row piece
+    constexpr int RPI = 64 / VPR;       // rows per wave instruction: 8 (fp64) / 16 (fp32)
+    constexpr int NQ = RW / RPI;        // passes over the wave's rows
+    const int rr = lane / VPR, ch = lane % VPR;
+#pragma unroll
+    for (int xh = 0; xh < 4; ++xh) {
+      vec_t t[2][NQ];
+#pragma unroll
+      for (int xx = 0; xx < 2; ++xx)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          t[xx][q] = *reinterpret_cast<const vec_t*>(
+              M + cm_off(p_pad, I0 + RW * w + rr + RPI * q, J0 + 16 * (2 * xh + xx) + VE * ch));
+#pragma unroll
+      for (int xx = 0; xx < 2; ++xx) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          Tr<T>::lds_store(s_out + (RW * w + rr + RPI * q) * RK_LD + VE * ch, t[xx][q]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int y = 0; y < YT; ++y)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[2 * xh + xx][y][r] = -s_out[(RW * w + 16 * y + l15) * RK_LD + Tr<T>::acc_row(l4, r)];
+        __builtin_amdgcn_wave_barrier();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  for (int c = 0; c < nch; ++c) {
+    __syncthreads();
+    rk_store<T, 128, NT>(rj, s_rkj, tid);
+    rk_store<T, 128, NT>(ri, s_rki, tid);
+    __syncthreads();
+    if (c + 1 < nch) {
+      rk_load<T, 128, NT>(rj, srcJ + (c + 1) * chunk, CM_LD, tid, 128);
+      rk_load<T, 128, NT>(ri, srcI + (c + 1) * chunk, CM_LD, tid, 128);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      T av[8], bv[YT];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) av[x] = s_rkj[(16 * x + l15) * RK_LD + 4 * kk + l4];
+#pragma unroll
+      for (int y = 0; y < YT; ++y) bv[y] = s_rki[(RW * w + 16 * y + l15) * RK_LD + 4 * kk + l4];
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int y = 0; y < YT; ++y) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
+    }
+  }
+
+  // two-level solve on the accumulators (they hold -C^T):
+  //   X1^T = L11^-1 C1^T ;  -C2^T += L21 X1^T ;  X2^T = L22^-1 C2^T
+  // acc[4 h + xp][y] <- -sum_{x <= xp} D[xp][x] acc[4 h + x][y], one column tile at a time (in place)
+  auto tri_mult = [&](const int half) {
+#pragma unroll
+    for (int y = 0; y < YT; ++y) {
+      acc_t t[4];
+#pragma unroll
+      for (int xp = 0; xp < 4; ++xp) t[xp] = Tr<T>::zero();
+#pragma unroll
+      for (int xp = 0; xp < 4; ++xp) {
+#pragma unroll
+        for (int x = 0; x <= xp; ++x)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const T av = -s_dinv[(16 * xp + l15) * DI_LD + 16 * x + Tr<T>::acc_row(l4, r)];
+            t[xp] = Tr<T>::mfma(av, acc[4 * half + x][y][r], t[xp]);
+          }
+        __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every LDS read to the top
+      }
+#pragma unroll
+      for (int xp = 0; xp < 4; ++xp) acc[4 * half + xp][y] = t[xp];
+    }
+  };
+  const T* Dg = Dinv + ((int64_t)mt * nblk + 2 * Jo) * 4096;
+  __syncthreads();  // every wave is done with the operand tiles that region A now loses
+  load_block64<T, NT>(s_dinv, Dg, tid);
+  __syncthreads();
+  tri_mult(0);
+  __syncthreads();
+  load_block64_cm<T, NT>(s_dinv, M, p_pad, J0 + NB, J0, tid, false);
+  __syncthreads();
+#pragma unroll
+  for (int xp = 0; xp < 4; ++xp) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const T av = s_dinv[(16 * xp + l15) * DI_LD + 16 * x + Tr<T>::acc_row(l4, r)];
+#pragma unroll
+        for (int y = 0; y < YT; ++y) acc[4 + xp][y] = Tr<T>::mfma(av, acc[x][y][r], acc[4 + xp][y]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  load_block64<T, NT>(s_dinv, Dg + 4096, tid);
+  __syncthreads();
+  tri_mult(1);
+
+  // Store L[I, panel] through the output buffer, one 16-column chunk at a time (a contiguous 128 x 16
+  // block in the chunk-major layout).
+  typedef RKRegs<T, 128, NT> RR;
+  const int sc = tid % RR::VPR, srow = tid / RR::VPR;
+#pragma unroll
+  for (int xp = 0; xp < 8; ++xp) {
+    if (xp > 0) __syncthreads();
+#pragma unroll
+    for (int y = 0; y < YT; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        s_out[(RW * w + 16 * y + l15) * RK_LD + Tr<T>::acc_row(l4, r)] = acc[xp][y][r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RR::NP; ++q) {
+      const int rr = srow + RR::RPP * q;
+      *reinterpret_cast<vec_t*>(M + cm_off(p_pad, I0 + rr, J0 + 16 * xp + VE * sc)) =
+          Tr<T>::lds_load(s_out + rr * RK_LD + VE * sc);
+    }
+  }
+
+  // A[I,I] -= L[I,panel] L[I,panel]^T on the tile's own diagonal block (this workgroup alone owns it):
+  // 36 lower 16 x 16 tiles over the waves.  The accumulators of the solve are dead by now, so the eight
+  // chunks just written are staged once more (they come back from L2) instead of keeping both sets of
+  // accumulators alive through the store loop.
+  __threadfence_block();
+  acc_t upd[NU];
+  int ti[NU], tj[NU];
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+#pragma unroll
+  for (int q = 0; q < NU; ++q) {
+    const int t = ws + NW * q;
+    ti[q] = t < 36 ? kSyrkTi[t] : 0;
+    tj[q] = t < 36 ? kSyrkTj[t] : 0;
+    upd[q] = Tr<T>::zero();
+  }
+  {
+    const T* srcP = M + cm_off(p_pad, I0, J0);
+    RKRegs<T, 128, NT> rp = {};
+    __syncthreads();   // all stores above are issued and fenced
+    rk_load<T, 128, NT>(rp, srcP, CM_LD, tid, 128);
+    for (int c = 0; c < 8; ++c) {
+      __syncthreads();
+      rk_store<T, 128, NT>(rp, s_out, tid);
+      __syncthreads();
+      if (c + 1 < 8) rk_load<T, 128, NT>(rp, srcP + (c + 1) * chunk, CM_LD, tid, 128);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int q = 0; q < NU; ++q) {
+          if (ws + NW * q >= 36) continue;   // wave-uniform
+          const T av = s_out[(16 * ti[q] + l15) * RK_LD + 4 * kk + l4];
+          const T bv = s_out[(16 * tj[q] + l15) * RK_LD + 4 * kk + l4];
+          upd[q] = Tr<T>::mfma(av, bv, upd[q]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NU; ++q) {
+    if (ws + NW * q >= 36) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * ti[q] + Tr<T>::acc_row(l4, r), col = 16 * tj[q] + l15;
+      if (col <= row) M[cm_off(p_pad, I0 + row, I0 + col)] -= upd[q][r];
+    }
+  }
+
+  // Tile 0 is the next panel's diagonal block and has just received its last update: factor it here,
+  // the latency-bound sweep overlaps with the other workgroups' MFMA work.
+  if (tile == 0) {
+    __threadfence_block();
+    __syncthreads();
+    factor_diag128<T, NT>(M, p_pad, I0, Dinv + ((int64_t)mt * nblk + 2 * (Jo + 1)) * 4096,
+                          diag0 + (int64_t)mt * p_pad, piv_tol, info, s_a, tid);
+  }
+}
+
+// whole factorisation of n_mats matrices: one diagonal launch + (p_pad / 128 - 1) panel launches
+hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
+                             int n_mats, int f32, hipStream_t st) {
+  if (p_pad % 128 != 0 || n_mats < 1) return hipErrorInvalidValue;
+  const int nblk = p_pad / NB;
+  if (f32)
+    hipLaunchKernelGGL(chol_diag2_kernel<float>, dim3(n_mats), dim3(256), 0, st, (float*)A, (float*)Dinv, diag0,
+                       piv_tol, info, p_pad, 0, nblk);
+  else
+    hipLaunchKernelGGL(chol_diag2_kernel<double>, dim3(n_mats), dim3(256), 0, st, (double*)A, (double*)Dinv,
+                       diag0, piv_tol, info, p_pad, 0, nblk);
+  return hipGetLastError();
+}
+
+hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
+                              int Jo, int n_mats, int f32, hipStream_t st) {
+  if (p_pad % 128 != 0 || Jo < 0 || Jo >= p_pad / 128 - 1 || n_mats < 1) return hipErrorInvalidValue;
+  const int nblk = p_pad / NB;
+  dim3 grid(n_mats, p_pad / 128 - 1 - Jo);
+  // 256 threads: 512-thread workgroups (16 rows per wave, twice the waves per SIMD) were measured
+  // slower in both precisions -- the epilogue is bound by its memory traffic, not by latency
+  if (f32)
+    hipLaunchKernelGGL((chol_panel2_kernel<float, 256>), grid, dim3(256), 0, st, (float*)A, (float*)Dinv, diag0,
+                       piv_tol, info, p_pad, Jo, nblk);
+  else
+    hipLaunchKernelGGL((chol_panel2_kernel<double, 256>), grid, dim3(256), 0, st, (double*)A, (double*)Dinv,
+                       diag0, piv_tol, info, p_pad, Jo, nblk);
+  return hipGetLastError();
+}
+
+// =====================================================================================
+// strip2: the same solve  V = L^-1 RHS  by 128-column strips, advancing 128 ROWS per step.
+// The k-loop of a step covers both 64-row halves with one pass over the V rows above them, which
+// halves the re-reads of V (the larger share of the kernel's traffic: 16 flop per operand byte
+// instead of 10.7).  The step ends with a two-level triangular solve on the accumulators:
+//     X1 = Dinv_i C1 ;  C2 -= L[i+1][i] X1 ;  X2 = Dinv_{i+1} C2
+// in which X1, still in registers, is the B operand of the middle product.
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256, 2) void strip2_kernel(StripArgs a) {
+  typedef typename Tr<T>::acc_t acc_t;
+  typedef typename Tr<T>::vec_t vec_t;
+  constexpr int VE = Tr<T>::VE;
+  __shared__ __attribute__((aligned(16))) T s_rk[128 * RK_LD];
+  __shared__ __attribute__((aligned(16))) T s_kc[16 * KC_LD];
+  __shared__ __attribute__((aligned(16))) T s_dinv[64 * DI_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int ord = blockIdx.x;
+  const int c0 = blockIdx.y * 128;
+  const int p = a.p, p_pad = a.p_pad, m_pad = a.m_pad;
+  const int nblk = p_pad / NB;
+  const int n_iblk = (p + NB - 1) / NB;
+  const int64_t ldv = ldv_of(m_pad);
+  const int64_t chunk = (int64_t)p_pad * 16;
+  const T* L = static_cast<const T*>(a.A) + (int64_t)ord * p_pad * p_pad;   // chunk-major
+  const T* Lt = a.tri ? static_cast<const T*>(a.rhs) + (int64_t)ord * p_pad * p_pad : nullptr;
+  const int32_t* perm = a.tri ? nullptr : a.perms + (int64_t)ord * p;
+  T* V = static_cast<T*>(a.V) + (int64_t)ord * v_rows_of(p) * ldv;
+  const T* Dv = static_cast<const T*>(a.Dinv) + (int64_t)ord * nblk * 4096;
+
+  const int ib0 = a.tri ? c0 / NB : 0;       // even: strips are 128 wide
+  const int kstart = a.tri ? c0 : 0;
+  if (a.tri) {
+    constexpr int VPR = 128 / VE;
+    for (int idx = tid; idx < ib0 * NB * VPR; idx += 256) {
+      const int row = idx / VPR, cv = idx % VPR;
+      *reinterpret_cast<vec_t*>(V + row * ldv + c0 + VE * cv) = Tr<T>::vzero();
+    }
+  }
+
+  for (int ib = ib0; ib < n_iblk; ib += 2) {
+    const int I0 = ib * NB;
+    const bool two = ib + 1 < n_iblk;          // the last step of an odd block count has one half
+    const int rows_valid = two ? 128 : 64;
+    acc_t acc[8][2];
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) acc[x][y] = Tr<T>::zero();
+
+    const T* srcL = L + cm_off(p_pad, I0, kstart);
+    const T* srcV = V + kstart * ldv + c0;
+    const int nch = (I0 - kstart) / KCH;
+    RKRegs<T, 128> rl = {};
+    KCRegs<T> rv = {};
+    if (nch > 0) {
+      rk_load<T, 128>(rl, srcL, CM_LD, tid, rows_valid);
+      kc_load<T>(rv, srcV, ldv, tid);
+    }
+    for (int c = 0; c < nch; ++c) {
+      __syncthreads();
+      rk_store<T, 128>(rl, s_rk, tid);
+      kc_store<T>(rv, s_kc, tid);
+      __syncthreads();
+      if (c + 1 < nch) {
+        rk_load<T, 128>(rl, srcL + (c + 1) * chunk, CM_LD, tid, rows_valid);
+        kc_load<T>(rv, srcV + (c + 1) * KCH * ldv, ldv, tid);
+      }
+      // tri: V[k][col] = 0 for col > k, so columns c0+64.. (waves 2, 3) see only zeros while k < c0+64
+      if (a.tri && w >= 2 && c < 4) continue;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        T av[8], bv[2];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) av[x] = s_rk[(16 * x + l15) * RK_LD + 4 * kk + l4];
+#pragma unroll
+        for (int y = 0; y < 2; ++y) bv[y] = s_kc[(4 * kk + l4) * KC_LD + 32 * w + 16 * y + l15];
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
+      }
+    }
+
+    __syncthreads();  // s_dinv is still being read by slower waves of the previous step
+    load_block64<T>(s_dinv, Dv + (int64_t)ib * 4096, tid);
+
+    // C = RHS[I] - acc  (direct global reads: 16 lanes cover one contiguous row segment), one half at a
+    // time so that only 32 loads are in flight
+    auto rhs_minus_acc = [&](const int half) {
+#pragma unroll
+      for (int xx = 0; xx < 4; ++xx) {
+        const int x = 4 * half + xx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = I0 + 16 * x + Tr<T>::acc_row(l4, r);
+          const int blk_end = I0 + (half + 1) * NB;    // end of the row's own diagonal block
+#pragma unroll
+          for (int y = 0; y < 2; ++y) {
+            const int c = c0 + 32 * w + 16 * y + l15;
+            T rv0 = (T)0;
+            if (a.tri) {
+              if (c < blk_end) rv0 = Lt[cm_off(p_pad, i, c)];
+            } else {
+              if (i < p) rv0 = (T)a.Ft[(int64_t)perm[i] * m_pad + c];
+            }
+            acc[x][y][r] = rv0 - acc[x][y][r];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // 8 loads in flight, not 32
+      }
+    };
+    // acc[4 h + xp][y] <- sum_{x <= xp} D[xp][x] acc[4 h + x][y], one column tile at a time (in place)
+    auto tri_solve = [&](const int half) {
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        acc_t t[4];
+#pragma unroll
+        for (int xp = 0; xp < 4; ++xp) t[xp] = Tr<T>::zero();
+#pragma unroll
+        for (int xp = 0; xp < 4; ++xp)
+#pragma unroll
+          for (int x = 0; x <= xp; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const T av = s_dinv[(16 * xp + l15) * DI_LD + 16 * x + Tr<T>::acc_row(l4, r)];
+              t[xp] = Tr<T>::mfma(av, acc[4 * half + x][y][r], t[xp]);
+            }
+        __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every LDS read to the top
+#pragma unroll
+        for (int xp = 0; xp < 4; ++xp) acc[4 * half + xp][y] = t[xp];
+      }
+    };
+    auto store_half = [&](const int half) {
+#pragma unroll
+      for (int xp = 0; xp < 4; ++xp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = I0 + half * NB + 16 * xp + Tr<T>::acc_row(l4, r);
+#pragma unroll
+          for (int y = 0; y < 2; ++y) V[i * ldv + c0 + 32 * w + 16 * y + l15] = acc[4 * half + xp][y][r];
+        }
+    };
+
+    rhs_minus_acc(0);
+    __syncthreads();
+    tri_solve(0);     // X1 = Dinv_i * C1
+    store_half(0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (two) {
+      rhs_minus_acc(1);
+      // C2 -= L[i+1][i] * X1  (X1 straight from its accumulators)
+      __syncthreads();
+      load_block64_cm<T>(s_dinv, L, p_pad, I0 + NB, I0, tid, true);
+      __syncthreads();
+#pragma unroll
+      for (int xp = 0; xp < 4; ++xp) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const T av = s_dinv[(16 * xp + l15) * DI_LD + 16 * x + Tr<T>::acc_row(l4, r)];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) acc[4 + xp][y] = Tr<T>::mfma(av, acc[x][y][r], acc[4 + xp][y]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      load_block64<T>(s_dinv, Dv + (int64_t)(ib + 1) * 4096, tid);
+      __syncthreads();
+      tri_solve(1);   // X2 = Dinv_{i+1} * C2
+      store_half(1);
+    }
+    // the next step's k-loop reads these rows back (written by other waves of this workgroup)
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
 hipError_t launch_strip(const StripArgs& a, hipStream_t st) {
   if (a.p < 1 || a.p_pad % NB != 0 || a.m_pad % 128 != 0 || a.n_ord < 1) return hipErrorInvalidValue;
   if (a.tri && a.m_pad > a.p_pad + 127) return hipErrorInvalidValue;
   if (a.tri ? (a.rhs == nullptr) : (a.perms == nullptr || a.Ft == nullptr)) return hipErrorInvalidValue;
   dim3 grid(a.n_ord, a.m_pad / 128);
-  if (a.f32)
-    hipLaunchKernelGGL(strip_kernel<float>, grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(strip_kernel<double>, grid, dim3(256), 0, st, a);
+  if (a.flags & 4) {   // A/B switch: the one-level kernel
+    if (a.f32)
+      hipLaunchKernelGGL(strip_kernel<float>, grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(strip_kernel<double>, grid, dim3(256), 0, st, a);
+  } else {
+    if (a.f32)
+      hipLaunchKernelGGL(strip2_kernel<float>, grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(strip2_kernel<double>, grid, dim3(256), 0, st, a);
+  }
   return hipGetLastError();
 }
 

@@ -30,6 +30,11 @@ hipError_t launch_gather(const GatherArgs& a, hipStream_t st);
 // also factor diagonal block J + 1.
 hipError_t launch_chol_diag(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
                             int J, int n_mats, int f32, hipStream_t st);
+// two-level scheme (128-wide panels, p_pad a multiple of 128): one diagonal launch, then Jo = 0 .. p_pad/128 - 2
+hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
+                             int n_mats, int f32, hipStream_t st);
+hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
+                              int Jo, int n_mats, int f32, hipStream_t st);
 hipError_t launch_chol_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
                              int J, int n_mats, int flags, int f32, hipStream_t st);
 

@@ -201,7 +201,7 @@ int set_dims(lsspa_ctx* ctx, int p, int m, int tri) {
   ctx->p = p;
   ctx->m = m;
   ctx->tri = tri;
-  ctx->p_pad = round_up(p + 1, NB);
+  ctx->p_pad = round_up(p + 1, 128);   // the two-level factorisation walks 128-wide panels
   ctx->m_pad = round_up(m, 128);
   const size_t pp = (size_t)ctx->p_pad;
   TRY(dev_alloc(ctx, ctx->G, (size_t)p * pp));
@@ -360,7 +360,19 @@ int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
   const bool fused = !(ctx->flags & 2);  // panel step J also factors diagonal block J + 1
   // a pivot below ~p ulps of its feature's own variance is numerically zero (collinear feature)
   const double piv_tol = 16.0 * (double)p * (ctx->f32 ? 1.1920929e-07 : 2.220446049250313e-16);
-  for (int J = 0; J < nblk; ++J) {
+  if (!(ctx->flags & 8)) {
+    {
+      ProfScope ps(ctx, LSSPA_K_CHOL_DIAG);
+      HIPCHK(launch_chol2_diag(ctx->A.ptr, ctx->Dinv.ptr, ctx->diag0.ptr, piv_tol, ctx->info_d.ptr, p_pad, n_mats,
+                               ctx->f32, ctx->stream));
+    }
+    for (int Jo = 0; Jo + 1 < p_pad / 128; ++Jo) {
+      ProfScope ps(ctx, LSSPA_K_CHOL_PANEL);
+      HIPCHK(launch_chol2_panel(ctx->A.ptr, ctx->Dinv.ptr, ctx->diag0.ptr, piv_tol, ctx->info_d.ptr, p_pad, Jo,
+                                n_mats, ctx->f32, ctx->stream));
+    }
+  }
+  for (int J = 0; J < nblk && (ctx->flags & 8); ++J) {   // A/B switch: the one-level scheme
     if (J == 0 || !fused) {
       ProfScope ps(ctx, LSSPA_K_CHOL_DIAG);
       HIPCHK(launch_chol_diag(ctx->A.ptr, ctx->Dinv.ptr, ctx->diag0.ptr, piv_tol, ctx->info_d.ptr, p_pad, J,

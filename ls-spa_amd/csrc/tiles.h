@@ -113,19 +113,20 @@ struct Tr<float> {
   }
 };
 
-// ---- register staging of a [R rows][16 k] tile (R = 64 or 128), 256 threads --------------------
-template <typename T, int R>
+// ---- register staging of a [R rows][16 k] tile (R = 64 or 128), NT threads ---------------------
+template <typename T, int R, int NT = 256>
 struct RKRegs {
   static constexpr int VPR = 16 / Tr<T>::VE;   // 16-byte vectors per row: 8 (fp64) / 4 (fp32)
-  static constexpr int RPP = 256 / VPR;        // rows per pass of the workgroup: 32 / 64
+  static constexpr int RPP = NT / VPR;         // rows per pass of the workgroup: 32 / 64 at 256 threads
   static constexpr int NP = R / RPP;           // passes
+  static_assert(NP >= 1 && NP * RPP == R, "tile rows must be a multiple of the rows per pass");
   typename Tr<T>::vec_t v[NP];
 };
 
-template <typename T, int R>
-__device__ __forceinline__ void rk_load(RKRegs<T, R>& r, const T* __restrict__ src, int64_t ld, int tid,
+template <typename T, int R, int NT = 256>
+__device__ __forceinline__ void rk_load(RKRegs<T, R, NT>& r, const T* __restrict__ src, int64_t ld, int tid,
                                         int rows_valid) {
-  typedef RKRegs<T, R> RR;
+  typedef RKRegs<T, R, NT> RR;
   const int c = tid % RR::VPR, row = tid / RR::VPR;
 #pragma unroll
   for (int q = 0; q < RR::NP; ++q) {
@@ -137,9 +138,9 @@ __device__ __forceinline__ void rk_load(RKRegs<T, R>& r, const T* __restrict__ s
   }
 }
 
-template <typename T, int R>
-__device__ __forceinline__ void rk_store(const RKRegs<T, R>& r, T* lds, int tid) {
-  typedef RKRegs<T, R> RR;
+template <typename T, int R, int NT = 256>
+__device__ __forceinline__ void rk_store(const RKRegs<T, R, NT>& r, T* lds, int tid) {
+  typedef RKRegs<T, R, NT> RR;
   const int c = tid % RR::VPR, row = tid / RR::VPR;
 #pragma unroll
   for (int q = 0; q < RR::NP; ++q) Tr<T>::lds_store(lds + (row + RR::RPP * q) * RK_LD + Tr<T>::VE * c, r.v[q]);
@@ -171,13 +172,13 @@ __device__ __forceinline__ void kc_store(const KCRegs<T>& r, T* lds, int tid) {
   for (int q = 0; q < KR::NP; ++q) Tr<T>::lds_store(lds + (k + KR::RPP * q) * KC_LD + Tr<T>::VE * c, r.v[q]);
 }
 
-// copy a dense 64 x 64 block (row-major, ld 64) from global into LDS with stride DI_LD, 256 threads
-template <typename T>
+// copy a dense 64 x 64 block (row-major, ld 64) from global into LDS with stride DI_LD, NT threads
+template <typename T, int NT = 256>
 __device__ __forceinline__ void load_block64(T* lds, const T* __restrict__ g, int tid) {
   constexpr int VE = Tr<T>::VE, VPR = 64 / VE, NV = 4096 / VE;
 #pragma unroll
-  for (int q = 0; q < NV / 256; ++q) {
-    const int idx = tid + 256 * q;
+  for (int q = 0; q < NV / NT; ++q) {
+    const int idx = tid + NT * q;
     const int row = idx / VPR, cv = idx % VPR;
     Tr<T>::lds_store(lds + row * DI_LD + VE * cv,
                      *reinterpret_cast<const typename Tr<T>::vec_t*>(g + row * 64 + VE * cv));
