@@ -34,7 +34,7 @@ hipError_t launch_chol_diag(void* A, void* Dinv, const double* diag0, double piv
 hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
                              int n_mats, int f32, hipStream_t st);
 hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
-                              int Jo, int n_mats, int f32, hipStream_t st);
+                              int Jo, int n_mats, int f32, hipStream_t st, int flags = 0);
 hipError_t launch_chol_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
                              int J, int n_mats, int flags, int f32, hipStream_t st);
 

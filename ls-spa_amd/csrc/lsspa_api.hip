@@ -71,6 +71,9 @@ struct lsspa_ctx {
   // row-sharded reduction in progress: summed Gram buffers [2][P1pad][P1pad]
   DevBuf<double> Cred;
   bool reduce_open = false;
+  // second stream for the two-slice schedule of a batch
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int64_t hist_cap = 0, hist_n = 0;
   int ldh() const { return ((p + 127) / 128) * 128; }
   int flags = 0;
@@ -132,7 +135,7 @@ struct ProfScope {
   ProfRec rec;
   bool live;
   ProfScope(lsspa_ctx* c, int cls) : ctx(c), live(false) {
-    if (!c->prof_on) return;
+    if (!c || !c->prof_on) return;
     rec.cls = cls;
     if (hipEventCreate(&rec.beg) != hipSuccess) return;
     if (hipEventCreate(&rec.end) != hipSuccess) {
@@ -333,12 +336,23 @@ int ensure_pinned(lsspa_ctx* ctx, size_t count) {
 
 // Run gather -> factorisation -> strip -> lift for n_ord orderings already resident in perms_d.
 // lifts for sample s land in lifts_d[(s_off + s)][p].
-int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
+// Orderings [ord_off, ord_off + n_ord) of the staged batch on stream st.  Each slice owns its part of every
+// workspace buffer (a slice's matrices are laid out [source][ordering] inside its own region), so two
+// slices can run on two streams at once.
+int run_slice(lsspa_ctx* ctx, int ord_off, int n_ord, int per_sample, int s_off, hipStream_t st) {
   const int p = ctx->p, p_pad = ctx->p_pad, m_pad = ctx->m_pad, nblk = p_pad / NB;
   const int n_src = ctx->tri ? 2 : 1;
   const int n_mats = n_ord * n_src;
+  const size_t es = ctx->esz(), pp2 = (size_t)p_pad * p_pad;
+  char* const A_s = ctx->A.ptr + (size_t)ord_off * n_src * pp2 * es;
+  char* const Dinv_s = ctx->Dinv.ptr + (size_t)ord_off * n_src * nblk * 4096 * es;
+  double* const diag0_s = ctx->diag0.ptr + (size_t)ord_off * n_src * p_pad;
+  char* const V_s = ctx->V.ptr + (size_t)ord_off * (size_t)v_rows_of(p) * (size_t)ldv_of(m_pad) * es;
+  double* const Ppart_s = ctx->Ppart.ptr + (size_t)ord_off * (m_pad / 64) * p_pad;
+  const int32_t* const perms_s = ctx->perms_d.ptr + (size_t)ord_off * p;
+  const bool timed = (st == ctx->stream);   // the profiling events live on the context's stream
   {
-    ProfScope ps(ctx, LSSPA_K_GATHER);
+    ProfScope ps(timed ? ctx : nullptr, LSSPA_K_GATHER);
     GatherArgs ga;
     ga.S[0] = ctx->G.ptr;
     ga.s[0] = ctx->g.ptr;
@@ -347,71 +361,71 @@ int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
     ga.s[1] = ctx->tri ? ctx->h.ptr : nullptr;
     ga.aug[1] = 2.0 * ctx->y_norm_sq + 1.0;
     ga.ld_src = p_pad;
-    ga.perms = ctx->perms_d.ptr;
+    ga.perms = perms_s;
     ga.p = p;
     ga.p_pad = p_pad;
     ga.n_ord = n_ord;
     ga.n_src = n_src;
-    ga.A = ctx->A.ptr;
-    ga.diag0 = ctx->diag0.ptr;
+    ga.A = A_s;
+    ga.diag0 = diag0_s;
     ga.f32 = ctx->f32;
-    HIPCHK(launch_gather(ga, ctx->stream));
+    HIPCHK(launch_gather(ga, st));
   }
   const bool fused = !(ctx->flags & 2);  // panel step J also factors diagonal block J + 1
   // a pivot below ~p ulps of its feature's own variance is numerically zero (collinear feature)
   const double piv_tol = 16.0 * (double)p * (ctx->f32 ? 1.1920929e-07 : 2.220446049250313e-16);
   if (!(ctx->flags & 8)) {
     {
-      ProfScope ps(ctx, LSSPA_K_CHOL_DIAG);
-      HIPCHK(launch_chol2_diag(ctx->A.ptr, ctx->Dinv.ptr, ctx->diag0.ptr, piv_tol, ctx->info_d.ptr, p_pad, n_mats,
-                               ctx->f32, ctx->stream));
+      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_DIAG);
+      HIPCHK(launch_chol2_diag(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, n_mats,
+                               ctx->f32, st));
     }
     for (int Jo = 0; Jo + 1 < p_pad / 128; ++Jo) {
-      ProfScope ps(ctx, LSSPA_K_CHOL_PANEL);
-      HIPCHK(launch_chol2_panel(ctx->A.ptr, ctx->Dinv.ptr, ctx->diag0.ptr, piv_tol, ctx->info_d.ptr, p_pad, Jo,
-                                n_mats, ctx->f32, ctx->stream));
+      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_PANEL);
+      HIPCHK(launch_chol2_panel(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, Jo,
+                                n_mats, ctx->f32, st, ctx->flags));
     }
   }
   for (int J = 0; J < nblk && (ctx->flags & 8); ++J) {   // A/B switch: the one-level scheme
     if (J == 0 || !fused) {
-      ProfScope ps(ctx, LSSPA_K_CHOL_DIAG);
-      HIPCHK(launch_chol_diag(ctx->A.ptr, ctx->Dinv.ptr, ctx->diag0.ptr, piv_tol, ctx->info_d.ptr, p_pad, J,
-                              n_mats, ctx->f32, ctx->stream));
+      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_DIAG);
+      HIPCHK(launch_chol_diag(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, J,
+                              n_mats, ctx->f32, st));
     }
     if (J + 1 < nblk) {
-      ProfScope ps(ctx, LSSPA_K_CHOL_PANEL);
-      HIPCHK(launch_chol_panel(ctx->A.ptr, ctx->Dinv.ptr, ctx->diag0.ptr, piv_tol, ctx->info_d.ptr, p_pad, J,
-                               n_mats, ctx->flags, ctx->f32, ctx->stream));
+      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_PANEL);
+      HIPCHK(launch_chol_panel(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, J,
+                               n_mats, ctx->flags, ctx->f32, st));
     }
   }
   {
-    ProfScope ps(ctx, LSSPA_K_STRIP);
+    ProfScope ps(timed ? ctx : nullptr, LSSPA_K_STRIP);
     StripArgs sa;
-    sa.A = ctx->A.ptr;
-    sa.Dinv = ctx->Dinv.ptr;
-    sa.rhs = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * p_pad * ctx->esz() : nullptr;
+    sa.A = A_s;
+    sa.Dinv = Dinv_s;
+    sa.rhs = ctx->tri ? A_s + (size_t)n_ord * pp2 * es : nullptr;
     sa.Ft = ctx->tri ? nullptr : ctx->Ft.ptr;
     sa.f32 = ctx->f32;
-    sa.perms = ctx->perms_d.ptr;
-    sa.V = ctx->V.ptr;
+    sa.perms = perms_s;
+    sa.V = V_s;
     sa.p = p;
     sa.p_pad = p_pad;
     sa.m_pad = m_pad;
     sa.n_ord = n_ord;
     sa.tri = ctx->tri;
     sa.flags = ctx->flags;
-    HIPCHK(launch_strip(sa, ctx->stream));
+    HIPCHK(launch_strip(sa, st));
   }
   {
-    ProfScope ps(ctx, LSSPA_K_LIFT);
+    ProfScope ps(timed ? ctx : nullptr, LSSPA_K_LIFT);
     LiftArgs la;
-    la.A = ctx->A.ptr;
-    la.At = ctx->tri ? ctx->A.ptr + (size_t)n_ord * p_pad * p_pad * ctx->esz() : nullptr;
+    la.A = A_s;
+    la.At = ctx->tri ? A_s + (size_t)n_ord * pp2 * es : nullptr;
     la.f32 = ctx->f32;
     la.ytil = ctx->tri ? nullptr : ctx->ytil.ptr;
-    la.V = ctx->V.ptr;
-    la.perms = ctx->perms_d.ptr;
-    la.Ppart = ctx->Ppart.ptr;
+    la.V = V_s;
+    la.perms = perms_s;
+    la.Ppart = Ppart_s;
     la.lifts = ctx->lifts.ptr + (size_t)s_off * p;
     la.y_norm_sq = ctx->y_norm_sq;
     la.p = p;
@@ -420,8 +434,30 @@ int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
     la.n_ord = n_ord;
     la.per_sample = per_sample;
     la.tri = ctx->tri;
-    HIPCHK(launch_lift(la, ctx->stream));
+    HIPCHK(launch_lift(la, st));
   }
+  return LSSPA_OK;
+}
+
+// Run gather -> factorisation -> strip -> lift for n_ord orderings already resident in perms_d.
+// lifts for sample s land in lifts_d[(s_off + s)][p].  A large batch is cut into two slices on two
+// streams: the launches of a slice depend on each other, so while one slice drains the tail of a
+// launch (a few workgroups still factoring diagonal blocks) or sits in a memory-bound kernel, the
+// other slice's workgroups take the idle CUs.
+int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
+  const int half = ((n_ord / 2) / per_sample) * per_sample;
+  if (ctx->prof_on || (ctx->flags & 32) || half < 32) return run_slice(ctx, 0, n_ord, per_sample, s_off, ctx->stream);
+  if (!ctx->side_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));          // the orderings are on the device
+  HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+  TRY(run_slice(ctx, 0, half, per_sample, s_off, ctx->stream));
+  TRY(run_slice(ctx, half, n_ord - half, per_sample, s_off + half / per_sample, ctx->side_stream));
+  HIPCHK(hipEventRecord(ctx->ev_join, ctx->side_stream));
+  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   return LSSPA_OK;
 }
 
@@ -530,6 +566,12 @@ int lsspa_destroy(lsspa_ctx* ctx) {
   dev_free(ctx->Ppart); dev_free(ctx->lifts); dev_free(ctx->diag0); dev_free(ctx->perms_d); dev_free(ctx->info_d);
   dev_free(ctx->mean); dev_free(ctx->M2); dev_free(ctx->pend); dev_free(ctx->state_n);
   dev_free(ctx->Cred);
+  if (ctx->side_stream) {
+    (void)hipStreamSynchronize(ctx->side_stream);
+    (void)hipStreamDestroy(ctx->side_stream);
+    (void)hipEventDestroy(ctx->ev_fork);
+    (void)hipEventDestroy(ctx->ev_join);
+  }
   dev_free(ctx->hist); dev_free(ctx->xi_d); dev_free(ctx->draws); dev_free(ctx->err_out);
   for (int b = 0; b < 2; ++b) {
     if (ctx->perms_h[b]) (void)hipHostFree(ctx->perms_h[b]);

@@ -52,13 +52,16 @@ __host__ __device__ inline int64_t ldv_of(int m_pad) { return (int64_t)m_pad + L
 // rows of a V matrix: the ordering's row blocks rounded up to 128
 __host__ __device__ inline int64_t v_rows_of(int p) { return (int64_t)((p + 127) / 128) * 128; }
 
-// Note on v_mfma_f64_4x4x4_4b_f64: it issues every 16.5 cycles (32 flop/clk/SIMD, 70-76 TFLOP/s in
-// tools/mfma_bench3.hip / mfma_bench4.hip) against ~99 cycles per 2048-flop 16x16x4 instruction
-// (47 TFLOP/s), and a 16x16x4 step can be built from four of them (lane maps probed in
-// tools/mfma_probe4.hip: lane l = 16 q + 4 g + t holds A_g[i=t][k=q], B_g[k=q][j=t], D_g[i=q][j=t];
-// CBSZ/ABID broadcast is ignored for f64).  Panel and strip kernels written that way (git history:
-// "Experimental 4x4x4-MFMA kernel variants") were correct but not faster in situ: the k-loops are
-// bound by their load -> LDS -> barrier pipeline, not by MFMA issue.
+// Note on v_mfma_f64_4x4x4_4b_f64: in a dependent-free register loop it issues every 16.5 cycles
+// (70-76 TFLOP/s, tools/mfma_bench3.hip) against 47 TFLOP/s for the 16x16x4 form, and a 16x16x4 step can
+// be built from four of them (lane maps probed in tools/mfma_probe4.hip: lane l = 16 q + 4 g + t holds
+// A_g[i=t][k=q], B_g[k=q][j=t], D_g[i=q][j=t]; CBSZ/ABID broadcast is ignored for f64).  It buys nothing
+// in the kernels: tools/mfma_bench5.hip runs the k-loop of the two-level kernels in isolation (global
+// prefetch -> LDS -> barrier -> fragments -> MFMA, 2 workgroups per CU) and both forms sustain the same
+// 48-54 TFLOP/s with random operands streaming from HBM (61 / 57 without the loads, 64-70 with all-zero
+// operands): the fp64 matrix pipe is bound by power -- the sustained clock depends on the data -- not by
+// issue rate.  Kernel variants written with the 4x4x4 form (git history: "Experimental 4x4x4-MFMA kernel
+// variants") were correct and slower.  ~50 TFLOP/s is the practical fp64 ceiling these kernels price against.
 
 // ---- per-element-type traits ---------------------------------------------------------------------
 template <typename T>

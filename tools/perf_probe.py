@@ -65,6 +65,21 @@ if len(sys.argv) > 5:
     for f in sets:
         keys = res[f][0].keys()
         print("flags", f, {k: round(min(r[k] for r in res[f]), 3) for k in keys})
+    # wall-clock A/B without events (the two-slice schedule only runs unprofiled)
+    eng.profile(False)
+    wall = {f: [] for f in sets}
+    for rnd in range(4):
+        for f in sets:
+            eng.set_flags(f)
+            eng.run_batch(perms, True); eng.merge(); eng.synchronize()
+            t0 = time.perf_counter()
+            for s in range(5):
+                eng.run_batch(perms, True); eng.merge()
+            eng.synchronize()
+            wall[f].append((time.perf_counter() - t0) / 5)
+    for f in sets:
+        print("flags", f, f"wall {1e3*min(wall[f]):.3f} ms/batch")
+    eng.profile(True)
     eng.set_flags(0)
 n, mean, cov = eng.stats()
 print("n", n, "sum(mean)", mean.sum(), "r2", r2)
