@@ -21,7 +21,11 @@ namespace lsspa {
 // =====================================================================================
 constexpr int GROWS = 16;
 
-template <typename T>
+// PAIRED: ordering 2 s + 1 is ordering 2 s reversed (an antithetical pair).  With pi' = reverse(pi),
+// row p-1-i of the second matrix is  S[pi_i][pi_{p-1-j'}],  j' <= p-1-i : the OTHER end of the same source
+// row that row i of the first matrix takes its entries from.  One staging of the source row in LDS
+// therefore serves both matrices, which halves the row reads.
+template <typename T, bool PAIRED>
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* rowbuf = reinterpret_cast<double*>(smem_raw);                      // [p_pad]
@@ -30,18 +34,22 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
   typedef typename Tr<T>::vec_t vec_t;
 
   const int tid = threadIdx.x;
-  const int mat = blockIdx.y;
-  const int src = mat / a.n_ord;
-  const int ord = mat - src * a.n_ord;
+  const int n_slots = PAIRED ? a.n_ord / 2 : a.n_ord;
+  const int src = blockIdx.y / n_slots;
+  const int ord = (blockIdx.y - src * n_slots) * (PAIRED ? 2 : 1);
+  const int mat = src * a.n_ord + ord;
   const int i0 = blockIdx.x * GROWS;
   const int p = a.p, p_pad = a.p_pad;
   const int32_t* perm = a.perms + (int64_t)ord * p;
   const double* S = a.S[src];
   const double* svec = a.s[src];
   T* out = static_cast<T*>(a.A) + (int64_t)mat * p_pad * p_pad;   // chunk-major, see tiles.h
+  T* out2 = out + (int64_t)p_pad * p_pad;                           // the reversed ordering's matrix
   double* d0 = a.diag0 + (int64_t)mat * p_pad;
+  double* d02 = d0 + p_pad;
 
-  const int jmax = min(i0 + GROWS, p);  // permutation entries this workgroup can touch
+  // permutation entries this workgroup can touch: all of them when it also writes the mirror rows
+  const int jmax = PAIRED ? p : min(i0 + GROWS, p);
   for (int j = tid; j < jmax; j += 256) sperm[j] = perm[j];
   __syncthreads();
 
@@ -67,30 +75,59 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
         *reinterpret_cast<vec_t*>(out + cm_off(p_pad, i, j)) = v;
       }
       if (tid == 0) d0[i] = rowbuf[sperm[i]];
+      if (PAIRED) {
+        const int i2 = p - 1 - i;
+        const int jend2 = min(((i2 + 1 + NB - 1) / NB) * NB, p_pad);
+        for (int j = VE * tid; j < jend2; j += VE * 256) {
+          vec_t v;
+#pragma unroll
+          for (int e = 0; e < VE; ++e) v[e] = (j + e <= i2) ? (T)rowbuf[sperm[p - 1 - (j + e)]] : (T)0;
+          *reinterpret_cast<vec_t*>(out2 + cm_off(p_pad, i2, j)) = v;
+        }
+        if (tid == 0) d02[i2] = rowbuf[sperm[i]];
+      }
     } else if (i == p) {
-      for (int j = tid; j < jend; j += 256)
+      for (int j = tid; j < jend; j += 256) {
         out[cm_off(p_pad, i, j)] = (T)((j < p) ? svec[sperm[j]] : (j == p ? a.aug[src] : 0.0));
-      if (tid == 0) d0[i] = a.aug[src];
+        if (PAIRED) out2[cm_off(p_pad, i, j)] = (T)((j < p) ? svec[sperm[p - 1 - j]] : (j == p ? a.aug[src] : 0.0));
+      }
+      if (tid == 0) {
+        d0[i] = a.aug[src];
+        if (PAIRED) d02[i] = a.aug[src];
+      }
     } else {
-      for (int j = tid; j < jend; j += 256) out[cm_off(p_pad, i, j)] = (j == i) ? (T)1 : (T)0;
-      if (tid == 0) d0[i] = 1.0;
+      for (int j = tid; j < jend; j += 256) {
+        out[cm_off(p_pad, i, j)] = (j == i) ? (T)1 : (T)0;
+        if (PAIRED) out2[cm_off(p_pad, i, j)] = (j == i) ? (T)1 : (T)0;
+      }
+      if (tid == 0) {
+        d0[i] = 1.0;
+        if (PAIRED) d02[i] = 1.0;
+      }
     }
   }
 }
 
 hipError_t launch_gather(const GatherArgs& a, hipStream_t st) {
   if (a.p < 1 || a.p_pad % NB != 0 || a.p_pad <= a.p || a.n_ord < 1 || a.n_src < 1 || a.n_src > 2 ||
-      (a.ld_src & 1))
+      (a.ld_src & 1) || (a.paired && (a.n_ord & 1)))
     return hipErrorInvalidValue;
   const size_t shmem = sizeof(double) * a.p_pad + sizeof(int32_t) * a.p_pad;
   if (shmem > 64 * 1024) return hipErrorInvalidValue;
-  dim3 grid((a.p_pad + GROWS - 1) / GROWS, a.n_ord * a.n_src);
+  dim3 grid((a.p_pad + GROWS - 1) / GROWS, (a.paired ? a.n_ord / 2 : a.n_ord) * a.n_src);
   // aug row reads sperm[j] for all j < p: the workgroup holding row p must have them all
   // (jmax = min(i0 + GROWS, p) = p there), so nothing else to arrange.
-  if (a.f32)
-    hipLaunchKernelGGL(gather_kernel<float>, grid, dim3(256), shmem, st, a);
-  else
-    hipLaunchKernelGGL(gather_kernel<double>, grid, dim3(256), shmem, st, a);
+  if (a.paired) {
+    if (a.f32)
+      hipLaunchKernelGGL((gather_kernel<float, true>), grid, dim3(256), shmem, st, a);
+    else
+      hipLaunchKernelGGL((gather_kernel<double, true>), grid, dim3(256), shmem, st, a);
+  } else {
+    if (a.f32)
+      hipLaunchKernelGGL((gather_kernel<float, false>), grid, dim3(256), shmem, st, a);
+    else
+      hipLaunchKernelGGL((gather_kernel<double, false>), grid, dim3(256), shmem, st, a);
+  }
   return hipGetLastError();
 }
 
@@ -770,7 +807,8 @@ template <typename T, int NT>
 __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict__ A, T* __restrict__ Dinv,
                                                                  const double* __restrict__ diag0,
                                                                  double piv_tol, int32_t* __restrict__ info,
-                                                                 int p_pad, int Jo, int nblk) {
+                                                                 int p_pad, int Jo, int nblk, int n_mats,
+                                                                 int grouped) {
   typedef typename Tr<T>::acc_t acc_t;
   typedef typename Tr<T>::vec_t vec_t;
   constexpr int VE = Tr<T>::VE;
@@ -791,8 +829,25 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int mt = blockIdx.x;     // matrix: fastest in dispatch order, so the tile-0 workgroups start first
-  const int tile = blockIdx.y;
+  // Dispatch order (1-D grid).  The tile-0 workgroups, which also factor the next diagonal block, come
+  // first, one per matrix.  The other tiles follow in groups of eight matrices: consecutive ids walk the
+  // eight matrices (id % 8 = matrix % 8 = XCD, workgroups go round-robin over the XCDs), then the tiles,
+  // so the tiles of one matrix run at about the same time on ONE XCD and share the panel-row operand
+  // L[J, 0:J0] through its L2 (worth ~1 %: the loop is not bound by that traffic).
+  int mt, tile;
+  {
+    const int id = blockIdx.x;
+    if (id < n_mats || !grouped) {
+      mt = id % n_mats;
+      tile = id / n_mats;
+    } else {
+      const int n_tiles = gridDim.x / n_mats;
+      const int rem = id - n_mats, per = 8 * (n_tiles - 1);
+      const int g = rem / per, within = rem - g * per;
+      tile = 1 + within / 8;
+      mt = 8 * g + (within & 7);
+    }
+  }
   T* M = A + (int64_t)mt * p_pad * p_pad;
   const int J0 = Jo * 128;
   const int I0 = J0 + 128 + tile * 128;
@@ -1007,18 +1062,20 @@ hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double pi
 }
 
 hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
-                              int Jo, int n_mats, int f32, hipStream_t st) {
+                              int Jo, int n_mats, int f32, hipStream_t st, int flags) {
   if (p_pad % 128 != 0 || Jo < 0 || Jo >= p_pad / 128 - 1 || n_mats < 1) return hipErrorInvalidValue;
   const int nblk = p_pad / NB;
-  dim3 grid(n_mats, p_pad / 128 - 1 - Jo);
+  const int n_tiles = p_pad / 128 - 1 - Jo;
+  dim3 grid(n_mats * n_tiles);
+  const int grouped = (n_mats % 8 == 0 && n_tiles > 1 && !(flags & 64)) ? 1 : 0;
   // 256 threads: 512-thread workgroups (16 rows per wave, twice the waves per SIMD) were measured
   // slower in both precisions -- the epilogue is bound by its memory traffic, not by latency
   if (f32)
     hipLaunchKernelGGL((chol_panel2_kernel<float, 256>), grid, dim3(256), 0, st, (float*)A, (float*)Dinv, diag0,
-                       piv_tol, info, p_pad, Jo, nblk);
+                       piv_tol, info, p_pad, Jo, nblk, n_mats, grouped);
   else
     hipLaunchKernelGGL((chol_panel2_kernel<double, 256>), grid, dim3(256), 0, st, (double*)A, (double*)Dinv,
-                       diag0, piv_tol, info, p_pad, Jo, nblk);
+                       diag0, piv_tol, info, p_pad, Jo, nblk, n_mats, grouped);
   return hipGetLastError();
 }
 

@@ -21,6 +21,8 @@ struct GatherArgs {
   void* A;                 // [n_src * n_ord] chunk-major p_pad x p_pad matrices, lower triangles written
   double* diag0;           // [n_src * n_ord][p_pad]: the permuted diagonals before any update (pivot scale)
   int f32;
+  int paired;              // orderings 2 s and 2 s + 1 are each other's reverse (antithetical pairs): one pass over
+                           // the source rows writes both matrices
 };
 hipError_t launch_gather(const GatherArgs& a, hipStream_t st);
 

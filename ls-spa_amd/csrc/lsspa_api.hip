@@ -369,6 +369,7 @@ int run_slice(lsspa_ctx* ctx, int ord_off, int n_ord, int per_sample, int s_off,
     ga.A = A_s;
     ga.diag0 = diag0_s;
     ga.f32 = ctx->f32;
+    ga.paired = (per_sample == 2 && !(ctx->flags & 256)) ? 1 : 0;   // stage_and_run lays pairs out back to back
     HIPCHK(launch_gather(ga, st));
   }
   const bool fused = !(ctx->flags & 2);  // panel step J also factors diagonal block J + 1
