@@ -1087,19 +1087,25 @@ hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double p
 //     X1 = Dinv_i C1 ;  C2 -= L[i+1][i] X1 ;  X2 = Dinv_{i+1} C2
 // in which X1, still in registers, is the B operand of the middle product.
 // =====================================================================================
-template <typename T>
-__global__ __launch_bounds__(256, 2) void strip2_kernel(StripArgs a) {
+// NT threads = NT / 64 waves, each owning 32 columns: the strip is CW = NT / 2 columns wide.  The wider
+// strip (NT = 512) reads L half as often; the accumulators per wave, and so the waves per SIMD, are the same.
+template <typename T, int NT>
+__global__ __launch_bounds__(NT, 2) void strip2_kernel(StripArgs a) {
+  constexpr int CW = NT / 2;
+  typedef KCWRegs<T, CW, NT> KR;
   typedef typename Tr<T>::acc_t acc_t;
   typedef typename Tr<T>::vec_t vec_t;
   constexpr int VE = Tr<T>::VE;
   __shared__ __attribute__((aligned(16))) T s_rk[128 * RK_LD];
-  __shared__ __attribute__((aligned(16))) T s_kc[16 * KC_LD];
+  __shared__ __attribute__((aligned(16))) T s_kc[16 * KR::LD];
   __shared__ __attribute__((aligned(16))) T s_dinv[64 * DI_LD];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int ord = blockIdx.x;
-  const int c0 = blockIdx.y * 128;
+  const int c0 = blockIdx.y * CW;
+  const int cols_valid = min(CW, a.m_pad - c0);   // the last strip of a wide layout may be half empty
+  const bool wactive = 32 * (threadIdx.x >> 6) < cols_valid;
   const int p = a.p, p_pad = a.p_pad, m_pad = a.m_pad;
   const int nblk = p_pad / NB;
   const int n_iblk = (p + NB - 1) / NB;
@@ -1111,13 +1117,13 @@ __global__ __launch_bounds__(256, 2) void strip2_kernel(StripArgs a) {
   T* V = static_cast<T*>(a.V) + (int64_t)ord * v_rows_of(p) * ldv;
   const T* Dv = static_cast<const T*>(a.Dinv) + (int64_t)ord * nblk * 4096;
 
-  const int ib0 = a.tri ? c0 / NB : 0;       // even: strips are 128 wide
+  const int ib0 = a.tri ? c0 / NB : 0;       // even: strips are a multiple of 128 wide
   const int kstart = a.tri ? c0 : 0;
   if (a.tri) {
-    constexpr int VPR = 128 / VE;
-    for (int idx = tid; idx < ib0 * NB * VPR; idx += 256) {
+    constexpr int VPR = CW / VE;
+    for (int idx = tid; idx < ib0 * NB * VPR; idx += NT) {
       const int row = idx / VPR, cv = idx % VPR;
-      *reinterpret_cast<vec_t*>(V + row * ldv + c0 + VE * cv) = Tr<T>::vzero();
+      if (VE * cv < cols_valid) *reinterpret_cast<vec_t*>(V + row * ldv + c0 + VE * cv) = Tr<T>::vzero();
     }
   }
 
@@ -1125,6 +1131,11 @@ __global__ __launch_bounds__(256, 2) void strip2_kernel(StripArgs a) {
     const int I0 = ib * NB;
     const bool two = ib + 1 < n_iblk;          // the last step of an odd block count has one half
     const int rows_valid = two ? 128 : 64;
+    // Strides re-materialised per step: otherwise every row address of the epilogue (32 of them, 64 bit)
+    // is hoisted out of this loop and carried -- spilled -- through the k-loop.
+    int64_t ldv_e = ldv;
+    int pp_e = p_pad;
+    asm volatile("" : "+s"(ldv_e), "+s"(pp_e));
     acc_t acc[8][2];
 #pragma unroll
     for (int x = 0; x < 8; ++x)
@@ -1134,30 +1145,30 @@ __global__ __launch_bounds__(256, 2) void strip2_kernel(StripArgs a) {
     const T* srcL = L + cm_off(p_pad, I0, kstart);
     const T* srcV = V + kstart * ldv + c0;
     const int nch = (I0 - kstart) / KCH;
-    RKRegs<T, 128> rl = {};
-    KCRegs<T> rv = {};
+    RKRegs<T, 128, NT> rl = {};
+    KR rv = {};
     if (nch > 0) {
-      rk_load<T, 128>(rl, srcL, CM_LD, tid, rows_valid);
-      kc_load<T>(rv, srcV, ldv, tid);
+      rk_load<T, 128, NT>(rl, srcL, CM_LD, tid, rows_valid);
+      kcw_load<T, CW, NT>(rv, srcV, ldv, tid, cols_valid);
     }
     for (int c = 0; c < nch; ++c) {
       __syncthreads();
-      rk_store<T, 128>(rl, s_rk, tid);
-      kc_store<T>(rv, s_kc, tid);
+      rk_store<T, 128, NT>(rl, s_rk, tid);
+      kcw_store<T, CW, NT>(rv, s_kc, tid, cols_valid);
       __syncthreads();
       if (c + 1 < nch) {
-        rk_load<T, 128>(rl, srcL + (c + 1) * chunk, CM_LD, tid, rows_valid);
-        kc_load<T>(rv, srcV + (c + 1) * KCH * ldv, ldv, tid);
+        rk_load<T, 128, NT>(rl, srcL + (c + 1) * chunk, CM_LD, tid, rows_valid);
+        kcw_load<T, CW, NT>(rv, srcV + (c + 1) * KCH * ldv, ldv, tid, cols_valid);
       }
-      // tri: V[k][col] = 0 for col > k, so columns c0+64.. (waves 2, 3) see only zeros while k < c0+64
-      if (a.tri && w >= 2 && c < 4) continue;
+      // tri: V[k][col] = 0 for col > k: wave w (columns c0 + 32 w ..) sees only zeros while k < c0 + 32 w
+      if (a.tri && c < 2 * w) continue;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         T av[8], bv[2];
 #pragma unroll
         for (int x = 0; x < 8; ++x) av[x] = s_rk[(16 * x + l15) * RK_LD + 4 * kk + l4];
 #pragma unroll
-        for (int y = 0; y < 2; ++y) bv[y] = s_kc[(4 * kk + l4) * KC_LD + 32 * w + 16 * y + l15];
+        for (int y = 0; y < 2; ++y) bv[y] = s_kc[(4 * kk + l4) * KR::LD + 32 * w + 16 * y + l15];
 #pragma unroll
         for (int x = 0; x < 8; ++x)
 #pragma unroll
@@ -1166,31 +1177,54 @@ __global__ __launch_bounds__(256, 2) void strip2_kernel(StripArgs a) {
     }
 
     __syncthreads();  // s_dinv is still being read by slower waves of the previous step
-    load_block64<T>(s_dinv, Dv + (int64_t)ib * 4096, tid);
+    load_block64<T, NT>(s_dinv, Dv + (int64_t)ib * 4096, tid);
 
     // C = RHS[I] - acc  (direct global reads: 16 lanes cover one contiguous row segment), one half at a
     // time so that only 32 loads are in flight
+    // Every load below is unconditional (clamped address, value selected afterwards): a guarded load
+    // becomes a branch per element, and the wait at each join turns the 32 loads into a latency chain.
     auto rhs_minus_acc = [&](const int half) {
+      const int blk_end = I0 + (half + 1) * NB;    // end of the rows' own diagonal block
+      if (a.tri) {
 #pragma unroll
-      for (int xx = 0; xx < 4; ++xx) {
-        const int x = 4 * half + xx;
+        for (int xx = 0; xx < 4; ++xx) {
+          const int x = 4 * half + xx;
+          T t[4][2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = I0 + 16 * x + Tr<T>::acc_row(l4, r);
-          const int blk_end = I0 + (half + 1) * NB;    // end of the row's own diagonal block
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int y = 0; y < 2; ++y) {
-            const int c = c0 + 32 * w + 16 * y + l15;
-            T rv0 = (T)0;
-            if (a.tri) {
-              if (c < blk_end) rv0 = Lt[cm_off(p_pad, i, c)];
-            } else {
-              if (i < p) rv0 = (T)a.Ft[(int64_t)perm[i] * m_pad + c];
+            for (int y = 0; y < 2; ++y)   // column clamped into the rows' own block: always inside the matrix
+              t[r][y] = Lt[cm_off(pp_e, I0 + 16 * x + Tr<T>::acc_row(l4, r),
+                                  min(c0 + 32 * w + 16 * y + l15, blk_end - 1))];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+              const int c = c0 + 32 * w + 16 * y + l15;
+              acc[x][y][r] = ((c < blk_end) ? t[r][y] : (T)0) - acc[x][y][r];
             }
-            acc[x][y][r] = rv0 - acc[x][y][r];
-          }
+          __builtin_amdgcn_sched_barrier(0);   // 8 loads in flight, not 32
         }
-        __builtin_amdgcn_sched_barrier(0);   // 8 loads in flight, not 32
+      } else {
+#pragma unroll
+        for (int xx = 0; xx < 4; ++xx) {
+          const int x = 4 * half + xx;
+          double t[4][2];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = I0 + 16 * x + Tr<T>::acc_row(l4, r);
+            const int64_t srow = (int64_t)perm[min(i, p - 1)] * m_pad;
+#pragma unroll
+            for (int y = 0; y < 2; ++y) t[r][y] = a.Ft[srow + (wactive ? c0 + 32 * w + 16 * y + l15 : 0)];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = I0 + 16 * x + Tr<T>::acc_row(l4, r);
+#pragma unroll
+            for (int y = 0; y < 2; ++y) acc[x][y][r] = ((i < p) ? (T)t[r][y] : (T)0) - acc[x][y][r];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     };
     // acc[4 h + xp][y] <- sum_{x <= xp} D[xp][x] acc[4 h + x][y], one column tile at a time (in place)
@@ -1221,7 +1255,8 @@ __global__ __launch_bounds__(256, 2) void strip2_kernel(StripArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int i = I0 + half * NB + 16 * xp + Tr<T>::acc_row(l4, r);
 #pragma unroll
-          for (int y = 0; y < 2; ++y) V[i * ldv + c0 + 32 * w + 16 * y + l15] = acc[4 * half + xp][y][r];
+          for (int y = 0; y < 2; ++y)
+            if (wactive) V[i * ldv_e + c0 + 32 * w + 16 * y + l15] = acc[4 * half + xp][y][r];
         }
     };
 
@@ -1235,7 +1270,7 @@ __global__ __launch_bounds__(256, 2) void strip2_kernel(StripArgs a) {
       rhs_minus_acc(1);
       // C2 -= L[i+1][i] * X1  (X1 straight from its accumulators)
       __syncthreads();
-      load_block64_cm<T>(s_dinv, L, p_pad, I0 + NB, I0, tid, true);
+      load_block64_cm<T, NT>(s_dinv, L, p_pad, I0 + NB, I0, tid, true);
       __syncthreads();
 #pragma unroll
       for (int xp = 0; xp < 4; ++xp) {
@@ -1250,7 +1285,7 @@ __global__ __launch_bounds__(256, 2) void strip2_kernel(StripArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
-      load_block64<T>(s_dinv, Dv + (int64_t)(ib + 1) * 4096, tid);
+      load_block64<T, NT>(s_dinv, Dv + (int64_t)(ib + 1) * 4096, tid);
       __syncthreads();
       tri_solve(1);   // X2 = Dinv_{i+1} * C2
       store_half(1);
@@ -1272,10 +1307,19 @@ hipError_t launch_strip(const StripArgs& a, hipStream_t st) {
     else
       hipLaunchKernelGGL(strip_kernel<double>, grid, dim3(256), 0, st, a);
   } else {
-    if (a.f32)
-      hipLaunchKernelGGL(strip2_kernel<float>, grid, dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL(strip2_kernel<double>, grid, dim3(256), 0, st, a);
+    if (!(a.flags & 512)) {   // default: 128-column strips, 256 threads (flag: 256-column strips, 512 threads --
+                             // a third less L traffic, measured 5 % slower at p = 1000)
+      if (a.f32)
+        hipLaunchKernelGGL((strip2_kernel<float, 256>), grid, dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((strip2_kernel<double, 256>), grid, dim3(256), 0, st, a);
+    } else {
+      const dim3 wide(a.n_ord, (a.m_pad + 255) / 256);
+      if (a.f32)
+        hipLaunchKernelGGL((strip2_kernel<float, 512>), wide, dim3(512), 0, st, a);
+      else
+        hipLaunchKernelGGL((strip2_kernel<double, 512>), wide, dim3(512), 0, st, a);
+    }
   }
   return hipGetLastError();
 }

@@ -49,10 +49,16 @@ __global__ __launch_bounds__(256) void lift_partial_kernel(LiftArgs a) {
       if (lane < 16) Pp[j0 + lane] = 0.0;
       continue;
     }
+    // unconditional loads (rows up to n_rows exist and are written by the strip kernel), values selected
+    // afterwards: a guarded load becomes a branch, and sixteen of them a latency chain
+    T vraw[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) vraw[jj] = V[(j0 + jj) * ldv + c];
+    const T zraw = L[cm_off(p_pad, p, min(j0 + r16, p - 1))];
     double v[16];
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) v[jj] = (j0 + jj < p) ? (double)V[(j0 + jj) * ldv + c] : 0.0;
-    const double zl = (j0 + r16 < p) ? (double)L[cm_off(p_pad, p, j0 + r16)] : 0.0;  // lane r16 holds z[j0 + r16]
+    for (int jj = 0; jj < 16; ++jj) v[jj] = (j0 + jj < p) ? (double)vraw[jj] : 0.0;
+    const double zl = (j0 + r16 < p) ? (double)zraw : 0.0;  // lane r16 holds z[j0 + r16]
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
       const double zj = __shfl(zl, jj, 64);

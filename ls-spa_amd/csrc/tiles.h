@@ -175,6 +175,40 @@ __device__ __forceinline__ void kc_store(const KCRegs<T>& r, T* lds, int tid) {
   for (int q = 0; q < KR::NP; ++q) Tr<T>::lds_store(lds + (k + KR::RPP * q) * KC_LD + Tr<T>::VE * c, r.v[q]);
 }
 
+// ---- the same for a [16 k][CW cols] tile and NT threads (row stride CW + 16 in LDS).  Columns at or
+// beyond cols_valid are not read: the lane loads column 0 instead (an address select, no branch -- a
+// branch would put a wait for the loads at its join and serialise the prefetch) and stores zeros. ------
+template <typename T, int CW, int NT>
+struct KCWRegs {
+  static constexpr int VPR = CW / Tr<T>::VE;   // vectors per k row
+  static constexpr int RPP = NT / VPR;         // k rows per pass
+  static constexpr int NP = 16 / RPP;          // passes
+  static constexpr int LD = CW + 16;
+  static_assert(RPP >= 1 && NP >= 1 && NP * RPP == 16, "tile shape does not divide over the workgroup");
+  typename Tr<T>::vec_t v[NP];
+};
+
+template <typename T, int CW, int NT>
+__device__ __forceinline__ void kcw_load(KCWRegs<T, CW, NT>& r, const T* __restrict__ src, int64_t ld, int tid,
+                                         int cols_valid) {
+  typedef KCWRegs<T, CW, NT> KR;
+  const int c = tid % KR::VPR, k = tid / KR::VPR;
+  const int cc = (Tr<T>::VE * c < cols_valid) ? Tr<T>::VE * c : 0;
+#pragma unroll
+  for (int q = 0; q < KR::NP; ++q)
+    r.v[q] = *reinterpret_cast<const typename Tr<T>::vec_t*>(src + (int64_t)(k + KR::RPP * q) * ld + cc);
+}
+
+template <typename T, int CW, int NT>
+__device__ __forceinline__ void kcw_store(const KCWRegs<T, CW, NT>& r, T* lds, int tid, int cols_valid) {
+  typedef KCWRegs<T, CW, NT> KR;
+  const int c = tid % KR::VPR, k = tid / KR::VPR;
+  const bool ok = Tr<T>::VE * c < cols_valid;
+#pragma unroll
+  for (int q = 0; q < KR::NP; ++q)
+    Tr<T>::lds_store(lds + (k + KR::RPP * q) * KR::LD + Tr<T>::VE * c, ok ? r.v[q] : Tr<T>::vzero());
+}
+
 // copy a dense 64 x 64 block (row-major, ld 64) from global into LDS with stride DI_LD, NT threads
 template <typename T, int NT = 256>
 __device__ __forceinline__ void load_block64(T* lds, const T* __restrict__ g, int tid) {

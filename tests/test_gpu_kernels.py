@@ -237,3 +237,22 @@ def test_stats_checkpoint_resume(engine):
     np.testing.assert_allclose(cov, cov_ref, rtol=0, atol=1e-16)
     np.testing.assert_array_equal(engine.history(), hist_ref)
     engine.history_enable(0)
+
+
+@pytest.mark.parametrize("p,n,m", [(130, 400, 300), (300, 700, 650), (70, 300, 40), (200, 600, 150)])
+def test_wide_strip_variant(engine, p, n, m):
+    """The 256-column / 512-thread strip kernel (developer flag 512) against the default one and the
+    oracle, including half-filled last strips (m_pad = 128 or 384) in both modes."""
+    Xa, Xe, ya, ye = problem(11, p, n, m)
+    red = O.reduce(Xa, Xe, ya, ye, 0.0)
+    yy = float(ye @ ye)
+    rng = np.random.default_rng(6)
+    perms = np.array([rng.permutation(p) for _ in range(5)])
+    want = np.array([O.sample_lift(*red, yy, o, True) for o in perms])
+    engine.load_data(Xa, Xe, ya, ye, 0.0)
+    try:
+        engine.set_flags(512)
+        got = engine.run_batch(perms, True, want_lifts=True, accumulate=False)
+    finally:
+        engine.set_flags(0)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-11)

@@ -14,11 +14,11 @@ def load(d):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "lsspa" in r["Kernel_Name"]:
-            agg[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("lsspa::", "")].append(float(r["Counter_Value"]))
+            agg[r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("lsspa::", "")].append(float(r["Counter_Value"]))
     return agg
 
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
-per_batch = {"gather_kernel": 1, "chol_diag_kernel": 1, "chol_panel_kernel": 15, "strip_kernel": 1,
+per_batch = {"gather_kernel": 1, "chol_diag2_kernel": 1, "chol_panel2_kernel": 7, "strip2_kernel": 1,
              "lift_partial_kernel": 1, "lift_finish_kernel": 1, "stats_batch_kernel": 1}
 rows, traffic = [], {}
 for k, n in per_batch.items():
@@ -31,8 +31,8 @@ with open("profiles/r01_pmc_summary.csv", "w") as fh:
     fh.write("kernel,launches_per_batch,FETCH_SIZE_bytes_raw,fetch_bytes_corrected_x2,WRITE_SIZE_bytes,hbm_bytes_per_batch,hbm_bytes_per_launch\n")
     for r in rows:
         fh.write(",".join(str(x) for x in r) + "\n")
-alias = {"gather": "gather_kernel", "chol_diag": "chol_diag_kernel", "chol_panel": "chol_panel_kernel",
-         "strip": "strip_kernel", "lift": "lift_partial_kernel"}
+alias = {"gather": "gather_kernel", "chol_diag": "chol_diag2_kernel", "chol_panel": "chol_panel2_kernel",
+         "strip": "strip2_kernel", "lift": "lift_partial_kernel"}
 json.dump({"p": 1000, "batch_size": 128, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
            "tools/pmc_summary.py; FETCH_SIZE doubled (gfx950 16-B/lane correction)",
            "hbm_bytes_per_launch": {a: traffic[k] for a, k in alias.items()}}, open("profiles/pmc_traffic.json", "w"), indent=1)
