@@ -239,9 +239,9 @@ def main():
                     "unit": "TFLOP/s", "frac": ach / peak_tf, "traffic": traffic,
                     "algorithmic_flops_per_launch": flops, "avg_launch_ms": per_class[dom]["avg_launch_ms"],
                     "traffic_gbps": (traffic / (per_class[dom]["avg_launch_ms"] * 1e-3) / 1e9) if traffic else None,
-                    "note": "peak = vendor fp64 matrix/vector figure; v_mfma_f64_16x16x4 sustains 47.8 TFLOP/s "
-                            "on this chip (tools/mfma_bench.hip); the kernel's k-loop is co-limited by operand "
-                            "traffic (DESIGN.md section 5)"}
+                    "note": "peak = vendor fp64 matrix/vector figure; with random operands streaming from HBM the fp64 "
+                            "matrix pipe sustains 48-54 TFLOP/s in the isolated k-loop of these kernels "
+                            "(tools/mfma_bench5.hip: power bound, data dependent), which is the practical ceiling"}
         g_bytes = 2.0 * p * p * esz * n_ord         # 2 p^2 s bytes per ordering
         g_ach = g_bytes / (per_class["gather"]["avg_launch_ms"] * 1e-3) / 1e9
         gram_flops = 2.0 * rows * (p + 1) * (p + 2) / 2   # (N + M)(p + 1)(p + 2), both sides -> per launch

@@ -441,13 +441,13 @@ int run_slice(lsspa_ctx* ctx, int ord_off, int n_ord, int per_sample, int s_off,
 }
 
 // Run gather -> factorisation -> strip -> lift for n_ord orderings already resident in perms_d.
-// lifts for sample s land in lifts_d[(s_off + s)][p].  A large batch is cut into two slices on two
-// streams: the launches of a slice depend on each other, so while one slice drains the tail of a
-// launch (a few workgroups still factoring diagonal blocks) or sits in a memory-bound kernel, the
-// other slice's workgroups take the idle CUs.
+// lifts for sample s land in lifts_d[(s_off + s)][p].  With developer flag 32 a large batch is cut into
+// two slices on two streams (the launches of a slice depend on each other, so while one slice drains the
+// tail of a launch the other slice's workgroups take the idle CUs).
 int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
   const int half = ((n_ord / 2) / per_sample) * per_sample;
-  if (ctx->prof_on || (ctx->flags & 32) || half < 32) return run_slice(ctx, 0, n_ord, per_sample, s_off, ctx->stream);
+  // opt-in (developer flag 32): measured gain 0.8 % at p = 1000 -- not worth two launch shapes per kernel in the traces
+  if (ctx->prof_on || !(ctx->flags & 32) || half < 32) return run_slice(ctx, 0, n_ord, per_sample, s_off, ctx->stream);
   if (!ctx->side_stream) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
