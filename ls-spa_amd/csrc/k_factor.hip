@@ -710,51 +710,324 @@ __device__ __forceinline__ void full_mult_lower_half(typename Tr<T>::acc_t (&acc
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Blocked factorisation of a 64 x 64 diagonal block with its inverse, 16 x 16 sub-blocks:
+//   for kb = 0..3:  (1) one wave factors the 16 x 16 diagonal sub-block in registers (carried-identity
+//                       elimination, no workgroup barrier: rows and pivots travel by lane shuffles);
+//                   (2) L[ib][kb] = T[ib][kb] Ld^-T (ib > kb)  and  X[kb][jb] = Ld^-1 Y[kb][jb] (jb < kb);
+//                   (3) T[ib][jb] -= L[ib][kb] L[jb][kb]^T  and  Y[ib][jb] -= L[ib][kb] X[kb][jb]
+//                       ((2), (3): 16 x 16 x 16 tile products on the matrix pipe, one tile per wave and turn),
+// i.e. forward substitution on [T | I] block by block.  About a dozen barriers instead of the 64 of the
+// column-at-a-time sweep -- this routine sits on the critical path of every panel launch.
+// LDS: s_t  64 x DI_LD  the block; its unused upper 16 x 16 blocks (jb, ib) hold Y[ib][jb], ib > jb
+//      s_x  4 x 16 x XD_LD  the diagonal sub-blocks of the inverse; then 16 pivots' 1/sqrt(d)
+// ---------------------------------------------------------------------------------------------
+#ifdef LSSPA_FACTOR_STAMPS
+__device__ long long g_stamps[32];
+#define FSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
+constexpr int XD_LD = 17;
+constexpr int FB_SX_ELEMS = 4 * 16 * XD_LD + 16;
+
+template <typename T>
+__device__ __forceinline__ T bcast_lane(T v, int src) {   // value of v in lane src (uniform src)
+  if constexpr (sizeof(T) == 8) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint((double)v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint((double)v), src);
+    return (T)__hiloint2double(hi, lo);
+  } else {
+    return (T)__int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)v), src));
+  }
+}
+
+// 1 / d to working precision without the division sequence: hardware reciprocal + two Newton steps
+// (the elimination's critical path runs through this once per pivot)
+template <typename T>
+__device__ __forceinline__ T fast_recip(T d) {
+  if constexpr (sizeof(T) == 8) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+  } else {
+    float r = __builtin_amdgcn_rcpf(d);
+    r = fmaf(fmaf(-d, r, 1.0f), r, r);
+    return r;
+  }
+}
+
+// value of v in the lane whose byte address (4 * lane) is addr
+template <typename T>
+__device__ __forceinline__ T bperm(int addr, T v) {
+  if constexpr (sizeof(T) == 8) {
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint((double)v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint((double)v));
+    return (T)__hiloint2double(hi, lo);
+  } else {
+    return (T)__int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int((float)v)));
+  }
+}
+
+// one wave: factor the 16 x 16 block at s_blk (stride DI_LD, lower part valid) in place (L, zeros above the
+// diagonal) and write its inverse to s_inv (16 x XD_LD).  d0: the 16 original diagonal entries (pivot scale).
+// Lane (i = lane & 15, q = lane >> 4) keeps T[i][4q..4q+3] of the FULL symmetric block and Y[i][4q..4q+3].
+// Elimination without masks: step k subtracts f_i * (row k) from every row i > k of [T | Y], all columns;
+// the finished columns of T are overwritten by that, so each lane copies its entry of column k aside first.
+// Per pivot: one scalar broadcast, nine lane permutes (two addresses), a Newton reciprocal, eight FMAs --
+// no division, square root or memory access inside the sweep.
+template <typename T>
+__device__ __forceinline__ void wave_factor16(T* s_blk, T* s_inv, T* s_dd, const double* __restrict__ d0,
+                                              double piv_tol, int lane, int& bad) {
+  const int i = lane & 15, q = lane >> 4;
+  T t[4], y[4], lcol[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = 4 * q + e;
+    t[e] = (j <= i) ? s_blk[i * DI_LD + j] : s_blk[j * DI_LD + i];
+    y[e] = (j == i) ? (T)1 : (T)0;
+    lcol[e] = (T)0;
+  }
+  const double tol_i = piv_tol * d0[i];   // lane i (any q) holds the threshold of pivot i
+  T dmine = (T)1;                         // lane i keeps pivot i for the final scaling
+  const int a_row = 64 * q;               // + 4 k : byte address of lane (k, q) = 4 (k + 16 q)
+  const int a_col = 4 * i;                // + 64 kq : lane (i, kq)
+  // pivots in groups of four: the register index ke is static, the group index a (uniform) run-time value --
+  // sixteen fully unrolled steps cost 256 VGPRs and an instruction-cache footprint for nothing
+#pragma unroll 1
+  for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+  for (int ke = 0; ke < 4; ++ke) {
+    const int k = 4 * kq + ke;
+    T d = bcast_lane<T>(t[ke], k + 16 * kq);
+    const double tol = bcast_lane<double>(tol_i, k);
+    if (!((double)d > tol)) {   // numerically not positive definite (or NaN): flag it, go on
+      d = (T)1;
+      bad = 1;
+    }
+    if (i == k) dmine = d;
+    if (q == kq) lcol[ke] = t[ke];                         // column k of T is final: L[i][k] * L[k][k]
+    const T cik = bperm<T>(a_col + 64 * kq, t[ke]);        // T[i][k]
+    T tk[4], yk[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      tk[e] = bperm<T>(a_row + 4 * k, t[e]);               // T[k][4q + e]
+      yk[e] = bperm<T>(a_row + 4 * k, y[e]);               // Y[k][4q + e]
+    }
+    const T f = (i > k) ? cik * fast_recip<T>(d) : (T)0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      t[e] -= f * tk[e];
+      y[e] -= f * yk[e];
+    }
+  }
+  if (q == 0) s_dd[i] = (T)1 / sqrt(dmine);   // 1 / L[i][i]
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = 4 * q + e;
+    T lv = (T)0, xv = (T)0;
+    if (j < i) lv = lcol[e] * s_dd[j];
+    if (j == i) lv = (T)1 / s_dd[j];
+    if (j <= i) xv = y[e] * s_dd[i];
+    s_blk[i * DI_LD + j] = lv;
+    s_inv[i * XD_LD + j] = xv;
+  }
+}
+
+// out(16x16) = sign * A * B (+ C): A[m][k] = a[m * lda + k]; B[k][n] = bt ? b[n * ldb + k] : b[k * ldb + n];
+// result / accumulation tile at c (stride ldc).  One wave.
+template <typename T>
+__device__ __forceinline__ void tile16_mma(const T* a, int lda, const T* b, int ldb, bool bt, T* c, int ldc,
+                                           bool accumulate, T sign, int lane) {
+  typedef typename Tr<T>::acc_t acc_t;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  acc_t o = Tr<T>::zero();
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int kx = 4 * kk + l4;
+    const T av = sign * a[l15 * lda + kx];
+    const T bv = bt ? b[l15 * ldb + kx] : b[kx * ldb + l15];
+    o = Tr<T>::mfma(av, bv, o);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    T* dst = c + Tr<T>::acc_row(l4, r) * ldc + l15;
+    *dst = accumulate ? *dst + o[r] : o[r];
+  }
+}
+
+// Factor the 64 x 64 diagonal block of M at (r0, r0) (chunk-major, lower part meaningful) in place and write
+// its inverse to Dg (row-major 64 x 64).  NT threads, the first four waves work.  s_t: >= 64 * DI_LD elements,
+// s_x: >= FB_SX_ELEMS elements of LDS.
+// first half: the block into LDS (lower 16 x 16 blocks from memory, the rest zero: Y starts as the identity),
+// in two moves so that the fetch can be issued long before the LDS region is free
+template <typename T, int NT>
+struct Block64Regs {
+  typename Tr<T>::vec_t v[4096 / Tr<T>::VE / NT];
+};
+
+template <typename T, int NT>
+__device__ __forceinline__ void factor_block64_fetch(Block64Regs<T, NT>& b, const T* __restrict__ M, int p_pad, int r0,
+                                                     int tid) {
+  constexpr int VE = Tr<T>::VE, VPR = 64 / VE, NV = 4096 / VE;
+#pragma unroll
+  for (int qq = 0; qq < NV / NT; ++qq) {
+    const int idx = tid + NT * qq;
+    const int row = idx / VPR, col = VE * (idx % VPR);   // VE consecutive columns stay inside one 16-column block
+    b.v[qq] = *reinterpret_cast<const typename Tr<T>::vec_t*>(M + cm_off(p_pad, r0 + row, r0 + col));
+  }
+}
+
+template <typename T, int NT>
+__device__ __forceinline__ void factor_block64_put(const Block64Regs<T, NT>& b, T* s_t, int tid) {
+  constexpr int VE = Tr<T>::VE, VPR = 64 / VE, NV = 4096 / VE;
+#pragma unroll
+  for (int qq = 0; qq < NV / NT; ++qq) {
+    const int idx = tid + NT * qq;
+    const int row = idx / VPR, col = VE * (idx % VPR);
+    Tr<T>::lds_store(s_t + row * DI_LD + col, ((col >> 4) > (row >> 4)) ? Tr<T>::vzero() : b.v[qq]);
+  }
+  __syncthreads();
+}
+
+template <typename T, int NT>
+__device__ __forceinline__ void factor_block64_load(const T* __restrict__ M, int p_pad, int r0, T* s_t, int tid) {
+  FSTAMP(0);
+  Block64Regs<T, NT> b;
+  factor_block64_fetch<T, NT>(b, M, p_pad, r0, tid);
+  factor_block64_put<T, NT>(b, s_t, tid);
+  FSTAMP(1);
+}
+
+// second half: factor the block held in s_t, store L to M and the inverse to Dg.  On return s_t still holds L
+// (lower blocks) and the off-diagonal blocks of the inverse (block (jb, ib) = X[ib][jb]), s_x its diagonal blocks.
+template <typename T, int NT>
+__device__ __forceinline__ void factor_block64_core(T* __restrict__ M, int p_pad, int r0, T* __restrict__ Dg,
+                                                    const double* __restrict__ diag0, double piv_tol,
+                                                    int32_t* __restrict__ info, T* s_t, T* s_x, int tid) {
+  const int lane = tid & 63, w = tid >> 6;
+  T* const s_dd = s_x + 4 * 16 * XD_LD;
+  int bad = 0;
+#pragma unroll 1
+  for (int kb = 0; kb < 4; ++kb) {
+    T* const blk = s_t + (16 * kb) * DI_LD + 16 * kb;
+    T* const inv = s_x + kb * 16 * XD_LD;
+    if (w == 0) wave_factor16<T>(blk, inv, s_dd, diag0 + r0 + 16 * kb, piv_tol, lane, bad);
+    __syncthreads();
+    FSTAMP(2 + 3 * kb);
+    // (2): 3 - kb panel tiles and kb inverse tiles: three tiles in all, one per wave
+    if (w < 3) {
+      if (w < 3 - kb) {
+        const int ib = kb + 1 + w;           // L[ib][kb] = T[ib][kb] * Ld^-T, in place
+        T* tb = s_t + (16 * ib) * DI_LD + 16 * kb;
+        tile16_mma<T>(tb, DI_LD, inv, XD_LD, true, tb, DI_LD, false, (T)1, lane);
+      } else {
+        const int jb = w - (3 - kb);         // X[kb][jb] = Ld^-1 * Y[kb][jb], in place (stored at block (jb, kb))
+        T* yb = s_t + (16 * jb) * DI_LD + 16 * kb;
+        tile16_mma<T>(inv, XD_LD, yb, DI_LD, false, yb, DI_LD, false, (T)1, lane);
+      }
+    }
+    __syncthreads();
+    FSTAMP(3 + 3 * kb);
+    if (kb == 3) break;
+    // (3): trailing tiles (ib >= jb > kb) and Y tiles (ib > kb, jb <= kb), dealt round-robin to the four waves
+    {
+      int t = 0;
+      for (int ib = kb + 1; ib < 4; ++ib) {
+        const T* lik = s_t + (16 * ib) * DI_LD + 16 * kb;
+        for (int jb = kb + 1; jb <= ib; ++jb, ++t)
+          if ((t & 3) == w)                  // T[ib][jb] -= L[ib][kb] * L[jb][kb]^T
+            tile16_mma<T>(lik, DI_LD, s_t + (16 * jb) * DI_LD + 16 * kb, DI_LD, true,
+                          s_t + (16 * ib) * DI_LD + 16 * jb, DI_LD, true, (T)-1, lane);
+        for (int jb = 0; jb <= kb; ++jb, ++t)
+          if ((t & 3) == w) {                // Y[ib][jb] -= L[ib][kb] * X[kb][jb]
+            const T* xb = (jb == kb) ? inv : s_t + (16 * jb) * DI_LD + 16 * kb;
+            tile16_mma<T>(lik, DI_LD, xb, (jb == kb) ? XD_LD : DI_LD, false,
+                          s_t + (16 * jb) * DI_LD + 16 * ib, DI_LD, true, (T)-1, lane);
+          }
+      }
+    }
+    __syncthreads();
+    FSTAMP(4 + 3 * kb);
+  }
+  // store L (lower) and its inverse (lower; off-diagonal blocks from the upper block positions), 16-byte vectors
+  {
+    typedef typename Tr<T>::vec_t vec_t;
+    constexpr int VE = Tr<T>::VE, VPR = 64 / VE, NV = 4096 / VE;
+#pragma unroll
+    for (int qq = 0; qq < NV / NT; ++qq) {
+      const int idx = tid + NT * qq;
+      const int row = idx / VPR, col = VE * (idx % VPR), rb = row >> 4, cb = col >> 4;
+      vec_t xv = Tr<T>::vzero();
+      if (cb <= rb) {
+        *reinterpret_cast<vec_t*>(M + cm_off(p_pad, r0 + row, r0 + col)) = Tr<T>::lds_load(s_t + row * DI_LD + col);
+#pragma unroll
+        for (int e = 0; e < VE; ++e)
+          xv[e] = (cb < rb) ? s_t[(16 * cb + (row & 15)) * DI_LD + 16 * rb + ((col + e) & 15)]
+                            : s_x[(rb * 16 + (row & 15)) * XD_LD + ((col + e) & 15)];
+      }
+      *reinterpret_cast<vec_t*>(Dg + row * 64 + col) = xv;
+    }
+  }
+  FSTAMP(14);
+  if (w == 0 && bad && lane == 0) atomicOr(&info[0], 1);
+}
+
+template <typename T, int NT>
+__device__ __forceinline__ void factor_block64(T* __restrict__ M, int p_pad, int r0, T* __restrict__ Dg,
+                                               const double* __restrict__ diag0, double piv_tol,
+                                               int32_t* __restrict__ info, T* s_t, T* s_x, int tid) {
+  factor_block64_load<T, NT>(M, p_pad, r0, s_t, tid);
+  factor_block64_core<T, NT>(M, p_pad, r0, Dg, diag0, piv_tol, info, s_t, s_x, tid);
+}
+
 // Factor the 128 x 128 diagonal block at (r0, r0) in place; inverses of its two 64 x 64 diagonal
-// factors to Dg[0..4095] and Dg[4096..8191].  NT threads (the first 256 work); s_a: >= 64 * DI_LD
-// elements of LDS.
+// factors to Dg[0..4095] and Dg[4096..8191].  256 threads; s_a: >= 64 * DI_LD elements of LDS, s_x: >= FB_SX_ELEMS.
+// Everything between the two 64 x 64 factorisations stays on chip: A21 is fetched (into the registers that
+// will be the B operand) before the first one starts, L11^-1 is read where that factorisation left it in
+// LDS, and A22's update  -= L21 L21^T  is applied to its LDS copy, not to memory.
 template <typename T, int NT = 256>
 __device__ __forceinline__ void factor_diag128(T* __restrict__ M, int p_pad, int r0, T* __restrict__ Dg,
                                                const double* __restrict__ diag0, double piv_tol,
-                                               int32_t* __restrict__ info, T* s_a, int tid) {
+                                               int32_t* __restrict__ info, T* s_a, T* s_x, int tid) {
+  static_assert(NT == 256, "four waves");
   typedef typename Tr<T>::acc_t acc_t;
   const int lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-  const bool active = tid < 256;
-  eliminate_block64<T>(M, p_pad, r0, Dg, diag0, piv_tol, info, reinterpret_cast<ElimScratch<T>*>(s_a), tid,
-                       active);
-  __threadfence_block();
-  __syncthreads();
-  // L21^T = L11^-1 A21^T : wave w < 4 owns rows i = 16 w + l15 of A21; the tile loaded as
-  // (k = 16 x + acc_row, i) is the B operand
-  load_block64<T, NT>(s_a, Dg, tid);
+  // A21 tile of wave w: rows i = 16 w + l15, loaded as (k = 16 x + acc_row, i) = the B operand of L11^-1 A21^T
   acc_t c[4], o[4];
-  if (active) {
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+  for (int x = 0; x < 4; ++x)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        c[x][r] = M[cm_off(p_pad, r0 + NB + 16 * w + l15, r0 + 16 * x + Tr<T>::acc_row(l4, r))];
+    for (int r = 0; r < 4; ++r)
+      c[x][r] = M[cm_off(p_pad, r0 + NB + 16 * w + l15, r0 + 16 * x + Tr<T>::acc_row(l4, r))];
+  Block64Regs<T, NT> a22;   // fetched now, needed after the first factorisation: its latency is off the critical path
+  factor_block64_fetch<T, NT>(a22, M, p_pad, r0 + NB, tid);
+  FSTAMP(16);
+  factor_block64<T, NT>(M, p_pad, r0, Dg, diag0, piv_tol, info, s_a, s_x, tid);
+  FSTAMP(17);
+  // L21^T = L11^-1 A21^T, L11^-1 block (xp, x) read from the upper block (x, xp) of s_a / the diagonal blocks in s_x
+#pragma unroll
+  for (int xp = 0; xp < 4; ++xp) {
+    o[xp] = Tr<T>::zero();
+#pragma unroll
+    for (int x = 0; x <= xp; ++x)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kx = Tr<T>::acc_row(l4, r);
+        const T av = (x < xp) ? s_a[(16 * x + l15) * DI_LD + 16 * xp + kx] : s_x[(16 * xp + l15) * XD_LD + kx];
+        o[xp] = Tr<T>::mfma(av, c[x][r], o[xp]);
+      }
   }
+  FSTAMP(18);
+  __syncthreads();   // L11^-1 has been read by everyone (and stored): the region now takes L21 in operand layout
+#pragma unroll
+  for (int xp = 0; xp < 4; ++xp)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_a[(16 * w + l15) * DI_LD + 16 * xp + Tr<T>::acc_row(l4, r)] = o[xp][r];
   __syncthreads();
-  if (active) {
-#pragma unroll
-    for (int xp = 0; xp < 4; ++xp) {
-      o[xp] = Tr<T>::zero();
-#pragma unroll
-      for (int x = 0; x <= xp; ++x)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          o[xp] = Tr<T>::mfma(s_a[(16 * xp + l15) * DI_LD + 16 * x + Tr<T>::acc_row(l4, r)], c[x][r], o[xp]);
-    }
-  }
-  __syncthreads();   // L11^-1 has been read by everyone; the region now takes L21 in operand layout
-  if (active) {
-#pragma unroll
-    for (int xp = 0; xp < 4; ++xp)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s_a[(16 * w + l15) * DI_LD + 16 * xp + Tr<T>::acc_row(l4, r)] = o[xp][r];
-  }
-  __syncthreads();
+  FSTAMP(19);
   // store L21 (contiguous 16-column row pieces in the chunk-major layout)
   {
     constexpr int VE = Tr<T>::VE, VPR = 64 / VE, NV = 4096 / VE;
@@ -766,26 +1039,37 @@ __device__ __forceinline__ void factor_diag128(T* __restrict__ M, int p_pad, int
           Tr<T>::lds_load(s_a + row * DI_LD + VE * cv);
     }
   }
-  // A22 -= L21 L21^T, lower 16 x 16 tiles of the 4 x 4 grid: 10 tiles over the NT / 64 waves
+  // L21 L21^T, lower 16 x 16 tiles of the 4 x 4 grid: 10 tiles, wave w keeps tiles w, w + 4, w + 8 in registers
+  acc_t u[3];
 #pragma unroll
-  for (int q = 0; q < (10 + NT / 64 - 1) / (NT / 64); ++q) {
-    const int t = w + (NT / 64) * q;
-    if (t >= 10) break;
-    const int ti = kSyrkTi[t], tj = kSyrkTj[t];
-    acc_t u = Tr<T>::zero();
+  for (int q = 0; q < 3; ++q) {
+    const int t = w + 4 * q;
+    u[q] = Tr<T>::zero();
+    if (t < 10) {
+      const int ti = kSyrkTi[t], tj = kSyrkTj[t];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
-      u = Tr<T>::mfma(s_a[(16 * ti + l15) * DI_LD + 4 * kk + l4], s_a[(16 * tj + l15) * DI_LD + 4 * kk + l4], u);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * ti + Tr<T>::acc_row(l4, r), col = 16 * tj + l15;
-      if (col <= row) M[cm_off(p_pad, r0 + NB + row, r0 + NB + col)] -= u[r];
+      for (int kk = 0; kk < 16; ++kk)
+        u[q] = Tr<T>::mfma(s_a[(16 * ti + l15) * DI_LD + 4 * kk + l4], s_a[(16 * tj + l15) * DI_LD + 4 * kk + l4],
+                           u[q]);
     }
   }
-  __threadfence_block();
+  FSTAMP(20);
+  __syncthreads();   // L21 has been read: the region takes A22
+  factor_block64_put<T, NT>(a22, s_a, tid);
+  FSTAMP(21);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int t = w + 4 * q;
+    if (t < 10) {
+      const int ti = kSyrkTi[t], tj = kSyrkTj[t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_a[(16 * ti + Tr<T>::acc_row(l4, r)) * DI_LD + 16 * tj + l15] -= u[q][r];
+    }
+  }
   __syncthreads();
-  eliminate_block64<T>(M, p_pad, r0 + NB, Dg + 4096, diag0, piv_tol, info,
-                       reinterpret_cast<ElimScratch<T>*>(s_a), tid, active);
+  FSTAMP(22);
+  factor_block64_core<T, NT>(M, p_pad, r0 + NB, Dg + 4096, diag0, piv_tol, info, s_a, s_x, tid);
+  FSTAMP(23);
 }
 
 template <typename T>
@@ -794,11 +1078,11 @@ __global__ __launch_bounds__(256, 2) void chol_diag2_kernel(T* __restrict__ A, T
                                                             int32_t* __restrict__ info, int p_pad, int Jo,
                                                             int nblk) {
   __shared__ __attribute__((aligned(16))) T s_a[64 * DI_LD];
-  static_assert(sizeof(ElimScratch<T>) <= sizeof(T) * 64 * DI_LD, "elimination scratch must fit");
+  __shared__ __attribute__((aligned(16))) T s_x[FB_SX_ELEMS];
   const int mt = blockIdx.x;
   T* M = A + (int64_t)mt * p_pad * p_pad;
   factor_diag128<T>(M, p_pad, Jo * 128, Dinv + ((int64_t)mt * nblk + 2 * Jo) * 4096,
-                    diag0 + (int64_t)mt * p_pad, piv_tol, info, s_a, threadIdx.x);
+                    diag0 + (int64_t)mt * p_pad, piv_tol, info, s_a, s_x, threadIdx.x);
 }
 
 // Workgroup of NT threads (NT / 64 waves): wave w owns tile rows RW w .. RW w + RW - 1 (RW = 128 / waves)
@@ -821,6 +1105,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
   __shared__ __attribute__((aligned(16))) T s_a[2 * 128 * RK_LD];
   __shared__ __attribute__((aligned(16))) T s_b[128 * RK_LD];
   static_assert(2 * 128 * RK_LD >= 64 * DI_LD, "a 64 x 64 block must fit region A");
+  static_assert(128 * RK_LD >= FB_SX_ELEMS, "the diagonal factorisation's side buffer must fit region B");
   static_assert(sizeof(ElimScratch<T>) <= sizeof(T) * 64 * DI_LD, "elimination scratch must fit region A");
   T* const s_rkj = s_a;
   T* const s_rki = s_a + 128 * RK_LD;
@@ -1043,7 +1328,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
     __threadfence_block();
     __syncthreads();
     factor_diag128<T, NT>(M, p_pad, I0, Dinv + ((int64_t)mt * nblk + 2 * (Jo + 1)) * 4096,
-                          diag0 + (int64_t)mt * p_pad, piv_tol, info, s_a, tid);
+                          diag0 + (int64_t)mt * p_pad, piv_tol, info, s_a, s_b, tid);
   }
 }
 
