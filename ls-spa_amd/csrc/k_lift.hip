@@ -23,8 +23,15 @@ __global__ __launch_bounds__(256) void lift_partial_kernel(LiftArgs a) {
   __shared__ double s_E[4][16 * TT_LD];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int ord = blockIdx.x;
-  const int strip = blockIdx.y * 4 + w;
   const int nstrips = a.m_pad / 64;
+  // Strip of wave w.  In tri mode a strip only has the rows below its first column, so its work falls off
+  // linearly with its index: deal the strips so that every workgroup gets the same total -- wave 0 walks
+  // up from the left, wave 1 down from the middle, wave 2 up from the middle, wave 3 down from the right.
+  int strip = blockIdx.y * 4 + w;
+  if (a.tri && (nstrips % 4) == 0) {
+    const int nwg = nstrips / 4, y = blockIdx.y;
+    strip = (w == 0) ? y : (w == 1) ? 2 * nwg - 1 - y : (w == 2) ? 2 * nwg + y : 4 * nwg - 1 - y;
+  }
   if (strip >= nstrips) return;  // whole wave leaves; no workgroup barrier below
   const int cs = strip * 64;
   const int p = a.p, p_pad = a.p_pad, m_pad = a.m_pad;
@@ -105,6 +112,33 @@ __global__ __launch_bounds__(256) void lift_finish_kernel(LiftArgs a) {
   }
 }
 
+// The same for antithetical pairs laid out back to back (ordering 2 s + 1 = ordering 2 s reversed): position j
+// of the first ordering and position p - 1 - j of the second are the same feature, so one thread adds both
+// contributions and no ordering of writes is needed -- the work spreads over (sample, 256 positions) workgroups.
+template <typename T>
+__global__ __launch_bounds__(256) void lift_finish_paired_kernel(LiftArgs a) {
+  const int sample = blockIdx.x;
+  const int j = blockIdx.y * 256 + threadIdx.x;
+  const int nstrips = a.m_pad / 64;
+  const int p = a.p, p_pad = a.p_pad;
+  if (j >= p) return;
+  const double wgt = 0.5 / a.y_norm_sq;
+  const int ord = 2 * sample;
+  const int j2 = p - 1 - j;
+  const T* L0 = static_cast<const T*>(a.A) + (int64_t)ord * p_pad * p_pad;
+  const T* L1 = L0 + (int64_t)p_pad * p_pad;
+  const double* P0 = a.Ppart + (int64_t)ord * nstrips * p_pad;
+  const double* P1 = P0 + (int64_t)nstrips * p_pad;
+  double s0 = 0.0, s1 = 0.0;
+  for (int t = 0; t < nstrips; ++t) {
+    s0 += P0[(int64_t)t * p_pad + j];
+    s1 += P1[(int64_t)t * p_pad + j2];
+  }
+  const double v0 = (double)L0[cm_off(p_pad, p, j)] * s0 * wgt;
+  const double v1 = (double)L1[cm_off(p_pad, p, j2)] * s1 * wgt;
+  a.lifts[(int64_t)sample * p + a.perms[(int64_t)ord * p + j]] = v0 + v1;
+}
+
 hipError_t launch_lift(const LiftArgs& a, hipStream_t st) {
   if (a.p < 1 || a.p_pad % NB != 0 || a.m_pad % 128 != 0 || a.n_ord < 1 ||
       (a.per_sample != 1 && a.per_sample != 2) || a.n_ord % a.per_sample != 0 || !(a.y_norm_sq > 0.0))
@@ -116,7 +150,13 @@ hipError_t launch_lift(const LiftArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(lift_partial_kernel<double>, g1, dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (a.f32)
+  if (a.per_sample == 2 && a.paired) {
+    const dim3 g3(a.n_ord / 2, (a.p + 255) / 256);
+    if (a.f32)
+      hipLaunchKernelGGL(lift_finish_paired_kernel<float>, g3, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(lift_finish_paired_kernel<double>, g3, dim3(256), 0, st, a);
+  } else if (a.f32)
     hipLaunchKernelGGL(lift_finish_kernel<float>, g2, dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL(lift_finish_kernel<double>, g2, dim3(256), 0, st, a);

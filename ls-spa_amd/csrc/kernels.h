@@ -64,6 +64,7 @@ struct LiftArgs {
   double y_norm_sq;
   int p, p_pad, m_pad, n_ord, per_sample, tri;  // per_sample = 1 or 2 orderings per sample
   int f32;
+  int paired;              // per_sample == 2 and ordering 2 s + 1 is ordering 2 s reversed
 };
 hipError_t launch_lift(const LiftArgs& a, hipStream_t st);
 

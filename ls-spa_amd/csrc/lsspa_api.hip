@@ -435,6 +435,7 @@ int run_slice(lsspa_ctx* ctx, int ord_off, int n_ord, int per_sample, int s_off,
     la.n_ord = n_ord;
     la.per_sample = per_sample;
     la.tri = ctx->tri;
+    la.paired = (per_sample == 2) ? 1 : 0;   // stage_and_run builds the second ordering as the reverse of the first
     HIPCHK(launch_lift(la, st));
   }
   return LSSPA_OK;
