@@ -131,10 +131,23 @@ def main():
     if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if rehearse:
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner on stdout when its first communicator comes up; stdout is reserved
+        # for the one JSON line, so park fd 1 on stderr until the communicator exists
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if rehearse:
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         # engine kernels, the all-reduce and the merge share one torch stream: no host sync per step
         tstream, eng_stream = TorchComm.make_stream(dev)
         comm = TorchComm(stream=tstream, force_collective=rehearse)
