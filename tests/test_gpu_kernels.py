@@ -256,3 +256,22 @@ def test_wide_strip_variant(engine, p, n, m):
     finally:
         engine.set_flags(0)
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("p,n,m", [(100, 400, 300), (257, 900, 700), (70, 300, 40)])
+def test_two_level_kernels_agree_with_one_level_path(engine, p, n, m):
+    """Two independent implementations of the factorisation and the solve live in the library: the two-level
+    kernels (default) and the one-level ones (developer flags 4 | 8 | 2048-free path).  Same inputs, same
+    lifts to round-off; the paired / unpaired gather (flag 256) likewise."""
+    Xa, Xe, ya, ye = problem(13, p, n, m)
+    engine.load_data(Xa, Xe, ya, ye, 1e-3)
+    rng = np.random.default_rng(8)
+    perms = np.array([rng.permutation(p) for _ in range(6)])
+    base = engine.run_batch(perms, True, want_lifts=True, accumulate=False)
+    try:
+        for flags in (4 | 8, 256, 4 | 8 | 256 | 2):
+            engine.set_flags(flags)
+            other = engine.run_batch(perms, True, want_lifts=True, accumulate=False)
+            np.testing.assert_allclose(other, base, rtol=0, atol=5e-13)
+    finally:
+        engine.set_flags(0)
