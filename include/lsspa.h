@@ -152,7 +152,12 @@ int lsspa_profile_enable(lsspa_ctx* ctx, int32_t on);
 int lsspa_profile_get(lsspa_ctx* ctx, int32_t kernel_class, double* total_ms, int64_t* launches);
 int lsspa_profile_reset(lsspa_ctx* ctx);
 
-/* developer switch for in-process A/B timing of kernel variants (0 = shipped configuration) */
+/* developer switches for in-process A/B timing and cross-checks of kernel variants (0 = shipped configuration):
+ *     2  one-level path only: stand-alone diagonal-block launches instead of the fused ones
+ *     4  one-level strip kernel (64-row steps)          8  one-level panel / diagonal kernels (64-wide panels)
+ *    32  two half-batches on two streams               64  plain (matrix, tile) dispatch order in the panel kernel
+ *   256  unpaired gather                              512  256-column strips (512-thread workgroups)
+ * Every combination computes the same lifts (tests/test_gpu_kernels.py). */
 int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);
 
 /* test hooks */
