@@ -275,3 +275,26 @@ def test_two_level_kernels_agree_with_one_level_path(engine, p, n, m):
             np.testing.assert_allclose(other, base, rtol=0, atol=5e-13)
     finally:
         engine.set_flags(0)
+
+
+@pytest.mark.parametrize("anti", [False, True])
+def test_batch_larger_than_the_workspace_is_split(engine, anti):
+    """More orderings in one call than a launch sequence holds (4096): the batch is cut into sub-batches
+    that share the pinned staging buffers; lifts and accumulated statistics must not notice."""
+    p = 12
+    Xa, Xe, ya, ye = problem(17, p, 80, 60)
+    red = O.reduce(Xa, Xe, ya, ye, 0.0)
+    yy = float(ye @ ye)
+    rng = np.random.default_rng(9)
+    n = 4500 if not anti else 2300
+    perms = np.array([rng.permutation(p) for _ in range(n)])
+    engine.load_data(Xa, Xe, ya, ye, 0.0)
+    got = engine.run_batch(perms, anti, want_lifts=True, accumulate=True)
+    engine.merge()
+    idx = rng.choice(n, 60, replace=False)
+    want = np.array([O.sample_lift(*red, yy, perms[i], anti) for i in idx])
+    np.testing.assert_allclose(got[idx], want, rtol=0, atol=1e-11)
+    cnt, mean, cov = engine.stats()
+    assert cnt == n
+    np.testing.assert_allclose(mean, got.mean(0), rtol=0, atol=1e-13)
+    np.testing.assert_allclose(cov, np.cov(got, rowvar=False, bias=True), rtol=0, atol=1e-13)
