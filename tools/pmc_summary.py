@@ -19,7 +19,7 @@ def load(d):
 
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
 per_batch = {"gather_kernel": 1, "chol_diag2_kernel": 1, "chol_panel2_kernel": 7, "strip2_kernel": 1,
-             "lift_partial_kernel": 1, "lift_finish_kernel": 1, "stats_batch_kernel": 1}
+             "lift_partial_kernel": 1, "lift_finish_paired_kernel": 1, "stats_batch_kernel": 1}
 rows, traffic = [], {}
 for k, n in per_batch.items():
     f = sum(fetch[k][-n:]) * 1024.0
