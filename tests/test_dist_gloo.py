@@ -35,8 +35,27 @@ def _worker(rank, world, port, out_dir):
     shard = ls_spa(d[0][rank::world], d[1][rank::world], d[2][rank::world], d[3][rank::world],
                    perms=g["perms64"][:20], batch_size=16, tolerance=0.0, row_sharded=True,
                    _engine=eng3, _comm=TorchComm())
+    # only the training rows sharded, every rank holds all test rows
+    eng4 = OracleEngine()
+    shard_tr = ls_spa(d[0][rank::world], d[1], d[2][rank::world], d[3], perms=g["perms64"][:20], batch_size=16,
+                      tolerance=0.0, row_sharded="train", _engine=eng4, _comm=TorchComm())
+    # checkpoint / resume with two ranks: one state file per rank, killed in the third batch, resumed
+    class Dies(OracleEngine):
+        def run_batch(self, *a, **k):
+            if len(self.calls) == 2:
+                raise KeyboardInterrupt
+            return super().run_batch(*a, **k)
+    ck = os.path.join(out_dir, "state.npz")
+    kw = dict(perms=None, method="argsort", seed=3, max_samples=80, batch_size=16, tolerance=0.0,
+              error_estimator="device")
+    try:
+        ls_spa(*d, checkpoint=ck, _engine=Dies(), _comm=TorchComm(), **kw)
+    except KeyboardInterrupt:
+        pass
+    resumed = ls_spa(*d, checkpoint=ck, _engine=OracleEngine(), _comm=TorchComm(), **kw)
     np.savez(os.path.join(out_dir, f"s{rank}.npz"), attribution=shard.attribution, theta=shard.theta,
-             r2=shard.r_squared)
+             r2=shard.r_squared, attribution_tr=shard_tr.attribution, res_attr=resumed.attribution,
+             res_err=resumed.error_history, ck_exists=os.path.exists(ck + f".rank{rank}"))
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), attribution=res.attribution,
              history=res.attribution_history, err=res.error_history, calls=np.array(eng.calls),
              dev_err=dev.error_history, dev_feat=dev.attribution_errors, dev_rows=eng2.history_count())
@@ -77,4 +96,13 @@ def test_two_ranks_match_single_process(tmp_path):
         np.testing.assert_allclose(s["attribution"], full.attribution, rtol=0, atol=1e-11)
         np.testing.assert_allclose(s["theta"], full.theta, rtol=1e-9)
         assert abs(float(s["r2"]) - full.r_squared) < 1e-11
+        np.testing.assert_allclose(s["attribution_tr"], full.attribution, rtol=0, atol=1e-11)
+        assert bool(s["ck_exists"])
+    # two-rank resume == uninterrupted single-process run with the same sampler and estimator
+    straight = ls_spa(*d, method="argsort", seed=3, max_samples=80, batch_size=16, tolerance=0.0,
+                      error_estimator="lowrank", _engine=OracleEngine())
+    for rk in (0, 1):
+        s = np.load(tmp_path / f"s{rk}.npz")
+        np.testing.assert_allclose(s["res_attr"], straight.attribution, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(s["res_err"], straight.error_history, rtol=1e-9)
     # and the reference itself agrees (fixture made from it on the first 48... full 64 run differs)
