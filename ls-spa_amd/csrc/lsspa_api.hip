@@ -62,6 +62,12 @@ struct lsspa_ctx {
   bool perms_busy[2] = {false, false};
   int perms_turn = 0;
   size_t perms_h_count = 0;
+  // the device side is double-buffered too ([2][cap_ord][p]) and fed by a copy stream, so the H2D copy of
+  // batch k+1 runs under the kernels of batch k instead of between two batches on the compute stream
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t perms_used[2] = {nullptr, nullptr};   // the kernels that read device slot b have run
+  bool perms_used_valid[2] = {false, false};
+  const int32_t* perms_cur = nullptr;              // device slot of the batch being launched
 
   // running statistics
   DevBuf<double> mean, M2, pend, state_n;
@@ -274,7 +280,7 @@ size_t bytes_per_ordering(const lsspa_ctx* ctx) {
   const size_t es = ctx->esz();
   return nm * pp * pp * es + (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad) * es +
          nm * nblk * 4096 * es + nm * pp * 8 +
-         (size_t)(ctx->m_pad / 64) * pp * 8 + (size_t)ctx->p * 4;
+         (size_t)(ctx->m_pad / 64) * pp * 8 + (size_t)ctx->p * 8;
 }
 
 int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
@@ -307,7 +313,8 @@ int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
       TRY(dev_alloc(ctx, ctx->Dinv, nm * cap * nblk * 4096 * es));
       TRY(dev_alloc(ctx, ctx->diag0, nm * cap * pp));
       TRY(dev_alloc(ctx, ctx->Ppart, (size_t)cap * (ctx->m_pad / 64) * pp));
-      TRY(dev_alloc(ctx, ctx->perms_d, (size_t)cap * ctx->p));
+      TRY(dev_alloc(ctx, ctx->perms_d, (size_t)2 * cap * ctx->p));
+      ctx->perms_used_valid[0] = ctx->perms_used_valid[1] = false;
       ctx->cap_ord = cap;
     }
   }
@@ -349,7 +356,7 @@ int run_slice(lsspa_ctx* ctx, int ord_off, int n_ord, int per_sample, int s_off,
   double* const diag0_s = ctx->diag0.ptr + (size_t)ord_off * n_src * p_pad;
   char* const V_s = ctx->V.ptr + (size_t)ord_off * (size_t)v_rows_of(p) * (size_t)ldv_of(m_pad) * es;
   double* const Ppart_s = ctx->Ppart.ptr + (size_t)ord_off * (m_pad / 64) * p_pad;
-  const int32_t* const perms_s = ctx->perms_d.ptr + (size_t)ord_off * p;
+  const int32_t* const perms_s = ctx->perms_cur + (size_t)ord_off * p;
   const bool timed = (st == ctx->stream);   // the profiling events live on the context's stream
   {
     ProfScope ps(timed ? ctx : nullptr, LSSPA_K_GATHER);
@@ -487,11 +494,22 @@ int stage_and_run(lsspa_ctx* ctx, const int32_t* perms, int n_samples, int per_s
       for (int j = 0; j < p; ++j) d1[j] = src[p - 1 - j];
     }
   }
-  HIPCHK(hipMemcpyAsync(ctx->perms_d.ptr, hp, sizeof(int32_t) * (size_t)n_ord * p, hipMemcpyHostToDevice,
-                        ctx->stream));
-  HIPCHK(hipEventRecord(ctx->perms_ev[turn], ctx->stream));
+  if (!ctx->copy_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) HIPCHK(hipEventCreateWithFlags(&ctx->perms_used[b], hipEventDisableTiming));
+  }
+  int32_t* dp = ctx->perms_d.ptr + (size_t)turn * ctx->cap_ord * p;
+  if (ctx->perms_used_valid[turn]) HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->perms_used[turn], 0));
+  HIPCHK(hipMemcpyAsync(dp, hp, sizeof(int32_t) * (size_t)n_ord * p, hipMemcpyHostToDevice, ctx->copy_stream));
+  HIPCHK(hipEventRecord(ctx->perms_ev[turn], ctx->copy_stream));
   ctx->perms_busy[turn] = true;
-  return run_orderings(ctx, n_ord, per_sample, s_off);
+  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->perms_ev[turn], 0));
+  ctx->perms_cur = dp;
+  const int rc = run_orderings(ctx, n_ord, per_sample, s_off);
+  if (rc != LSSPA_OK) return rc;
+  HIPCHK(hipEventRecord(ctx->perms_used[turn], ctx->stream));
+  ctx->perms_used_valid[turn] = true;
+  return LSSPA_OK;
 }
 
 bool is_permutation(const int32_t* perm, int p, std::vector<char>& seen) {
@@ -568,6 +586,11 @@ int lsspa_destroy(lsspa_ctx* ctx) {
   dev_free(ctx->Ppart); dev_free(ctx->lifts); dev_free(ctx->diag0); dev_free(ctx->perms_d); dev_free(ctx->info_d);
   dev_free(ctx->mean); dev_free(ctx->M2); dev_free(ctx->pend); dev_free(ctx->state_n);
   dev_free(ctx->Cred);
+  if (ctx->copy_stream) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamDestroy(ctx->copy_stream);
+    for (int b = 0; b < 2; ++b) (void)hipEventDestroy(ctx->perms_used[b]);
+  }
   if (ctx->side_stream) {
     (void)hipStreamSynchronize(ctx->side_stream);
     (void)hipStreamDestroy(ctx->side_stream);
