@@ -168,10 +168,12 @@ hipError_t launch_lift(const LiftArgs& a, hipStream_t st) {
 //   buf[0] (+)= n_s ;  buf[1+a] (+)= sum_s D[s][a] ;  buf[1+p+a*p+b] (+)= sum_s D[s][a] D[s][b]
 // 64 x 64 output tile per workgroup, 16 samples staged per step.
 // ---------------------------------------------------------------------------------------
+// With few 64 x 64 tiles (small p) the samples are cut into gridDim.z slices; slice z writes its moments to
+// parts + z * (1 + p + p*p) and stats_reduce_kernel adds the slices in a fixed order (no float atomics).
 __global__ __launch_bounds__(256) void stats_batch_kernel(const double* __restrict__ lifts,
                                                           const double* __restrict__ mean,
                                                           double* __restrict__ buf, int n_samples, int p,
-                                                          int accumulate) {
+                                                          int accumulate, int per_slice) {
   __shared__ double sa[16][65];
   __shared__ double sb[16][65];
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
@@ -183,6 +185,14 @@ __global__ __launch_bounds__(256) void stats_batch_kernel(const double* __restri
     for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
   double colsum[4] = {0.0, 0.0, 0.0, 0.0};
   const bool do_sum = (blockIdx.x == 0);  // column sums once per a-tile
+  const int s_lo = blockIdx.z * per_slice;
+  const int s_hi = min(n_samples, s_lo + per_slice);
+  if (gridDim.z > 1) {
+    buf += (int64_t)blockIdx.z * ((int64_t)1 + p + (int64_t)p * p);
+    accumulate = 0;
+  }
+  lifts += (int64_t)s_lo * p;
+  n_samples = max(0, s_hi - s_lo);
 
   for (int s0 = 0; s0 < n_samples; s0 += 16) {
     __syncthreads();
@@ -233,12 +243,35 @@ __global__ __launch_bounds__(256) void stats_batch_kernel(const double* __restri
     buf[0] = accumulate ? buf[0] + (double)n_samples : (double)n_samples;
 }
 
+__global__ __launch_bounds__(256) void stats_reduce_kernel(const double* __restrict__ parts, int n_parts,
+                                                           int64_t len, double* __restrict__ buf, int accumulate) {
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < len; o += (int64_t)gridDim.x * 256) {
+    double s = 0.0;
+    for (int z = 0; z < n_parts; ++z) s += parts[(int64_t)z * len + o];
+    buf[o] = accumulate ? buf[o] + s : s;
+  }
+}
+
+int stats_batch_slices(int n_samples, int p) {
+  const int nt = (p + 63) / 64;
+  int z = 512 / (nt * nt);                       // aim at ~2 workgroups per CU
+  z = z < (n_samples + 63) / 64 ? z : (n_samples + 63) / 64;   // at least 64 samples per slice
+  return z < 1 ? 1 : z;
+}
+
 hipError_t launch_stats_batch(const double* lifts, const double* mean, double* buf, int n_samples, int p,
-                              int accumulate, hipStream_t st) {
+                              int accumulate, double* parts, hipStream_t st) {
   if (n_samples < 1 || p < 1) return hipErrorInvalidValue;
   const int nt = (p + 63) / 64;
-  hipLaunchKernelGGL(stats_batch_kernel, dim3(nt, nt), dim3(256), 0, st, lifts, mean, buf, n_samples, p,
-                     accumulate);
+  const int nz = parts ? stats_batch_slices(n_samples, p) : 1;
+  const int per = (((n_samples + nz - 1) / nz + 15) / 16) * 16;
+  hipLaunchKernelGGL(stats_batch_kernel, dim3(nt, nt, nz), dim3(256), 0, st, lifts, mean, nz > 1 ? parts : buf,
+                     n_samples, p, accumulate, per);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || nz == 1) return e;
+  const int64_t len = (int64_t)1 + p + (int64_t)p * p;
+  const int grid = (int)((len + 255) / 256 < 1024 ? (len + 255) / 256 : 1024);
+  hipLaunchKernelGGL(stats_reduce_kernel, dim3(grid), dim3(256), 0, st, parts, nz, len, buf, accumulate);
   return hipGetLastError();
 }
 

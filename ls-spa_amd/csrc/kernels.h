@@ -69,8 +69,10 @@ struct LiftArgs {
 hipError_t launch_lift(const LiftArgs& a, hipStream_t st);
 
 // pending-batch moments about the current running mean: buf = [n_b, S (p), Q (p x p)]
+// parts: workspace of stats_batch_slices(n_samples, p) * (1 + p + p*p) doubles (or NULL: one slice)
+int stats_batch_slices(int n_samples, int p);
 hipError_t launch_stats_batch(const double* lifts, const double* mean, double* buf, int n_samples, int p,
-                              int accumulate, hipStream_t st);
+                              int accumulate, double* parts, hipStream_t st);
 // Chan merge of the pending batch into (n, mean, M2); n lives in state[0]
 hipError_t launch_stats_merge(const double* buf, double* state_n, double* mean, double* M2, int p,
                               hipStream_t st);

@@ -70,7 +70,7 @@ struct lsspa_ctx {
   const int32_t* perms_cur = nullptr;              // device slot of the batch being launched
 
   // running statistics
-  DevBuf<double> mean, M2, pend, state_n;
+  DevBuf<double> mean, M2, pend, state_n, stat_parts;
   bool pend_dirty = false;
   // history of lift vectors + device-side error estimator
   DevBuf<double> hist, xi_d, draws, err_out;
@@ -586,6 +586,7 @@ int lsspa_destroy(lsspa_ctx* ctx) {
   dev_free(ctx->Ppart); dev_free(ctx->lifts); dev_free(ctx->diag0); dev_free(ctx->perms_d); dev_free(ctx->info_d);
   dev_free(ctx->mean); dev_free(ctx->M2); dev_free(ctx->pend); dev_free(ctx->state_n);
   dev_free(ctx->Cred);
+  dev_free(ctx->stat_parts);
   if (ctx->copy_stream) {
     (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->copy_stream);
@@ -1067,7 +1068,10 @@ int lsspa_lift_batch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t an
   }
   if (accumulate) {
     ProfScope ps(ctx, LSSPA_K_STATS);
+    const int nz = stats_batch_slices(B, p);
+    if (nz > 1) TRY(dev_alloc(ctx, ctx->stat_parts, (size_t)nz * ((size_t)1 + p + (size_t)p * p)));
     HIPCHK(launch_stats_batch(ctx->lifts.ptr, ctx->mean.ptr, ctx->pend.ptr, B, p, ctx->pend_dirty ? 1 : 0,
+                              nz > 1 ? ctx->stat_parts.ptr : nullptr,
                               ctx->stream));
     ctx->pend_dirty = true;
     if (ctx->hist_cap > 0) TRY(hist_append(ctx, ctx->lifts.ptr, B, hipMemcpyDeviceToDevice));
