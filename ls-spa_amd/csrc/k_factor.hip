@@ -71,7 +71,10 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
       for (int j = VE * tid; j < jend; j += VE * 256) {   // VE consecutive j stay inside one 16-column chunk
         vec_t v;
 #pragma unroll
-        for (int e = 0; e < VE; ++e) v[e] = (j + e <= i) ? (T)rowbuf[sperm[j + e]] : (T)0;
+        for (int e = 0; e < VE; ++e) {   // unconditional LDS reads (index clamped), value selected afterwards
+          const double rv = rowbuf[sperm[min(j + e, i)]];
+          v[e] = (j + e <= i) ? (T)rv : (T)0;
+        }
         *reinterpret_cast<vec_t*>(out + cm_off(p_pad, i, j)) = v;
       }
       if (tid == 0) d0[i] = rowbuf[sperm[i]];
@@ -81,7 +84,10 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
         for (int j = VE * tid; j < jend2; j += VE * 256) {
           vec_t v;
 #pragma unroll
-          for (int e = 0; e < VE; ++e) v[e] = (j + e <= i2) ? (T)rowbuf[sperm[p - 1 - (j + e)]] : (T)0;
+          for (int e = 0; e < VE; ++e) {
+            const double rv = rowbuf[sperm[p - 1 - min(j + e, i2)]];
+            v[e] = (j + e <= i2) ? (T)rv : (T)0;
+          }
           *reinterpret_cast<vec_t*>(out2 + cm_off(p_pad, i2, j)) = v;
         }
         if (tid == 0) d02[i2] = rowbuf[sperm[i]];
@@ -1143,8 +1149,8 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
   const int nch = J0 / KCH;
   RKRegs<T, 128, NT> rj = {}, ri = {};
   if (nch > 0) {
-    rk_load<T, 128, NT>(rj, srcJ, CM_LD, tid, 128);
-    rk_load<T, 128, NT>(ri, srcI, CM_LD, tid, 128);
+    rk_load_full<T, 128, NT>(rj, srcJ, CM_LD, tid);
+    rk_load_full<T, 128, NT>(ri, srcI, CM_LD, tid);
   }
 
   // acc[x][y][r] <-> (panel column j = 16 x + acc_row(l4, r), tile row i = RW w + 16 y + l15); holds -C^T.
@@ -1188,8 +1194,8 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
     rk_store<T, 128, NT>(ri, s_rki, tid);
     __syncthreads();
     if (c + 1 < nch) {
-      rk_load<T, 128, NT>(rj, srcJ + (c + 1) * chunk, CM_LD, tid, 128);
-      rk_load<T, 128, NT>(ri, srcI + (c + 1) * chunk, CM_LD, tid, 128);
+      rk_load_full<T, 128, NT>(rj, srcJ + (c + 1) * chunk, CM_LD, tid);
+      rk_load_full<T, 128, NT>(ri, srcI + (c + 1) * chunk, CM_LD, tid);
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -1294,12 +1300,12 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
     const T* srcP = M + cm_off(p_pad, I0, J0);
     RKRegs<T, 128, NT> rp = {};
     __syncthreads();   // all stores above are issued and fenced
-    rk_load<T, 128, NT>(rp, srcP, CM_LD, tid, 128);
+    rk_load_full<T, 128, NT>(rp, srcP, CM_LD, tid);
     for (int c = 0; c < 8; ++c) {
       __syncthreads();
       rk_store<T, 128, NT>(rp, s_out, tid);
       __syncthreads();
-      if (c + 1 < 8) rk_load<T, 128, NT>(rp, srcP + (c + 1) * chunk, CM_LD, tid, 128);
+      if (c + 1 < 8) rk_load_full<T, 128, NT>(rp, srcP + (c + 1) * chunk, CM_LD, tid);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -1433,7 +1439,8 @@ __global__ __launch_bounds__(NT, 2) void strip2_kernel(StripArgs a) {
     RKRegs<T, 128, NT> rl = {};
     KR rv = {};
     if (nch > 0) {
-      rk_load<T, 128, NT>(rl, srcL, CM_LD, tid, rows_valid);
+      if (two) rk_load_full<T, 128, NT>(rl, srcL, CM_LD, tid);
+      else rk_load<T, 128, NT>(rl, srcL, CM_LD, tid, 64);
       kcw_load<T, CW, NT>(rv, srcV, ldv, tid, cols_valid);
     }
     for (int c = 0; c < nch; ++c) {
@@ -1442,7 +1449,8 @@ __global__ __launch_bounds__(NT, 2) void strip2_kernel(StripArgs a) {
       kcw_store<T, CW, NT>(rv, s_kc, tid, cols_valid);
       __syncthreads();
       if (c + 1 < nch) {
-        rk_load<T, 128, NT>(rl, srcL + (c + 1) * chunk, CM_LD, tid, rows_valid);
+        if (two) rk_load_full<T, 128, NT>(rl, srcL + (c + 1) * chunk, CM_LD, tid);
+        else rk_load<T, 128, NT>(rl, srcL + (c + 1) * chunk, CM_LD, tid, 64);
         kcw_load<T, CW, NT>(rv, srcV + (c + 1) * KCH * ldv, ldv, tid, cols_valid);
       }
       // tri: V[k][col] = 0 for col > k: wave w (columns c0 + 32 w ..) sees only zeros while k < c0 + 32 w

@@ -141,6 +141,17 @@ __device__ __forceinline__ void rk_load(RKRegs<T, R, NT>& r, const T* __restrict
   }
 }
 
+// the same for a tile whose R rows all exist: no per-row guard (the guard compiles to an exec-masked branch
+// around every load even when the bound is the literal tile height)
+template <typename T, int R, int NT = 256>
+__device__ __forceinline__ void rk_load_full(RKRegs<T, R, NT>& r, const T* __restrict__ src, int64_t ld, int tid) {
+  typedef RKRegs<T, R, NT> RR;
+  const int c = tid % RR::VPR, row = tid / RR::VPR;
+#pragma unroll
+  for (int q = 0; q < RR::NP; ++q)
+    r.v[q] = *reinterpret_cast<const typename Tr<T>::vec_t*>(src + (int64_t)(row + RR::RPP * q) * ld + Tr<T>::VE * c);
+}
+
 template <typename T, int R, int NT = 256>
 __device__ __forceinline__ void rk_store(const RKRegs<T, R, NT>& r, T* lds, int tid) {
   typedef RKRegs<T, R, NT> RR;
