@@ -334,3 +334,33 @@ def test_checkpoint_resume_on_the_product_path(tmp_path, estimator):
     np.testing.assert_allclose(res.attribution, full.attribution, rtol=0, atol=1e-14)
     np.testing.assert_allclose(res.error_history, full.error_history, rtol=1e-8)
     assert len(res.error_history) == len(full.error_history) == 6   # 32, 64, 96, 128, 159, 160
+
+
+def test_integration_md_stub_runs(golden):
+    """The ctypes stub printed in INTEGRATION.md is executed as written (only the library path is resolved to
+    the in-tree build) and must reproduce the reference's toy attribution."""
+    import os
+    import re
+    from ls_spa import _native
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n# ls_spa/_hip\.py.*?\n(.*?)```", text, re.S).group(1)
+    _native.load()   # resolves the HIP runtime the way the package does
+    code = code.replace('C.CDLL("liblsspa_hip.so")', f'C.CDLL({_native._LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    g = golden("toy")
+    d = data_of(g)
+    eng = ns["Engine"](0)
+    eng.reduce(*d, 0.0)
+    import itertools
+    perms = np.array(list(itertools.permutations(range(3))))
+    lifts = eng.lifts(perms, False)
+    np.testing.assert_allclose(lifts.mean(0), g["attribution"], rtol=0, atol=1e-12)
+    n, mu, cov = eng.stats()
+    assert n == 6
+    np.testing.assert_allclose(mu, g["attribution"], rtol=0, atol=1e-12)
+    th, r2 = eng.full_fit()
+    np.testing.assert_allclose(th, g["theta"], rtol=1e-10)
+    assert abs(r2 - float(g["r_squared"])) < 1e-12
+    ns["_lib"].lsspa_destroy(eng.h)
