@@ -25,11 +25,12 @@ constexpr int GROWS = 16;
 // row p-1-i of the second matrix is  S[pi_i][pi_{p-1-j'}],  j' <= p-1-i : the OTHER end of the same source
 // row that row i of the first matrix takes its entries from.  One staging of the source row in LDS
 // therefore serves both matrices, which halves the row reads.
-template <typename T, bool PAIRED>
+template <typename T, bool PAIRED, typename ST>
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* rowbuf = reinterpret_cast<double*>(smem_raw);                      // [p_pad]
-  int32_t* sperm = reinterpret_cast<int32_t*>(smem_raw + sizeof(double) * a.p_pad);  // [p_pad]
+  ST* rowbuf = reinterpret_cast<ST*>(smem_raw);                                  // [p_pad]
+  int32_t* sperm = reinterpret_cast<int32_t*>(smem_raw + sizeof(ST) * a.p_pad);  // [p_pad]
+  typedef ST st2 __attribute__((ext_vector_type(2)));
   constexpr int VE = Tr<T>::VE;
   typedef typename Tr<T>::vec_t vec_t;
 
@@ -41,7 +42,9 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
   const int i0 = blockIdx.x * GROWS;
   const int p = a.p, p_pad = a.p_pad;
   const int32_t* perm = a.perms + (int64_t)ord * p;
-  const double* S = a.S[src];
+  const ST* S;
+  if constexpr (sizeof(ST) == 8) S = reinterpret_cast<const ST*>(a.S[src]);
+  else S = reinterpret_cast<const ST*>(a.Sf[src]);
   const double* svec = a.s[src];
   T* out = static_cast<T*>(a.A) + (int64_t)mat * p_pad * p_pad;   // chunk-major, see tiles.h
   T* out2 = out + (int64_t)p_pad * p_pad;                           // the reversed ordering's matrix
@@ -58,11 +61,11 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     if (i >= p_pad) break;
     const int jend = min(((i + 1 + NB - 1) / NB) * NB, p_pad);  // zero-fill to the block edge
     if (i < p) {
-      const double* srow = S + (int64_t)sperm[i] * a.ld_src;
+      const ST* srow = S + (int64_t)sperm[i] * a.ld_src;
       __syncthreads();  // previous row's picks are done
       for (int c = 2 * tid; c < p; c += 512) {
         if (c + 1 < p) {
-          *reinterpret_cast<v2d*>(rowbuf + c) = *reinterpret_cast<const v2d*>(srow + c);
+          *reinterpret_cast<st2*>(rowbuf + c) = *reinterpret_cast<const st2*>(srow + c);
         } else {
           rowbuf[c] = srow[c];
         }
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
         vec_t v;
 #pragma unroll
         for (int e = 0; e < VE; ++e) {   // unconditional LDS reads (index clamped), value selected afterwards
-          const double rv = rowbuf[sperm[min(j + e, i)]];
+          const ST rv = rowbuf[sperm[min(j + e, i)]];
           v[e] = (j + e <= i) ? (T)rv : (T)0;
         }
         *reinterpret_cast<vec_t*>(out + cm_off(p_pad, i, j)) = v;
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
           vec_t v;
 #pragma unroll
           for (int e = 0; e < VE; ++e) {
-            const double rv = rowbuf[sperm[p - 1 - min(j + e, i2)]];
+            const ST rv = rowbuf[sperm[p - 1 - min(j + e, i2)]];
             v[e] = (j + e <= i2) ? (T)rv : (T)0;
           }
           *reinterpret_cast<vec_t*>(out2 + cm_off(p_pad, i2, j)) = v;
@@ -118,22 +121,40 @@ hipError_t launch_gather(const GatherArgs& a, hipStream_t st) {
   if (a.p < 1 || a.p_pad % NB != 0 || a.p_pad <= a.p || a.n_ord < 1 || a.n_src < 1 || a.n_src > 2 ||
       (a.ld_src & 1) || (a.paired && (a.n_ord & 1)))
     return hipErrorInvalidValue;
-  const size_t shmem = sizeof(double) * a.p_pad + sizeof(int32_t) * a.p_pad;
+  const bool srcf = a.f32 && a.Sf[0] != nullptr && (a.n_src == 1 || a.Sf[1] != nullptr);
+  const size_t shmem = (srcf ? sizeof(float) : sizeof(double)) * a.p_pad + sizeof(int32_t) * a.p_pad;
   if (shmem > 64 * 1024) return hipErrorInvalidValue;
   dim3 grid((a.p_pad + GROWS - 1) / GROWS, (a.paired ? a.n_ord / 2 : a.n_ord) * a.n_src);
   // aug row reads sperm[j] for all j < p: the workgroup holding row p must have them all
   // (jmax = min(i0 + GROWS, p) = p there), so nothing else to arrange.
   if (a.paired) {
-    if (a.f32)
-      hipLaunchKernelGGL((gather_kernel<float, true>), grid, dim3(256), shmem, st, a);
+    if (srcf)
+      hipLaunchKernelGGL((gather_kernel<float, true, float>), grid, dim3(256), shmem, st, a);
+    else if (a.f32)
+      hipLaunchKernelGGL((gather_kernel<float, true, double>), grid, dim3(256), shmem, st, a);
     else
-      hipLaunchKernelGGL((gather_kernel<double, true>), grid, dim3(256), shmem, st, a);
+      hipLaunchKernelGGL((gather_kernel<double, true, double>), grid, dim3(256), shmem, st, a);
   } else {
-    if (a.f32)
-      hipLaunchKernelGGL((gather_kernel<float, false>), grid, dim3(256), shmem, st, a);
+    if (srcf)
+      hipLaunchKernelGGL((gather_kernel<float, false, float>), grid, dim3(256), shmem, st, a);
+    else if (a.f32)
+      hipLaunchKernelGGL((gather_kernel<float, false, double>), grid, dim3(256), shmem, st, a);
     else
-      hipLaunchKernelGGL((gather_kernel<double, false>), grid, dim3(256), shmem, st, a);
+      hipLaunchKernelGGL((gather_kernel<double, false, double>), grid, dim3(256), shmem, st, a);
   }
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void to_f32_kernel(const double* __restrict__ src, float* __restrict__ dst,
+                                                     int64_t count) {
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < count; o += (int64_t)gridDim.x * 256)
+    dst[o] = (float)src[o];
+}
+
+hipError_t launch_to_f32(const double* src, float* dst, int64_t count, hipStream_t st) {
+  if (count < 1) return hipErrorInvalidValue;
+  const int grid = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
+  hipLaunchKernelGGL(to_f32_kernel, dim3(grid), dim3(256), 0, st, src, dst, count);
   return hipGetLastError();
 }
 

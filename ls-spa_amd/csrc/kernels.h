@@ -13,6 +13,8 @@ namespace lsspa {
 
 struct GatherArgs {
   const double* S[2];      // source Gram matrices (train, test), fp64, row-major, stride ld_src
+  const float* Sf[2];      // optional fp32 copies of S (same stride): read instead of S when the work matrices are
+                           // fp32 -- same values after rounding, half the source traffic
   const double* s[2];      // source right-hand sides (g, h)
   double aug[2];           // diagonal value of the augmented row
   int64_t ld_src;
@@ -25,6 +27,8 @@ struct GatherArgs {
                            // the source rows writes both matrices
 };
 hipError_t launch_gather(const GatherArgs& a, hipStream_t st);
+// dst[i] = (float)src[i]
+hipError_t launch_to_f32(const double* src, float* dst, int64_t count, hipStream_t st);
 
 // Blocked Cholesky.  diag0 / piv_tol: a pivot d counts as non-positive (LSSPA_INFO_NOT_PD) when
 // d <= piv_tol * diag0.  chol_diag factors diagonal block J stand-alone (only block 0 needs it);

@@ -46,6 +46,8 @@ struct lsspa_ctx {
   int p = 0, p_pad = 0, m = 0, m_pad = 0, tri = 0;
   double aug_train = 0.0, y_norm_sq = 0.0;
   DevBuf<double> G, g, H, h, Ft, ytil, scal;
+  DevBuf<float> Gf, Hf;        // fp32 copies of G / H for the fp32 gather, made on first use
+  bool src_f32_valid = false;
 
   // per-batch workspace
   int cap_ord = 0;      // orderings the workspace can hold
@@ -207,6 +209,7 @@ int set_dims(lsspa_ctx* ctx, int p, int m, int tri) {
   if (tri && m != p) return ctx->fail(LSSPA_ERR_ARG, "tri mode needs m == p");
   HIPCHK(hipStreamSynchronize(ctx->stream));  // buffers below may be re-allocated
   ctx->have_problem = false;
+  ctx->src_f32_valid = false;
   ctx->p = p;
   ctx->m = m;
   ctx->tri = tri;
@@ -367,6 +370,21 @@ int run_slice(lsspa_ctx* ctx, int ord_off, int n_ord, int per_sample, int s_off,
     ga.S[1] = ctx->tri ? ctx->H.ptr : nullptr;
     ga.s[1] = ctx->tri ? ctx->h.ptr : nullptr;
     ga.aug[1] = 2.0 * ctx->y_norm_sq + 1.0;
+    ga.Sf[0] = ga.Sf[1] = nullptr;
+    if (ctx->f32) {
+      if (!ctx->src_f32_valid) {
+        const size_t cnt = (size_t)p * p_pad;
+        TRY(dev_alloc(ctx, ctx->Gf, cnt));
+        HIPCHK(launch_to_f32(ctx->G.ptr, ctx->Gf.ptr, (int64_t)cnt, st));
+        if (ctx->tri) {
+          TRY(dev_alloc(ctx, ctx->Hf, cnt));
+          HIPCHK(launch_to_f32(ctx->H.ptr, ctx->Hf.ptr, (int64_t)cnt, st));
+        }
+        ctx->src_f32_valid = true;
+      }
+      ga.Sf[0] = ctx->Gf.ptr;
+      ga.Sf[1] = ctx->tri ? ctx->Hf.ptr : nullptr;
+    }
     ga.ld_src = p_pad;
     ga.perms = perms_s;
     ga.p = p;
@@ -587,6 +605,7 @@ int lsspa_destroy(lsspa_ctx* ctx) {
   dev_free(ctx->mean); dev_free(ctx->M2); dev_free(ctx->pend); dev_free(ctx->state_n);
   dev_free(ctx->Cred);
   dev_free(ctx->stat_parts);
+  dev_free(ctx->Gf); dev_free(ctx->Hf);
   if (ctx->copy_stream) {
     (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->copy_stream);
