@@ -1256,14 +1256,20 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
       for (int xp = 0; xp < 4; ++xp) acc[4 * half + xp][y] = t[xp];
     }
   };
+  // Each 64 x 64 operand block of the solve is fetched into registers one stage ahead and put into LDS when
+  // the previous stage is done with the region.
   const T* Dg = Dinv + ((int64_t)mt * nblk + 2 * Jo) * 4096;
+  DenseBlock64Regs<T, NT> nb;
+  block64_fetch<T, NT>(nb, Dg, tid);
   __syncthreads();  // every wave is done with the operand tiles that region A now loses
-  load_block64<T, NT>(s_dinv, Dg, tid);
+  block64_put<T, NT>(nb, s_dinv, tid);
   __syncthreads();
+  block64_fetch_cm<T, NT>(nb, M, p_pad, J0 + NB, J0, tid);
   tri_mult(0);
   __syncthreads();
-  load_block64_cm<T, NT>(s_dinv, M, p_pad, J0 + NB, J0, tid, false);
+  block64_put<T, NT>(nb, s_dinv, tid);
   __syncthreads();
+  block64_fetch<T, NT>(nb, Dg + 4096, tid);
 #pragma unroll
   for (int xp = 0; xp < 4; ++xp) {
 #pragma unroll
@@ -1277,7 +1283,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
     __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
-  load_block64<T, NT>(s_dinv, Dg + 4096, tid);
+  block64_put<T, NT>(nb, s_dinv, tid);
   __syncthreads();
   tri_mult(1);
 
@@ -1315,7 +1321,11 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
     const int t = ws + NW * q;
     ti[q] = t < 36 ? kSyrkTi[t] : 0;
     tj[q] = t < 36 ? kSyrkTj[t] : 0;
-    upd[q] = Tr<T>::zero();
+    // start from -A[I,I] (unconditional loads: the block's upper triangle exists, its content is never stored):
+    // the reads are in flight under the re-staging loop instead of being a dependent read-modify-write at the end
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      upd[q][r] = -M[cm_off(p_pad, I0 + 16 * ti[q] + Tr<T>::acc_row(l4, r), I0 + 16 * tj[q] + l15)];
   }
   {
     const T* srcP = M + cm_off(p_pad, I0, J0);
@@ -1345,7 +1355,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * ti[q] + Tr<T>::acc_row(l4, r), col = 16 * tj[q] + l15;
-      if (col <= row) M[cm_off(p_pad, I0 + row, I0 + col)] -= upd[q][r];
+      if (col <= row) M[cm_off(p_pad, I0 + row, I0 + col)] = -upd[q][r];
     }
   }
 

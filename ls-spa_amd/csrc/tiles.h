@@ -233,6 +233,45 @@ __device__ __forceinline__ void load_block64(T* lds, const T* __restrict__ g, in
   }
 }
 
+// the same in two moves -- fetch into registers, put into LDS later -- so that the global latency of a block
+// needed by the next stage hides behind the current stage's arithmetic
+template <typename T, int NT = 256>
+struct DenseBlock64Regs {
+  typename Tr<T>::vec_t v[4096 / Tr<T>::VE / NT];
+};
+
+template <typename T, int NT = 256>
+__device__ __forceinline__ void block64_fetch(DenseBlock64Regs<T, NT>& b, const T* __restrict__ g, int tid) {
+  constexpr int VE = Tr<T>::VE, VPR = 64 / VE, NV = 4096 / VE;
+#pragma unroll
+  for (int q = 0; q < NV / NT; ++q) {
+    const int idx = tid + NT * q;
+    b.v[q] = *reinterpret_cast<const typename Tr<T>::vec_t*>(g + (idx / VPR) * 64 + VE * (idx % VPR));
+  }
+}
+
+// source: the 64 x 64 block at (r0, c0) of a chunk-major matrix
+template <typename T, int NT = 256>
+__device__ __forceinline__ void block64_fetch_cm(DenseBlock64Regs<T, NT>& b, const T* __restrict__ A, int p_pad, int r0,
+                                                 int c0, int tid) {
+  constexpr int VE = Tr<T>::VE, VPR = 64 / VE, NV = 4096 / VE;
+#pragma unroll
+  for (int q = 0; q < NV / NT; ++q) {
+    const int idx = tid + NT * q;
+    b.v[q] = *reinterpret_cast<const typename Tr<T>::vec_t*>(A + cm_off(p_pad, r0 + idx / VPR, c0 + VE * (idx % VPR)));
+  }
+}
+
+template <typename T, int NT = 256>
+__device__ __forceinline__ void block64_put(const DenseBlock64Regs<T, NT>& b, T* lds, int tid) {
+  constexpr int VE = Tr<T>::VE, VPR = 64 / VE, NV = 4096 / VE;
+#pragma unroll
+  for (int q = 0; q < NV / NT; ++q) {
+    const int idx = tid + NT * q;
+    Tr<T>::lds_store(lds + (idx / VPR) * DI_LD + VE * (idx % VPR), b.v[q]);
+  }
+}
+
 // fp64 helpers kept for the Gram kernel (always fp64 accumulation)
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return Tr<double>::mfma(a, b, c); }
 __device__ __forceinline__ int acc_row(int l4, int r) { return Tr<double>::acc_row(l4, r); }
