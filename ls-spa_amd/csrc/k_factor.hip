@@ -1452,7 +1452,6 @@ __global__ __launch_bounds__(NT, 2) void strip2_kernel(StripArgs a) {
   for (int ib = ib0; ib < n_iblk; ib += 2) {
     const int I0 = ib * NB;
     const bool two = ib + 1 < n_iblk;          // the last step of an odd block count has one half
-    const int rows_valid = two ? 128 : 64;
     // Strides re-materialised per step: otherwise every row address of the epilogue (32 of them, 64 bit)
     // is hoisted out of this loop and carried -- spilled -- through the k-loop.
     int64_t ldv_e = ldv;
