@@ -364,3 +364,30 @@ def test_integration_md_stub_runs(golden):
     np.testing.assert_allclose(th, g["theta"], rtol=1e-10)
     assert abs(r2 - float(g["r_squared"])) < 1e-12
     ns["_lib"].lsspa_destroy(eng.h)
+
+
+def test_c4_end_to_end_from_host_arrays():
+    """BASELINE config 4 end to end through the public call: 2 x 800 MB of host data (SURVEY.md 8d generator,
+    p = 1000, N = M = 1e5) streamed into the reduction, permutohedron QMC orderings, antithetical pairs,
+    two batches of 128.  Size-independent checks: the attribution sums to the out-of-sample R^2, theta
+    solves the normal equations, both batches were checked, and the run is reproducible."""
+    p, n = 1000, 100000
+    rng = np.random.default_rng(0)
+    Xa = rng.standard_normal((n, p))
+    Xe = rng.standard_normal((n, p))
+    w = rng.standard_normal(p)
+    ya = Xa @ w + rng.standard_normal(n)
+    ye = Xe @ w + rng.standard_normal(n)
+    kw = dict(method="permutohedron", batch_size=128, num_batches=2, tolerance=0.0, seed=42,
+              error_estimator="device")
+    res = ls_spa(Xa, Xe, ya, ye, **kw)
+    assert res.attribution.shape == (p,) and np.all(np.isfinite(res.attribution))
+    assert abs(res.attribution.sum() - res.r_squared) < 1e-9
+    G = Xa.T @ Xa
+    np.testing.assert_allclose(G @ res.theta, Xa.T @ ya, rtol=1e-8, atol=1e-6)
+    r2 = 1.0 - np.sum((ye - Xe @ res.theta) ** 2) / (ye @ ye)
+    assert abs(res.r_squared - r2) < 1e-10
+    assert len(res.error_history) == 3 and res.overall_error == res.error_history[-1]   # 128, 255, 256
+    assert 0 < res.overall_error < 1e-3
+    again = ls_spa(Xa, Xe, ya, ye, **kw)
+    np.testing.assert_array_equal(again.attribution, res.attribution)
