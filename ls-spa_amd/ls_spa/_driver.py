@@ -102,17 +102,10 @@ def _load_checkpoint(path, comm, expect):
     return st
 
 
-def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms, antithetical,
-                  return_attribution_history, method, error_estimator, comm=None, chunk_cap=None,
-                  checkpoint=None):
-    """The sampling loop on an engine whose problem is already loaded.  Returns
-    (attribution, attribution_errors, overall_error, error_history, attribution_history, n).
-
-    checkpoint: path of a state file.  Written after every error check (sample count, running mean and
-    covariance, generator state, error history, the lift history the thin-form estimators need); if it
-    exists when the call starts, the run continues from it -- the orderings, the estimator's draws and
-    therefore every later number are those of the uninterrupted run."""
-    comm = comm or _Comm()
+def prepare_sampling(p, *, max_samples, batch_size, seed, perms, antithetical, method):
+    """Generator and ordering source of a run, with the reference's overrides for small p applied
+    (ls_spa/ls_spa.py:169-177).  Split from run_estimator so that ls_spa() can start it -- the QMC
+    constructors work on a helper thread -- before the data reduction instead of after it."""
     rng = np.random.default_rng(seed)
     never_stop = False
     if perms is not None:
@@ -137,6 +130,24 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
         source = S.PermutohedronSource(p, seed, max_samples)
     else:
         raise ValueError(f"method must be one of {S.METHODS} or None")
+    return rng, source, batch_size, antithetical, max_samples, never_stop
+
+
+def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms, antithetical,
+                  return_attribution_history, method, error_estimator, comm=None, chunk_cap=None,
+                  checkpoint=None, prepared=None):
+    """The sampling loop on an engine whose problem is already loaded.  Returns
+    (attribution, attribution_errors, overall_error, error_history, attribution_history, n).
+
+    checkpoint: path of a state file.  Written after every error check (sample count, running mean and
+    covariance, generator state, error history, the lift history the thin-form estimators need); if it
+    exists when the call starts, the run continues from it -- the orderings, the estimator's draws and
+    therefore every later number are those of the uninterrupted run."""
+    comm = comm or _Comm()
+    if prepared is None:
+        prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
+                                    antithetical=antithetical, method=method)
+    rng, source, batch_size, antithetical, max_samples, never_stop = prepared
     if batch_size < 1:
         raise ValueError("batch_size must be positive")
 
@@ -290,8 +301,10 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         their rows and sum the Gram matrices with one all-reduce.  'train': only the training rows are
         sharded, every rank passes all test rows (needed when there are fewer than p test rows).
     """
-    X_train, X_test = np.array(X_train), np.array(X_test)
-    y_train, y_test = np.array(y_train), np.array(y_test)
+    # the reference coerces with np.array (a copy, ls_spa/ls_spa.py:158-161); the inputs are never written here, so
+    # asarray gives the same result without copying 1.6 GB at the C3 shape
+    X_train, X_test = np.asarray(X_train), np.asarray(X_test)
+    y_train, y_test = np.asarray(y_train), np.asarray(y_test)
     validate_data(X_train, X_test, y_train, y_test)
     if y_train.ndim != 1 or y_test.ndim != 1:
         raise ValueError("y_train and y_test must be one-dimensional")  # reference: concatenate error, :312
@@ -311,6 +324,8 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
     try:
         if precision != "float64" or getattr(engine, "precision", "float64") != "float64":
             engine.set_precision(precision)
+        prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
+                                    antithetical=antithetical, method=method)
         if row_sharded:
             engine.load_data_sharded(X_train, X_test, y_train, y_test, reg, _comm or _Comm(),
                                      shard_test=row_sharded != "train")
@@ -319,7 +334,7 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         attribution, feat_err, total_err, err_hist, history, _ = run_estimator(
             engine, p, max_samples=max_samples, batch_size=batch_size, tolerance=tolerance, seed=seed,
             perms=perms, antithetical=antithetical, return_attribution_history=return_attribution_history,
-            method=method, error_estimator=error_estimator, comm=_comm, checkpoint=checkpoint)
+            method=method, error_estimator=error_estimator, comm=_comm, checkpoint=checkpoint, prepared=prepared)
         theta, r_squared, info = engine.full_fit()
         if info or engine.info():
             warnings.warn("a permuted Gram matrix was not numerically positive definite; the attribution "

@@ -9,6 +9,7 @@ streams are part of the observable behaviour) and yield int orderings in chunks.
 from __future__ import annotations
 
 import itertools
+import threading
 import warnings
 
 import numpy as np
@@ -78,10 +79,39 @@ class RandomSource(OrderingSource):
         self._left -= int(min(count, self._left))
 
 
+class _BackgroundBuild:
+    """Constructs an object on a helper thread.  SciPy's Sobol constructor takes ~18 ms at p = 1000 -- as long as
+    two batches on the GPU -- so it runs while the caller is inside the (GIL-free) data reduction."""
+
+    def __init__(self, factory):
+        self._value, self._error = None, None
+
+        def work():
+            try:
+                self._value = factory()
+            except BaseException as exc:   # re-raised in the caller's thread
+                self._error = exc
+
+        self._thread = threading.Thread(target=work, daemon=True)
+        self._thread.start()
+
+    def get(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        if self._error is not None:
+            raise self._error
+        return self._value
+
+
 class ArgsortSource(OrderingSource):
     def __init__(self, p, seed, limit):
         from scipy.stats.qmc import Sobol
-        self._qmc, self._p, self._left = Sobol(p, seed=seed), p, limit
+        self._build, self._p, self._left = _BackgroundBuild(lambda: Sobol(p, seed=seed)), p, limit
+
+    @property
+    def _qmc(self):
+        return self._build.get()
 
     def _points(self, n):
         with warnings.catch_warnings():
@@ -110,9 +140,17 @@ class PermutohedronSource(ArgsortSource):
         from scipy.stats.qmc import MultivariateNormalQMC
         if p < 2:
             raise ValueError("permutohedron sampling needs p >= 2")
-        self._qmc = MultivariateNormalQMC(np.zeros(p - 1), seed=seed, inv_transform=False)
+        self._build = _BackgroundBuild(
+            lambda: (MultivariateNormalQMC(np.zeros(p - 1), seed=seed, inv_transform=False), helmert_rows(p)))
         self._p, self._left = p, limit
-        self._basis = helmert_rows(p)
+
+    @property
+    def _qmc(self):
+        return self._build.get()[0]
+
+    @property
+    def _basis(self):
+        return self._build.get()[1]
 
     def take(self, count):
         n = int(min(count, self._left))
