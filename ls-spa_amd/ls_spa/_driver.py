@@ -65,7 +65,9 @@ class _Comm:
 def _min_norm_theta(G, g):
     """theta of minimal norm for a numerically singular Gram matrix (the reference gets it
     from lstsq on the triangular factor, ls_spa/ls_spa.py:240)."""
-    w, Q = np.linalg.eigh(G)
+    from ._stats import host_blas_threads
+    with host_blas_threads():
+        w, Q = np.linalg.eigh(G)
     keep = w > w.max() * G.shape[0] * np.finfo(float).eps
     coef = np.zeros_like(w)
     coef[keep] = (Q.T @ g)[keep] / w[keep]

@@ -9,7 +9,34 @@ observable behaviour.
 """
 from __future__ import annotations
 
+import contextlib
+import os
+
 import numpy as np
+
+try:   # optional: present in this image; without it the BLAS default stands
+    from threadpoolctl import ThreadpoolController
+except Exception:   # pragma: no cover
+    ThreadpoolController = None
+
+_controller = None
+# OpenBLAS starts one thread per core; on a 256-core GPU host that makes the p x p SVD of the reference's estimator
+# 4.5x slower (684 ms against 151 ms at p = 1000) and the thin estimator 7x slower than with 16 threads
+# (tools/host_estimator_probe.py)
+HOST_BLAS_THREADS = int(os.environ.get("LSSPA_HOST_BLAS_THREADS", min(16, os.cpu_count() or 1)))
+
+
+@contextlib.contextmanager
+def host_blas_threads():
+    """Run the enclosed NumPy / LAPACK calls with a sane BLAS thread count."""
+    global _controller
+    if ThreadpoolController is None or HOST_BLAS_THREADS <= 0:
+        yield
+        return
+    if _controller is None:
+        _controller = ThreadpoolController()
+    with _controller.limit(limits=HOST_BLAS_THREADS):
+        yield
 
 
 def merge_sample_mean(old_mean, new_mean, old_N, new_N):
@@ -31,12 +58,13 @@ def error_estimates(rng, cov):
     (singular covariance), the SVD-method sampler draws again."""
     dim = cov.shape[0]
     origin = np.zeros(dim)
-    try:
-        draws = rng.multivariate_normal(origin, cov, size=2 ** 10, method="cholesky")
-    except Exception:
-        draws = rng.multivariate_normal(origin, cov, size=2 ** 10, method="svd")
-    per_feature = np.quantile(np.abs(draws), 0.95, axis=0)
-    overall = np.quantile(np.linalg.norm(draws, axis=1), 0.95)
+    with host_blas_threads():
+        try:
+            draws = rng.multivariate_normal(origin, cov, size=2 ** 10, method="cholesky")
+        except Exception:
+            draws = rng.multivariate_normal(origin, cov, size=2 ** 10, method="svd")
+        per_feature = np.quantile(np.abs(draws), 0.95, axis=0)
+        overall = np.quantile(np.linalg.norm(draws, axis=1), 0.95)
     return per_feature, overall
 
 
@@ -50,6 +78,6 @@ def error_estimates_lowrank(rng, centered_lifts, n_total=None):
     stream, so this is opt-in (``error_estimator='lowrank'``)."""
     n = centered_lifts.shape[0] if n_total is None else n_total
     xi = rng.standard_normal((2 ** 10, centered_lifts.shape[0]))
-    with np.errstate(divide="ignore", invalid="ignore"):
+    with host_blas_threads(), np.errstate(divide="ignore", invalid="ignore"):
         draws = (xi @ centered_lifts) / np.sqrt(n * (n - 1.0))
-    return np.quantile(np.abs(draws), 0.95, axis=0), np.quantile(np.linalg.norm(draws, axis=1), 0.95)
+        return np.quantile(np.abs(draws), 0.95, axis=0), np.quantile(np.linalg.norm(draws, axis=1), 0.95)
