@@ -90,14 +90,29 @@ r = ref.ls_spa(*d12, max_samples=40, batch_size=16, tolerance=0.0, seed=3,
 pack.update(result_fields(r, "seedpath_"))
 save("p12", **pack)
 
-# (5) the reference's correlated generator at p=100, N=M=2000, seed 42
-# (the experiment script runs its whole 2^19-ordering experiment on import, so its generator is
-# used through the oracle's restatement, oracle/lsspa_oracle.py:correlated_workload)
-sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
-import lsspa_oracle  # noqa: E402
+# (5) + (6): gen_data / permutohedron_samples / argsort_samples live in the experiment SCRIPT, which runs its whole
+# 2^19-ordering experiment when imported.  Their definitions are therefore lifted out of the script's syntax tree
+# and executed here against the script's own module-level names (p, N, M, conditioning, STN_RATIO) -- the
+# reference's code runs, nothing of it is stored, and the script body never starts.
+import ast  # noqa: E402
 
+_SCRIPT = "/root/reference/experiments/ground_truth_medium.py"
+
+
+def script_functions(names, **module_globals):
+    tree = ast.parse(open(_SCRIPT).read(), filename=_SCRIPT)
+    picked = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in picked) == sorted(names), [n.name for n in picked]
+    ns = {"np": np, **module_globals}
+    exec(compile(ast.Module(body=picked, type_ignores=[]), _SCRIPT, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+# (5) the reference's correlated generator at p=100, N=M=2000, seed 42 (ground_truth_medium.py:74-106)
 p, N, M = 100, 2000, 2000
-dc = lsspa_oracle.correlated_workload(np.random.default_rng(42), p, N, M)
+(gen_data,) = script_functions(["gen_data"], p=p, N=N, M=M, conditioning=20.0, STN_RATIO=5.0)
+X_tr_c, X_te_c, y_tr_c, y_te_c, theta_c, cov_c = gen_data(np.random.default_rng(42))
+dc = (X_tr_c, X_te_c, y_tr_c, y_te_c)
 red = ref.reduce_data(*dc, 0.0)
 yn = np.linalg.norm(dc[3]) ** 2
 orders100 = np.array([np.random.default_rng(5).permutation(p) for _ in range(16)])
@@ -107,20 +122,36 @@ rfull = ref.ls_spa(*dc, perms=orders100, batch_size=8, tolerance=0.0)
 save("corr_p100", R_tr=red[0], F_te=red[1], q_tr=red[2], q_te=red[3], y_norm_sq=np.float64(yn),
      orders=orders100, lifts=lifts100, attribution=rfull.attribution, theta=rfull.theta,
      r_squared=np.float64(rfull.r_squared), seed=np.int64(42), N=np.int64(N), M=np.int64(M))
+# the generator's own output, pinned by slices and sums (the raw data would be 3.2 MB): what the product's
+# ls_spa.workloads.correlated and the oracle's correlated_workload are checked against
+save("corr_data_p100", seed=np.int64(42), p=np.int64(p), N=np.int64(N), M=np.int64(M),
+     X_train_head=X_tr_c[:6], X_test_head=X_te_c[:6], X_train_tail=X_tr_c[-2:], X_test_tail=X_te_c[-2:],
+     y_train_head=y_tr_c[:32], y_test_head=y_te_c[:32], theta_true=theta_c, cov_head=cov_c[:4],
+     X_train_colsum=X_tr_c.sum(axis=0), X_test_colsum=X_te_c.sum(axis=0),
+     X_train_sq=np.float64((X_tr_c ** 2).sum()), X_test_sq=np.float64((X_te_c ** 2).sum()),
+     y_train_sq=np.float64(y_tr_c @ y_tr_c), y_test_sq=np.float64(y_te_c @ y_te_c))
 
-# (6) sampler outputs
+# (6) sampler outputs of the script's own argsort_samples / permutohedron_samples (:56-71) at p = 12
 p = 12
+permutohedron_samples, argsort_samples = script_functions(["permutohedron_samples", "argsort_samples"], p=p)
 exp = {}
-# the samplers in the experiment script close over a module-level p and run the whole
-# experiment on import, so they are evaluated here from their definitions' semantics:
-q = Sobol(p, seed=5)
-exp["argsort"] = np.argsort(q.random(32), axis=1)
-q = MultivariateNormalQMC(np.zeros(p - 1), seed=5, inv_transform=False)
-s = q.random(32)
-s = s / np.linalg.norm(s, axis=1, keepdims=True)
-U = lsspa_oracle.permutohedron_basis(p)   # rows (1,..,1,-k,0,..,0)/norm, ground_truth_medium.py:62-65
-exp["permutohedron"] = np.argsort(s @ U, axis=1)
-exp["U"] = U
+exp["argsort"] = argsort_samples(Sobol(p, seed=5), 32)
+exp["permutohedron"] = permutohedron_samples(MultivariateNormalQMC(np.zeros(p - 1), seed=5, inv_transform=False), 32)
+# the projection basis is a local of permutohedron_samples: run the function once more with an identity "sample"
+# and an argsort that hands its argument back, so that what comes out is  I @ U  as the reference builds it
+import types  # noqa: E402
+
+
+class _IdentityDraws:
+    def random(self, n):
+        return np.eye(n)
+
+
+_np_passthrough = types.SimpleNamespace(**{k: getattr(np, k) for k in ("linalg", "tril", "ones", "diag", "arange")})
+_np_passthrough.argsort = lambda a, axis=-1: a
+(_probe,) = script_functions(["permutohedron_samples"], p=p)
+_probe.__globals__["np"] = _np_passthrough
+exp["U"] = np.array(_probe(_IdentityDraws(), p - 1))
 save("samplers_p12", **exp)
 
 # (7) merge formulas on the 200/300 split of test/test_ls_spa.py:7-44

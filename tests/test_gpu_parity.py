@@ -391,3 +391,130 @@ def test_c4_end_to_end_from_host_arrays():
     assert 0 < res.overall_error < 1e-3
     again = ls_spa(Xa, Xe, ya, ye, **kw)
     np.testing.assert_array_equal(again.attribution, res.attribution)
+
+
+# ------------------------------------------------------------------ (f3) the experiment harness
+def test_medium_experiment_harness(tmp_path):
+    """experiments/medium_experiment.py at reduced size (rows 2000, ground truth from 2^10 samples, 512-sample
+    convergence runs).  Reference: experiments/ground_truth_medium.py:108-119 (ground truth from injected random
+    orderings drawn after the data from the SAME generator) and notebooks/medium_experiment.py:348-603 (six
+    sampler runs, L2 error of the running attribution against the ground truth)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("medium_experiment",
+                                                  os.path.join(root, "experiments", "medium_experiment.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = []
+    gt, table, runs = mod.run(p=100, rows=2000, gt_log2=10, samples=512, out_dir=str(tmp_path), log=lines.append)
+    # ground truth: every lift vector sums to the full model's R^2, so the mean does
+    assert abs(gt.attribution.sum() - gt.r_squared) < 1e-10
+    np.testing.assert_array_equal(np.load(tmp_path / "gt_Medium.npy"), gt.attribution)
+    # the same experiment on the oracle: same generator stream -> same data, same injected orderings
+    rng = np.random.default_rng(42)
+    d = O.correlated_workload(rng, 100, 2000, 2000)
+    perms = np.array([rng.permutation(100) for _ in range(2 ** 10)])
+    want = O.estimate(*d, perms=perms, tolerance=0.0, batch_size=2 ** 12)
+    np.testing.assert_allclose(gt.attribution, want.attribution, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(gt.theta, want.theta, rtol=1e-8, atol=1e-11)
+    assert abs(gt.r_squared - want.r_squared) < 1e-10
+    # six runs, full histories, the table and the CSV agree
+    assert sorted(runs) == sorted((m, a) for m in ("random", "argsort", "permutohedron") for a in (False, True))
+    for (method, anti), r in runs.items():
+        assert r.attribution_history.shape == (512, 100)
+        np.testing.assert_allclose(r.attribution_history[-1], r.attribution, rtol=0, atol=1e-13)
+        err = np.linalg.norm(r.attribution_history - gt.attribution, axis=1)
+        assert err[-1] < err[15]           # the estimate converges towards the ground truth
+    assert len(table) == 6 * 6            # n = 16 .. 512 for each run
+    csv = (tmp_path / "convergence.csv").read_text().strip().splitlines()
+    assert csv[0] == "method,antithetical,samples,l2_error" and len(csv) == 1 + len(table)
+    # one run against the oracle on its own sampler's orderings (QMC argsort, antithetical)
+    from scipy.stats.qmc import Sobol
+    orders = O.orderings_argsort(Sobol(100, seed=42), 512)
+    ow = O.estimate(*d, perms=orders[:64], tolerance=0.0, batch_size=2 ** 8, return_attribution_history=True)
+    np.testing.assert_allclose(runs[("argsort", True)].attribution_history[:64], ow.attribution_history,
+                               rtol=0, atol=1e-10)
+
+
+# ------------------------------------------------------------------ BASELINE config 5: p = 5000
+def test_p5000_lifts_against_the_oracle():
+    """One ordering at C5's feature count (p = 5000, reg = 1e-2), compared with the oracle's per-ordering
+    algorithm (QR + triangular solve + GEMM: ls_spa/ls_spa.py:256-287) on the reduced problem the device
+    holds: fp64 device path <= 1e-10, fp32 device path <= 1e-4 against the same oracle value."""
+    import torch
+    from ls_spa._engine import HipEngine
+    p, n = 5000, 12000
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    Xa = torch.randn(n, p, dtype=torch.float64, device=dev, generator=gen)
+    Xe = torch.randn(n, p, dtype=torch.float64, device=dev, generator=gen)
+    w = torch.randn(p, dtype=torch.float64, device=dev, generator=gen)
+    ya = Xa @ w + torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
+    ye = Xe @ w + torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
+    torch.cuda.synchronize()
+    eng = HipEngine(0)
+    try:
+        eng.load_device_data(Xa.data_ptr(), p, ya.data_ptr(), n, Xe.data_ptr(), p, ye.data_ptr(), n, p, 1e-2)
+        # the Gram reduction itself against fp64 GEMMs on the same device data
+        G, g, H, h = eng.gram()
+        np.testing.assert_allclose(G, (Xa.T @ Xa / n).cpu().numpy() + 1e-2 * np.eye(p), rtol=0, atol=1e-11)
+        np.testing.assert_allclose(h, (Xe.T @ ye).cpu().numpy(), rtol=1e-12, atol=1e-8)
+        del Xa, Xe
+        torch.cuda.empty_cache()
+        # reference-layout factors for the oracle (upper triangular, R^T R = G), from the device's Gram matrices
+        R = np.linalg.cholesky(G).T
+        F = np.linalg.cholesky(H).T
+        q = np.linalg.solve(R.T, g)
+        qt = np.linalg.solve(F.T, h)
+        perm = np.random.default_rng(11).permutation(p)
+        want = O.ordering_lift(R, F, q, qt, eng.y_norm_sq, perm)
+        got64 = eng.run_batch(perm[None, :], False, want_lifts=True, accumulate=False)[0]
+        assert eng.info() == 0
+        np.testing.assert_allclose(got64, want, **LIFT_TOL)
+        assert abs(got64.sum() - want.sum()) < 1e-10
+        # antithetical pairing at this size: the pair's mean of (ordering, reversed ordering)
+        rev64 = eng.run_batch(perm[None, ::-1].copy(), False, want_lifts=True, accumulate=False)[0]
+        pair = eng.run_batch(perm[None, :], True, want_lifts=True, accumulate=False)[0]
+        np.testing.assert_allclose(pair, 0.5 * (got64 + rev64), rtol=0, atol=1e-13)
+        eng.set_precision("float32")
+        got32 = eng.run_batch(perm[None, :], False, want_lifts=True, accumulate=False)[0]
+        assert eng.info() == 0
+        np.testing.assert_allclose(got32, want, rtol=0, atol=1e-4)
+    finally:
+        eng.close()
+
+
+def test_c5_full_size_from_host_arrays():
+    """BASELINE config 5 at its stated size through the public call: p = 5000, N = M = 200000, reg = 1e-2,
+    method='argsort', float32 data (2 x 4 GB of host memory streamed into the fp64-accumulating Gram
+    reduction), float32 per-ordering work, one batch of 128 antithetical samples (= 256 orderings of 5000
+    features) with the device-side error estimate.  Size-independent checks (the oracle cannot run at this size;
+    test_p5000_lifts_against_the_oracle pins the per-ordering arithmetic at this p)."""
+    p, n, reg = 5000, 200000, 1e-2
+    rng = np.random.default_rng(0)
+    Xa = rng.standard_normal((n, p), dtype=np.float32)
+    Xe = rng.standard_normal((n, p), dtype=np.float32)
+    w = rng.standard_normal(p, dtype=np.float32)
+    ya = Xa @ w + rng.standard_normal(n, dtype=np.float32)
+    ye = Xe @ w + rng.standard_normal(n, dtype=np.float32)
+    kw = dict(reg=reg, method="argsort", batch_size=128, num_batches=1, tolerance=0.0, seed=42,
+              error_estimator="device", precision="float32")
+    res = ls_spa(Xa, Xe, ya, ye, **kw)
+    assert res.attribution.shape == (p,) and np.all(np.isfinite(res.attribution))
+    # every lift vector sums to the full model's R^2 (fp32 per-ordering work: stated tolerance 1e-4)
+    assert abs(res.attribution.sum() - res.r_squared) < 1e-4
+    # theta solves the ridge normal equations (X^T X / N + reg I) theta = X^T y / N  (matrix-vector products only)
+    th = res.theta
+    resid = (Xa.T @ (Xa @ th.astype(np.float32) - ya)).astype(np.float64) / n + reg * th   # two fp32 GEMVs, no 8 GB upcast
+    assert np.abs(resid).max() < 1e-4 * max(1.0, np.abs(th).max())
+    pred = Xe @ th.astype(np.float32)
+    r2 = 1.0 - float(np.sum((ye - pred).astype(np.float64) ** 2)) / float(ye.astype(np.float64) @ ye.astype(np.float64))
+    assert abs(res.r_squared - r2) < 1e-4
+    assert 0.9 < res.r_squared < 1.0
+    assert len(res.error_history) == 2 and res.overall_error == res.error_history[-1]   # i = 127 (max_samples - 1), 128
+    assert 0 < res.overall_error < 1e-2
+    # relevant features carry the attribution: largest |theta| get the largest shares
+    top = np.argsort(-np.abs(th))[:50]
+    assert res.attribution[top].mean() > 5 * res.attribution.mean()

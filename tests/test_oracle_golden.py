@@ -105,6 +105,46 @@ def test_correlated_generator_lifts(golden):
     np.testing.assert_allclose(R.T @ R, g["R_tr"].T @ g["R_tr"], rtol=0, atol=1e-11)
 
 
+def _check_generator_output(out, g):
+    Xa, Xe, ya, ye = out[:4]
+    theta, cov = out[4:] if len(out) == 6 else (None, None)   # the oracle's generator returns the data only
+    tol = dict(rtol=0, atol=1e-12)
+    np.testing.assert_allclose(Xa[:6], g["X_train_head"], **tol)
+    np.testing.assert_allclose(Xe[:6], g["X_test_head"], **tol)
+    np.testing.assert_allclose(Xa[-2:], g["X_train_tail"], **tol)
+    np.testing.assert_allclose(Xe[-2:], g["X_test_tail"], **tol)
+    np.testing.assert_allclose(ya[:32], g["y_train_head"], **tol)
+    np.testing.assert_allclose(ye[:32], g["y_test_head"], **tol)
+    if theta is not None:
+        np.testing.assert_array_equal(theta, g["theta_true"])
+        np.testing.assert_allclose(cov[:4], g["cov_head"], **tol)
+    np.testing.assert_allclose(Xa.sum(axis=0), g["X_train_colsum"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(Xe.sum(axis=0), g["X_test_colsum"], rtol=0, atol=1e-9)
+    for arr, key in ((Xa, "X_train_sq"), (Xe, "X_test_sq")):
+        np.testing.assert_allclose((arr ** 2).sum(), float(g[key]), rtol=1e-13)
+    np.testing.assert_allclose(ya @ ya, float(g["y_train_sq"]), rtol=1e-13)
+    np.testing.assert_allclose(ye @ ye, float(g["y_test_sq"]), rtol=1e-13)
+
+
+def test_correlated_generator_data(golden):
+    """The fixture holds what the reference's own gen_data (experiments/ground_truth_medium.py:74-106, its
+    function body executed by make_golden.py) returns for seed 42: pins the oracle's restatement ..."""
+    g = golden("corr_data_p100")
+    args = (int(g["p"]), int(g["N"]), int(g["M"]))
+    _check_generator_output(O.correlated_workload(np.random.default_rng(int(g["seed"])), *args), g)
+
+
+def test_product_workload_matches_reference_generator(golden):
+    """... and the product's ls_spa.workloads.correlated, which the experiment harness runs on."""
+    from ls_spa import workloads
+    g = golden("corr_data_p100")
+    args = (int(g["p"]), int(g["N"]), int(g["M"]))
+    _check_generator_output(workloads.correlated(np.random.default_rng(int(g["seed"])), *args), g)
+    # the primary benchmark data (SURVEY.md 8d) is the same stream in the product and in the oracle
+    for a, b in zip(workloads.gaussian(7, 30, 20, seed=0), O.gaussian_workload(7, 30, 20, seed=0)):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_samplers(golden):
     from scipy.stats.qmc import MultivariateNormalQMC, Sobol
     g = golden("samplers_p12")
