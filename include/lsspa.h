@@ -130,7 +130,10 @@ int lsspa_stats_set(lsspa_ctx* ctx, int64_t n, const double* mean, const double*
  *   lsspa_error_buffer   : device pointer / element count of the draws, the all-reduce(SUM) target between
  *                          lsspa_error_draws and lsspa_error_quantiles when the samples are spread over ranks
  *   lsspa_error_quantiles: feature_errors [p] = 0.95-quantile of |x_a| over the draws, overall_error = the same
- *                          quantile of ||x||_2 (numpy's default linear interpolation) */
+ *                          quantile of ||x||_2 (numpy's default linear interpolation)
+ * Lifetime of host buffers: every entry point that takes a host pointer has finished reading it when it returns
+ * (lsspa_error_draws and lsspa_stats_set synchronise their upload; lsspa_lift_batch copies the orderings into
+ * pinned staging before it returns), so the caller may pass temporaries. */
 int lsspa_history_enable(lsspa_ctx* ctx, int64_t capacity);
 int lsspa_history_get(lsspa_ctx* ctx, int64_t* count, double* lifts);
 int lsspa_history_append(lsspa_ctx* ctx, const double* lifts, int64_t rows);
@@ -161,6 +164,9 @@ int lsspa_profile_reset(lsspa_ctx* ctx);
 int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);
 
 /* test hooks */
+/* the nth device allocation from now on fails with LSSPA_ERR_NOMEM (0 disarms): exercises the out-of-memory
+ * paths, after which a context must still be usable (e.g. with a smaller batch) */
+int lsspa_debug_fail_alloc(lsspa_ctx* ctx, int32_t nth);
 int lsspa_mfma_probe(lsspa_ctx* ctx, const double* A16x4, const double* B4x16, double* D16x16, int32_t dtype);
 /* factor one ordering and copy the padded factor(s) out: L [p_pad][p_pad] (train),
  * Lt [p_pad][p_pad] (test, tri mode only, else untouched), V [n_iblk*64][m_pad] */

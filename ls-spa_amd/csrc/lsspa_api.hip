@@ -85,6 +85,7 @@ struct lsspa_ctx {
   int64_t hist_cap = 0, hist_n = 0;
   int ldh() const { return ((p + 127) / 128) * 128; }
   int flags = 0;
+  int fail_alloc_in = 0;   // test hook (lsspa_debug_fail_alloc): the n-th device allocation from now fails
 
   // profiling
   bool prof_on = false;
@@ -117,8 +118,14 @@ int dev_alloc(lsspa_ctx* ctx, DevBuf<T>& b, size_t count) {
   if (b.ptr) (void)hipFree(b.ptr);
   b.ptr = nullptr;
   b.count = 0;
+  if (ctx->fail_alloc_in > 0 && --ctx->fail_alloc_in == 0)
+    return ctx->fail(LSSPA_ERR_NOMEM, "hipMalloc: out of memory (injected by lsspa_debug_fail_alloc)");
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&b.ptr), count * sizeof(T));
-  if (e != hipSuccess) return ctx->fail(LSSPA_ERR_NOMEM, "hipMalloc", e);
+  if (e != hipSuccess) {
+    b.ptr = nullptr;
+    (void)hipGetLastError();
+    return ctx->fail(LSSPA_ERR_NOMEM, "hipMalloc", e);
+  }
   b.count = count;
   return LSSPA_OK;
 }
@@ -204,12 +211,35 @@ __global__ void sumsq_kernel(const double* __restrict__ v, int n, double* __rest
 }
 
 // ---- problem set-up -----------------------------------------------------------------------
+// Drop the per-batch workspace (it is re-created on demand).  The capacities are zeroed FIRST, so that a context
+// whose next allocation fails is left with "no workspace", never with a capacity that points at freed buffers.
+void free_workspace(lsspa_ctx* ctx) {
+  ctx->cap_ord = 0;
+  ctx->cap_samples = 0;
+  ctx->perms_used_valid[0] = ctx->perms_used_valid[1] = false;
+  dev_free(ctx->A);
+  dev_free(ctx->V);
+  dev_free(ctx->Dinv);
+  dev_free(ctx->diag0);
+  dev_free(ctx->Ppart);
+  dev_free(ctx->perms_d);
+  dev_free(ctx->lifts);
+  dev_free(ctx->stat_parts);
+}
+
 int set_dims(lsspa_ctx* ctx, int p, int m, int tri) {
   if (p < 1 || m < 1) return ctx->fail(LSSPA_ERR_ARG, "p and m must be positive");
   if (tri && m != p) return ctx->fail(LSSPA_ERR_ARG, "tri mode needs m == p");
   HIPCHK(hipStreamSynchronize(ctx->stream));  // buffers below may be re-allocated
   ctx->have_problem = false;
   ctx->src_f32_valid = false;
+  // a workspace sized for another shape is released now: kept, it would count as unavailable memory when the
+  // new one is sized from hipMemGetInfo (and its layout depends on p_pad / m_pad / tri anyway)
+  if (p != ctx->p || m != ctx->m || tri != ctx->tri) {
+    free_workspace(ctx);
+    dev_free(ctx->Gf);
+    dev_free(ctx->Hf);
+  }
   ctx->p = p;
   ctx->m = m;
   ctx->tri = tri;
@@ -231,9 +261,6 @@ int set_dims(lsspa_ctx* ctx, int p, int m, int tri) {
   TRY(dev_alloc(ctx, ctx->pend, (size_t)1 + p + (size_t)p * p));
   TRY(dev_alloc(ctx, ctx->state_n, 8));
   TRY(dev_alloc(ctx, ctx->info_d, 8));
-  // the workspace depends on p: drop it, it is re-created on demand
-  ctx->cap_ord = 0;
-  ctx->cap_samples = 0;
   // so does the lift history (row stride): it has to be enabled again for the new problem
   ctx->hist_cap = 0;
   ctx->hist_n = 0;
@@ -301,27 +328,28 @@ int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
     cap &= ~1;  // keep antithetical pairs together
     if (cap < 2) return ctx->fail(LSSPA_ERR_NOMEM, "not enough device memory for two orderings");
     if (cap > ctx->cap_ord) {
-      dev_free(ctx->A);
-      dev_free(ctx->V);
-      dev_free(ctx->Dinv);
-      dev_free(ctx->diag0);
-      dev_free(ctx->Ppart);
-      dev_free(ctx->perms_d);
-      const size_t pp = ctx->p_pad, nblk = pp / NB, n_iblk = (ctx->p + NB - 1) / NB;
+      // capacity 0 while the buffers are being replaced: if one allocation fails (LSSPA_ERR_NOMEM) the caller may
+      // retry with a smaller batch and must then find "no workspace", not the old capacity over freed buffers
+      const int samples_kept = ctx->cap_samples;
+      DevBuf<double> lifts_kept = ctx->lifts;
+      ctx->lifts = DevBuf<double>();
+      free_workspace(ctx);
+      ctx->lifts = lifts_kept;
+      ctx->cap_samples = samples_kept;
+      const size_t pp = ctx->p_pad, nblk = pp / NB;
       const size_t nm = ctx->tri ? 2 : 1;
       const size_t es = ctx->esz();
       TRY(dev_alloc(ctx, ctx->A, nm * cap * pp * pp * es));
-      (void)n_iblk;
       TRY(dev_alloc(ctx, ctx->V, (size_t)cap * (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad) * es));
       TRY(dev_alloc(ctx, ctx->Dinv, nm * cap * nblk * 4096 * es));
       TRY(dev_alloc(ctx, ctx->diag0, nm * cap * pp));
       TRY(dev_alloc(ctx, ctx->Ppart, (size_t)cap * (ctx->m_pad / 64) * pp));
       TRY(dev_alloc(ctx, ctx->perms_d, (size_t)2 * cap * ctx->p));
-      ctx->perms_used_valid[0] = ctx->perms_used_valid[1] = false;
       ctx->cap_ord = cap;
     }
   }
   if (want_samples > ctx->cap_samples) {
+    ctx->cap_samples = 0;   // dev_alloc releases the old buffer before it asks for the new one
     TRY(dev_alloc(ctx, ctx->lifts, (size_t)want_samples * ctx->p));
     ctx->cap_samples = want_samples;
   }
@@ -371,17 +399,7 @@ int run_slice(lsspa_ctx* ctx, int ord_off, int n_ord, int per_sample, int s_off,
     ga.s[1] = ctx->tri ? ctx->h.ptr : nullptr;
     ga.aug[1] = 2.0 * ctx->y_norm_sq + 1.0;
     ga.Sf[0] = ga.Sf[1] = nullptr;
-    if (ctx->f32) {
-      if (!ctx->src_f32_valid) {
-        const size_t cnt = (size_t)p * p_pad;
-        TRY(dev_alloc(ctx, ctx->Gf, cnt));
-        HIPCHK(launch_to_f32(ctx->G.ptr, ctx->Gf.ptr, (int64_t)cnt, st));
-        if (ctx->tri) {
-          TRY(dev_alloc(ctx, ctx->Hf, cnt));
-          HIPCHK(launch_to_f32(ctx->H.ptr, ctx->Hf.ptr, (int64_t)cnt, st));
-        }
-        ctx->src_f32_valid = true;
-      }
+    if (ctx->f32) {   // made by ensure_f32_sources() before the first slice is launched
       ga.Sf[0] = ctx->Gf.ptr;
       ga.Sf[1] = ctx->tri ? ctx->Hf.ptr : nullptr;
     }
@@ -466,11 +484,27 @@ int run_slice(lsspa_ctx* ctx, int ord_off, int n_ord, int per_sample, int s_off,
   return LSSPA_OK;
 }
 
+// fp32 mode: the gather reads fp32 copies of the Gram matrices.  Converted once per problem on the context's
+// stream, BEFORE a batch forks onto a second stream (a slice on the side stream must not race the conversion).
+int ensure_f32_sources(lsspa_ctx* ctx) {
+  if (!ctx->f32 || ctx->src_f32_valid) return LSSPA_OK;
+  const size_t cnt = (size_t)ctx->p * ctx->p_pad;
+  TRY(dev_alloc(ctx, ctx->Gf, cnt));
+  HIPCHK(launch_to_f32(ctx->G.ptr, ctx->Gf.ptr, (int64_t)cnt, ctx->stream));
+  if (ctx->tri) {
+    TRY(dev_alloc(ctx, ctx->Hf, cnt));
+    HIPCHK(launch_to_f32(ctx->H.ptr, ctx->Hf.ptr, (int64_t)cnt, ctx->stream));
+  }
+  ctx->src_f32_valid = true;
+  return LSSPA_OK;
+}
+
 // Run gather -> factorisation -> strip -> lift for n_ord orderings already resident in perms_d.
 // lifts for sample s land in lifts_d[(s_off + s)][p].  With developer flag 32 a large batch is cut into
 // two slices on two streams (the launches of a slice depend on each other, so while one slice drains the
 // tail of a launch the other slice's workgroups take the idle CUs).
 int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
+  TRY(ensure_f32_sources(ctx));
   const int half = ((n_ord / 2) / per_sample) * per_sample;
   // opt-in (developer flag 32): measured gain 0.8 % at p = 1000 -- not worth two launch shapes per kernel in the traces
   if (ctx->prof_on || !(ctx->flags & 32) || half < 32) return run_slice(ctx, 0, n_ord, per_sample, s_off, ctx->stream);
@@ -1244,6 +1278,8 @@ int lsspa_error_draws(lsspa_ctx* ctx, const double* xi, int64_t ld_xi, int64_t n
   if (n_pad != n_local) HIPCHK(hipMemsetAsync(ctx->xi_d.ptr, 0, (size_t)ERR_DRAWS * n_pad * 8, ctx->stream));
   HIPCHK(hipMemcpy2DAsync(ctx->xi_d.ptr, (size_t)n_pad * 8, xi, (size_t)ld_xi * 8, (size_t)n_local * 8, ERR_DRAWS,
                           hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // xi is the caller's (pageable, possibly temporary) buffer: it may
+                                               // be released as soon as this call returns (lsspa.h)
   const double nt = (double)n_total;
   const double scale = 1.0 / sqrt(nt * (nt - 1.0));   // inf for n_total = 1, as numpy's division gives
   ProfScope ps(ctx, LSSPA_K_ERROR);
@@ -1315,6 +1351,12 @@ int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags) {
   return LSSPA_OK;
 }
 
+int lsspa_debug_fail_alloc(lsspa_ctx* ctx, int32_t nth) {
+  if (!ctx || nth < 0) return LSSPA_ERR_ARG;
+  ctx->fail_alloc_in = nth;
+  return LSSPA_OK;
+}
+
 int lsspa_set_precision(lsspa_ctx* ctx, int32_t dtype) {
   if (!ctx) return LSSPA_ERR_ARG;
   if (dtype != LSSPA_F64 && dtype != LSSPA_F32) return ctx->fail(LSSPA_ERR_ARG, "dtype");
@@ -1322,7 +1364,7 @@ int lsspa_set_precision(lsspa_ctx* ctx, int32_t dtype) {
   if ((dtype == LSSPA_F32) != (ctx->f32 != 0)) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->f32 = dtype == LSSPA_F32;
-    ctx->cap_ord = 0;   // the workspace is re-created for the new element size on demand
+    free_workspace(ctx);   // re-created for the new element size on demand
   }
   return LSSPA_OK;
 }

@@ -39,11 +39,19 @@ class TorchComm:
         s = torch.cuda.Stream(device=device)
         return s, s.cuda_stream
 
-    def _as_tensor(self, buf):
+    def _as_tensor(self, buf, engine):
         torch = self._torch
         if isinstance(buf, np.ndarray):
             return torch.from_numpy(buf)            # shares memory with the test double's buffer
-        return torch.as_tensor(buf, device="cuda")  # zero-copy view through __cuda_array_interface__
+        # zero-copy view through __cuda_array_interface__, on the ENGINE's device: with device="cuda" torch takes
+        # its current device and, if that is another GPU, silently copies the buffer there -- the collective would
+        # then reduce the copy and the engine's own buffer would never see the other ranks' moments
+        t = torch.as_tensor(buf, device=torch.device("cuda", engine.device))
+        ptr = buf.__cuda_array_interface__["data"][0]
+        if t.data_ptr() != ptr:
+            raise RuntimeError(f"torch copied the engine's buffer (engine on cuda:{engine.device}, tensor on "
+                               f"{t.device}): the all-reduce would not reach the engine")
+        return t
 
     def allreduce_pending(self, engine):
         self._allreduce(engine, engine.pending_buffer)
@@ -57,18 +65,28 @@ class TorchComm:
         self._allreduce(engine, engine.reduce_buffer)
 
     def sum_ints(self, values):
+        # on the GPU backend the tensor lives on torch's current device: one process per GPU sets it
+        # (torch.cuda.set_device(LOCAL_RANK)) before the process group is made, as RCCL itself requires
         t = self._torch.tensor([int(v) for v in values], dtype=self._torch.int64,
-                               device="cuda" if self._on_gpu else "cpu")
+                               device=self._torch.device("cuda", self._torch.cuda.current_device())
+                               if self._on_gpu else "cpu")
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
         return [int(v) for v in t.cpu().tolist()]
+
+    def gather_ints(self, values):
+        from ._driver import gather_ints_by_sum
+        return gather_ints_by_sum(self, values)
 
     def _allreduce(self, engine, get_buffer):
         if self.world == 1 and not self._force:
             return
-        t = self._as_tensor(get_buffer())
+        t = self._as_tensor(get_buffer(), engine)
         if not self._on_gpu:
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
             return
+        if self._torch.cuda.current_device() != engine.device:
+            raise RuntimeError(f"engine on cuda:{engine.device} but torch's current device is "
+                               f"cuda:{self._torch.cuda.current_device()}: call torch.cuda.set_device first")
         if self._stream is not None:
             # engine kernels, collective and merge are all ordered on the shared stream
             with self._torch.cuda.stream(self._stream):

@@ -58,8 +58,21 @@ class _Comm:
     def sum_ints(self, values):
         return [int(v) for v in values]
 
+    def gather_ints(self, values):
+        return [[int(v) for v in values]]
+
     def gather_lifts(self, local, counts):
         return local
+
+
+def gather_ints_by_sum(comm, values):
+    """Every rank's integer vector, [world][k], through the one integer collective a communicator has to offer
+    (sum_ints): each rank writes its own slot of a zero vector, the sum is the concatenation."""
+    k = len(values)
+    flat = [0] * (comm.world * k)
+    flat[comm.rank * k:(comm.rank + 1) * k] = [int(v) for v in values]
+    total = comm.sum_ints(flat)
+    return [total[r * k:(r + 1) * k] for r in range(comm.world)]
 
 
 def _min_norm_theta(G, g):
@@ -74,7 +87,7 @@ def _min_norm_theta(G, g):
     return Q @ coef
 
 
-_CKPT_VERSION = 1
+_CKPT_VERSION = 2
 
 
 def _ckpt_path(path, comm):
@@ -82,15 +95,18 @@ def _ckpt_path(path, comm):
 
 
 def _save_checkpoint(path, comm, state):
-    """Atomic write (temp file + rename) of the estimator state; one file per rank."""
+    """Atomic write (temp file + rename) of the estimator state; one file per rank.  The file it replaces is
+    kept as ``<file>.prev``: the ranks write after the same check but not at the same instant, so a job killed
+    between two ranks' renames leaves them one generation apart -- the older one is then the common state."""
     target = _ckpt_path(path, comm)
     tmp = target + ".tmp.npz"
     np.savez(tmp, **state)
+    if os.path.exists(target):
+        os.replace(target, target + ".prev")
     os.replace(tmp, target)
 
 
-def _load_checkpoint(path, comm, expect):
-    target = _ckpt_path(path, comm)
+def _read_checkpoint(target, expect):
     if not os.path.exists(target):
         return None
     with np.load(target, allow_pickle=False) as z:
@@ -102,6 +118,35 @@ def _load_checkpoint(path, comm, expect):
         if str(have) != str(want):
             raise ValueError(f"checkpoint {target} was written with {key}={have}, this run has {key}={want}")
     return st
+
+
+def _load_checkpoint(path, comm, expect):
+    """The state to resume from, or None.  With several ranks the ranks first agree on it: each reports the sample
+    counts of the (at most two) generations it holds and all resume from the largest count EVERY rank holds;
+    if there is none -- a rank without a file next to ranks with files, files of different runs -- every rank
+    raises the same error instead of running chunks that no longer pair up in the collectives."""
+    target = _ckpt_path(path, comm)
+    gens = [st for st in (_read_checkpoint(target, expect), _read_checkpoint(target + ".prev", expect))
+            if st is not None]
+    if comm.world == 1:
+        return gens[0] if gens else None
+    mine = ([int(st["n"]) for st in gens] + [-1, -1])[:2]
+    table = comm.gather_ints(mine)
+    held = [set(v for v in row if v >= 0) for row in table]
+    if not any(held):
+        return None
+    common = set.intersection(*held)
+    if not common:
+        raise ValueError(f"checkpoint {path}: the ranks hold no common state (sample counts per rank: "
+                         f"{[sorted(h) for h in held]}); remove the files to start over")
+    n = max(common)
+    return next(st for st in gens if int(st["n"]) == n)
+
+
+def _data_fingerprint(engine):
+    """A few numbers of the reduced problem that change with the data, the row count or reg."""
+    G, g, _, _ = engine.gram()
+    return f"{float(np.trace(G))!r}/{float(g @ g)!r}/{float(engine.y_norm_sq)!r}"
 
 
 def prepare_sampling(p, *, max_samples, batch_size, seed, perms, antithetical, method):
@@ -173,6 +218,8 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
     if checkpoint is not None:
         if return_attribution_history:
             raise ValueError("checkpoint= cannot be combined with return_attribution_history")
+        ident["precision"] = str(getattr(engine, "precision", "float64"))
+        ident["data"] = _data_fingerprint(engine)
         st = _load_checkpoint(checkpoint, comm, ident)
         if st is not None:
             i = int(st["n"])

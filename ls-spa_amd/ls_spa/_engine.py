@@ -296,6 +296,10 @@ class HipEngine:
         self._check(self._lib.lsspa_set_precision(self._h, N.F32 if name == "float32" else N.F64))
         self.precision = name
 
+    def debug_fail_alloc(self, nth: int):
+        """Test hook: the nth device allocation from now fails with MemoryError (0 disarms)."""
+        self._check(self._lib.lsspa_debug_fail_alloc(self._h, int(nth)))
+
     def mfma_probe(self, A, B, f32=False):
         A = np.ascontiguousarray(A, dtype=np.float64)
         B = np.ascontiguousarray(B, dtype=np.float64)

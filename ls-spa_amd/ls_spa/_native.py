@@ -66,6 +66,7 @@ SIGNATURES = {
     "lsspa_profile_reset": (C.c_int, [_vp]),
     "lsspa_set_flags": (C.c_int, [_vp, _i32]),
     "lsspa_set_precision": (C.c_int, [_vp, _i32]),
+    "lsspa_debug_fail_alloc": (C.c_int, [_vp, _i32]),
     "lsspa_mfma_probe": (C.c_int, [_vp, _pd, _pd, _pd, _i32]),
     "lsspa_debug_factor": (C.c_int, [_vp, _pi32, _pd, _pd, _pd, _pi32, _pi32, _pi32]),
 }

@@ -52,10 +52,32 @@ def _worker(rank, world, port, out_dir):
         ls_spa(*d, checkpoint=ck, _engine=Dies(), _comm=TorchComm(), **kw)
     except KeyboardInterrupt:
         pass
+    # ... and between the two ranks' renames of the second check: rank 1 is left one generation behind (its newest
+    # file is the older state); the ranks must agree on the state both hold (n = 16) instead of resuming apart
+    dist.barrier()
+    if rank == 1:
+        os.replace(ck + ".rank1.prev", ck + ".rank1")
+    dist.barrier()
     resumed = ls_spa(*d, checkpoint=ck, _engine=OracleEngine(), _comm=TorchComm(), **kw)
+    # a rank whose files are gone next to a rank that has them: every rank raises, nobody runs ahead alone
+    ck2 = os.path.join(out_dir, "state2.npz")
+    try:
+        ls_spa(*d, checkpoint=ck2, _engine=Dies(), _comm=TorchComm(), **kw)
+    except KeyboardInterrupt:
+        pass
+    dist.barrier()
+    if rank == 1:
+        os.remove(ck2 + ".rank1")
+        os.remove(ck2 + ".rank1.prev")
+    dist.barrier()
+    try:
+        ls_spa(*d, checkpoint=ck2, _engine=OracleEngine(), _comm=TorchComm(), **kw)
+        lonely = "ran"
+    except ValueError as exc:
+        lonely = "refused" if "no common state" in str(exc) else str(exc)
     np.savez(os.path.join(out_dir, f"s{rank}.npz"), attribution=shard.attribution, theta=shard.theta,
              r2=shard.r_squared, attribution_tr=shard_tr.attribution, res_attr=resumed.attribution,
-             res_err=resumed.error_history, ck_exists=os.path.exists(ck + f".rank{rank}"))
+             res_err=resumed.error_history, ck_exists=os.path.exists(ck + f".rank{rank}"), lonely=lonely)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), attribution=res.attribution,
              history=res.attribution_history, err=res.error_history, calls=np.array(eng.calls),
              dev_err=dev.error_history, dev_feat=dev.attribution_errors, dev_rows=eng2.history_count())
@@ -98,6 +120,7 @@ def test_two_ranks_match_single_process(tmp_path):
         assert abs(float(s["r2"]) - full.r_squared) < 1e-11
         np.testing.assert_allclose(s["attribution_tr"], full.attribution, rtol=0, atol=1e-11)
         assert bool(s["ck_exists"])
+        assert str(s["lonely"]) == "refused"
     # two-rank resume == uninterrupted single-process run with the same sampler and estimator
     straight = ls_spa(*d, method="argsort", seed=3, max_samples=80, batch_size=16, tolerance=0.0,
                       error_estimator="lowrank", _engine=OracleEngine())

@@ -298,3 +298,38 @@ def test_batch_larger_than_the_workspace_is_split(engine, anti):
     assert cnt == n
     np.testing.assert_allclose(mean, got.mean(0), rtol=0, atol=1e-13)
     np.testing.assert_allclose(cov, np.cov(got, rowvar=False, bias=True), rtol=0, atol=1e-13)
+
+
+def test_failed_allocation_leaves_the_context_usable():
+    """A workspace growth that runs out of memory (second allocation fails: injected) raises MemoryError and must
+    leave the context without a workspace -- not with the old capacity over freed buffers -- so that the next,
+    smaller batch allocates afresh and computes the same lifts as before."""
+    from ls_spa._engine import HipEngine
+    d = O.gaussian_workload(40, 300, 200, seed=3)
+    rng = np.random.default_rng(2)
+    perms = np.array([rng.permutation(40) for _ in range(64)])
+    eng = HipEngine(0)
+    try:
+        eng.load_data(*d, 0.0)
+        want = eng.run_batch(perms[:4], True, want_lifts=True, accumulate=False)
+        eng.debug_fail_alloc(2)
+        with pytest.raises(MemoryError):
+            eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        got = eng.run_batch(perms[:4], True, want_lifts=True, accumulate=False)
+        np.testing.assert_array_equal(got, want)
+        eng.debug_fail_alloc(1)     # the lifts buffer's growth fails this time
+        with pytest.raises(MemoryError):
+            eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        eng.debug_fail_alloc(0)
+        full = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        np.testing.assert_array_equal(full[:4], want)
+        # a new problem of another shape on the same context: the old workspace is released, not leaked
+        d2 = O.gaussian_workload(70, 300, 200, seed=4)
+        eng.load_data(*d2, 0.0)
+        perms2 = np.array([rng.permutation(70) for _ in range(8)])
+        got2 = eng.run_batch(perms2, False, want_lifts=True, accumulate=False)
+        red = O.reduce(*d2, 0.0)
+        want2 = np.array([O.ordering_lift(*red, float(d2[3] @ d2[3]), o) for o in perms2])
+        np.testing.assert_allclose(got2, want2, rtol=0, atol=1e-10)
+    finally:
+        eng.close()
