@@ -141,6 +141,31 @@ int lsspa_error_draws(lsspa_ctx* ctx, const double* xi, int64_t ld_xi, int64_t n
 int lsspa_error_buffer(lsspa_ctx* ctx, void** device_ptr, int64_t* count);
 int lsspa_error_quantiles(lsspa_ctx* ctx, double* feature_errors, double* overall_error);
 
+/* (e) -- collectives.  The reference is single-process; these implement the multi-GPU form of its running-statistics
+ * merge (ls_spa/ls_spa.py:103-119, :212-216): orderings are dealt over one process per GPU and the ONLY data-path
+ * exchange is one SUM all-reduce of the pending-batch moments per chunk.  RCCL over xGMI, resolved
+ * at run time (no link-time dependency; a single-GPU process never loads it); every collective is enqueued on the
+ * context's stream, so kernels -> all-reduce -> merge run without host synchronisation.
+ *   lsspa_comm_unique_id  : 128 opaque bytes made on rank 0 (ncclGetUniqueId) and handed to the other ranks by the
+ *                           host (the Python package uses a TCP exchange on MASTER_ADDR); errors: lsspa_last_error(NULL)
+ *   lsspa_comm_init       : collective over all ranks; binds the communicator to this context's GPU
+ *   lsspa_stats_allreduce : the pending buffer [n_b, S, Q]; from p = 2048 on Q travels as its upper triangle
+ *                           (1 + p + p (p + 1) / 2 elements: half the bytes; Q is exactly symmetric)
+ *   lsspa_reduce_allreduce: the Gram sums of a row-sharded reduction (between lsspa_reduce_partial and _finish)
+ *   lsspa_error_allreduce : the partial draws of the device-side estimator (between lsspa_error_draws and _quantiles)
+ *   lsspa_comm_sum_i64    : host integers, summed over the ranks in place (row counts of a sharded reduction)
+ *   lsspa_comm_allgather  : host fp64 [count] per rank -> [world][count] (lift vectors for attribution_history) */
+#define LSSPA_COMM_ID_BYTES 128
+int lsspa_comm_unique_id(uint8_t* id128);
+int lsspa_comm_init(lsspa_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world);
+int lsspa_comm_destroy(lsspa_ctx* ctx);
+int lsspa_comm_info(const lsspa_ctx* ctx, int32_t* rank, int32_t* world);
+int lsspa_stats_allreduce(lsspa_ctx* ctx);
+int lsspa_reduce_allreduce(lsspa_ctx* ctx);
+int lsspa_error_allreduce(lsspa_ctx* ctx);
+int lsspa_comm_sum_i64(lsspa_ctx* ctx, int64_t* values, int32_t count);
+int lsspa_comm_allgather(lsspa_ctx* ctx, const double* send, int64_t count, double* recv);
+
 /* per-kernel-class HIP-event timing on the context's stream */
 #define LSSPA_K_GATHER 0
 #define LSSPA_K_CHOL_DIAG 1
@@ -150,7 +175,8 @@ int lsspa_error_quantiles(lsspa_ctx* ctx, double* feature_errors, double* overal
 #define LSSPA_K_STATS 5
 #define LSSPA_K_GRAM 6
 #define LSSPA_K_ERROR 7
-#define LSSPA_K_COUNT 8
+#define LSSPA_K_COMM 8
+#define LSSPA_K_COUNT 9
 int lsspa_profile_enable(lsspa_ctx* ctx, int32_t on);
 int lsspa_profile_get(lsspa_ctx* ctx, int32_t kernel_class, double* total_ms, int64_t* launches);
 int lsspa_profile_reset(lsspa_ctx* ctx);
@@ -167,6 +193,8 @@ int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);
 /* the nth device allocation from now on fails with LSSPA_ERR_NOMEM (0 disarms): exercises the out-of-memory
  * paths, after which a context must still be usable (e.g. with a smaller batch) */
 int lsspa_debug_fail_alloc(lsspa_ctx* ctx, int32_t nth);
+/* use the packed (upper-triangle) form of lsspa_stats_allreduce from this p on (default 2048) */
+int lsspa_debug_pack_from(lsspa_ctx* ctx, int32_t p_min);
 int lsspa_mfma_probe(lsspa_ctx* ctx, const double* A16x4, const double* B4x16, double* D16x16, int32_t dtype);
 /* factor one ordering and copy the padded factor(s) out: L [p_pad][p_pad] (train),
  * Lt [p_pad][p_pad] (test, tri mode only, else untouched), V [n_iblk*64][m_pad] */

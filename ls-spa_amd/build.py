@@ -18,8 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIBNAME = "liblsspa_hip.so"
-SOURCES = ["k_factor.hip", "k_lift.hip", "k_gram.hip", "k_error.hip", "lsspa_api.hip"]
-HEADERS = ["tiles.h", "kernels.h", os.path.join("..", "..", "include", "lsspa.h")]
+SOURCES = ["k_factor.hip", "k_lift.hip", "k_gram.hip", "k_error.hip", "lsspa_comm.hip", "lsspa_api.hip"]
+HEADERS = ["tiles.h", "kernels.h", "comm.h", os.path.join("..", "..", "include", "lsspa.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -59,7 +59,7 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -275,6 +275,54 @@ hipError_t launch_stats_batch(const double* lifts, const double* mean, double* b
   return hipGetLastError();
 }
 
+// Packing of the pending-batch buffer for the all-reduce at large p: Q is symmetric (a sum of outer products,
+// computed tile by tile from commutative products in one sample order, so bitwise symmetric), hence only its upper
+// triangle travels:  packed = [n_b, S (p), Q[i][i..p-1] for i = 0..p-1]  -- 1 + p + p (p + 1) / 2 elements
+// instead of 1 + p + p^2 (100 MB instead of 200 MB at p = 5000).
+__device__ __forceinline__ int64_t tri_off(int64_t i, int64_t j, int64_t p) { return i * p - i * (i - 1) / 2 + (j - i); }
+
+__global__ __launch_bounds__(256) void stats_pack_kernel(const double* __restrict__ buf, double* __restrict__ packed,
+                                                         int p) {
+  const int64_t total = (int64_t)p * p;
+  const double* Q = buf + 1 + p;
+  double* T = packed + 1 + p;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+    const int64_t i = o / p, j = o - i * p;
+    if (j >= i) T[tri_off(i, j, p)] = Q[o];
+    if (o <= p) packed[o] = buf[o];   // n_b and S
+  }
+}
+
+__global__ __launch_bounds__(256) void stats_unpack_kernel(const double* __restrict__ packed, double* __restrict__ buf,
+                                                           int p) {
+  const int64_t total = (int64_t)p * p;
+  double* Q = buf + 1 + p;
+  const double* T = packed + 1 + p;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+    const int64_t i = o / p, j = o - i * p;
+    Q[o] = (j >= i) ? T[tri_off(i, j, p)] : T[tri_off(j, i, p)];
+    if (o <= p) buf[o] = packed[o];
+  }
+}
+
+int64_t stats_packed_count(int p) { return (int64_t)1 + p + (int64_t)p * (p + 1) / 2; }
+
+hipError_t launch_stats_pack(const double* buf, double* packed, int p, hipStream_t st) {
+  if (p < 1) return hipErrorInvalidValue;
+  const int64_t total = (int64_t)p * p;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(stats_pack_kernel, dim3(grid), dim3(256), 0, st, buf, packed, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_stats_unpack(const double* packed, double* buf, int p, hipStream_t st) {
+  if (p < 1) return hipErrorInvalidValue;
+  const int64_t total = (int64_t)p * p;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(stats_unpack_kernel, dim3(grid), dim3(256), 0, st, packed, buf, p);
+  return hipGetLastError();
+}
+
 // Chan et al. pairwise merge.  With delta = S / n_b (batch mean minus running mean):
 //   M2 += Q - n_b delta delta^T + (n n_b / (n + n_b)) delta delta^T ;  mean += (n_b / (n + n_b)) delta
 // M2 is updated by all workgroups first; mean and n by a second launch (stats_advance).

@@ -81,6 +81,12 @@ hipError_t launch_stats_batch(const double* lifts, const double* mean, double* b
 hipError_t launch_stats_merge(const double* buf, double* state_n, double* mean, double* M2, int p,
                               hipStream_t st);
 
+// upper-triangle packing of the pending-batch buffer for the all-reduce (Q is symmetric):
+// packed = [n_b, S (p), Q[i][i..p-1] ...], stats_packed_count(p) = 1 + p + p (p + 1) / 2 elements
+int64_t stats_packed_count(int p);
+hipError_t launch_stats_pack(const double* buf, double* packed, int p, hipStream_t st);
+hipError_t launch_stats_unpack(const double* packed, double* buf, int p, hipStream_t st);
+
 // theta = L^-T z for the factor stored in A (identity ordering), single workgroup; theta is fp64
 hipError_t launch_backsolve(const void* A, double* theta, int p, int p_pad, int f32, hipStream_t st);
 

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "comm.h"
 #include "kernels.h"
 #include "tiles.h"
 
@@ -85,6 +86,11 @@ struct lsspa_ctx {
   int64_t hist_cap = 0, hist_n = 0;
   int ldh() const { return ((p + 127) / 128) * 128; }
   int flags = 0;
+  // collectives (RCCL), see comm.h
+  Comm* comm = nullptr;
+  DevBuf<double> pack, xfer;     // packed moments; staging of host-side all-gathers
+  DevBuf<int64_t> ibuf;
+  int pack_from_p = 2048;        // the moments travel as an upper triangle from this p on
   int fail_alloc_in = 0;   // test hook (lsspa_debug_fail_alloc): the n-th device allocation from now fails
 
   // profiling
@@ -652,6 +658,9 @@ int lsspa_destroy(lsspa_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_join);
   }
   dev_free(ctx->hist); dev_free(ctx->xi_d); dev_free(ctx->draws); dev_free(ctx->err_out);
+  comm_destroy(ctx->comm);
+  ctx->comm = nullptr;
+  dev_free(ctx->pack); dev_free(ctx->xfer); dev_free(ctx->ibuf);
   for (int b = 0; b < 2; ++b) {
     if (ctx->perms_h[b]) (void)hipHostFree(ctx->perms_h[b]);
     if (ctx->perms_ev[b]) (void)hipEventDestroy(ctx->perms_ev[b]);
@@ -868,14 +877,12 @@ static int reduce_rows(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, co
 static int reduce_finalize(lsspa_ctx* ctx, int64_t N_total, double reg) {
   const int p = ctx->p;
   const size_t c_elems = (size_t)round_up(p + 1, 128) * round_up(p + 1, 128);
-  {
-    ProfScope ps(ctx, LSSPA_K_GRAM);
-    HIPCHK(launch_gram_finalize(ctx->Cred.ptr, p, 1.0 / (double)N_total, reg, ctx->G.ptr, ctx->p_pad, ctx->g.ptr,
-                                ctx->scal.ptr + 0, ctx->stream));
-    if (ctx->tri)
-      HIPCHK(launch_gram_finalize(ctx->Cred.ptr + c_elems, p, 1.0, 0.0, ctx->H.ptr, ctx->p_pad, ctx->h.ptr,
-                                  ctx->scal.ptr + 1, ctx->stream));
-  }
+  // (not part of the LSSPA_K_GRAM timing class: that class counts the Gram contractions, one launch per side)
+  HIPCHK(launch_gram_finalize(ctx->Cred.ptr, p, 1.0 / (double)N_total, reg, ctx->G.ptr, ctx->p_pad, ctx->g.ptr,
+                              ctx->scal.ptr + 0, ctx->stream));
+  if (ctx->tri)
+    HIPCHK(launch_gram_finalize(ctx->Cred.ptr + c_elems, p, 1.0, 0.0, ctx->H.ptr, ctx->p_pad, ctx->h.ptr,
+                                ctx->scal.ptr + 1, ctx->stream));
   double sc[2];
   HIPCHK(hipMemcpyAsync(sc, ctx->scal.ptr, sizeof sc, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1316,6 +1323,117 @@ int lsspa_error_quantiles(lsspa_ctx* ctx, double* feature_errors, double* overal
 }
 
 // ---------------------------------------------------------------------------------------------
+// Collectives: RCCL on the context's stream, so kernels -> all-reduce -> merge need no host synchronisation.
+int lsspa_comm_unique_id(uint8_t* id128) {
+  std::string err;
+  if (comm_unique_id(id128, err) != 0) {
+    g_create_error = err;
+    return LSSPA_ERR_HIP;
+  }
+  return LSSPA_OK;
+}
+
+int lsspa_comm_init(lsspa_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!id128 || world < 1 || rank < 0 || rank >= world) return ctx->fail(LSSPA_ERR_ARG, "need an id and 0 <= rank < world");
+  if (ctx->comm) return ctx->fail(LSSPA_ERR_STATE, "this context already has a communicator");
+  HIPCHK(hipSetDevice(ctx->device));
+  std::string err;
+  if (comm_create(id128, rank, world, ctx->device, &ctx->comm, err) != 0) return ctx->fail(LSSPA_ERR_HIP, err.c_str());
+  return LSSPA_OK;
+}
+
+int lsspa_comm_destroy(lsspa_ctx* ctx) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->comm) return LSSPA_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  comm_destroy(ctx->comm);
+  ctx->comm = nullptr;
+  return LSSPA_OK;
+}
+
+int lsspa_comm_info(const lsspa_ctx* ctx, int32_t* rank, int32_t* world) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (rank) *rank = comm_rank(ctx->comm);
+  if (world) *world = comm_world(ctx->comm);
+  return ctx->comm ? LSSPA_OK : LSSPA_ERR_STATE;
+}
+
+static int allreduce_buffer(lsspa_ctx* ctx, double* buf, size_t count) {
+  std::string err;
+  if (comm_allreduce_f64(ctx->comm, buf, count, ctx->stream, err) != 0) return ctx->fail(LSSPA_ERR_HIP, err.c_str());
+  return LSSPA_OK;
+}
+
+int lsspa_stats_allreduce(lsspa_ctx* ctx) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  if (!ctx->comm) return ctx->fail(LSSPA_ERR_STATE, "no communicator: call lsspa_comm_init first");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int p = ctx->p;
+  ProfScope ps(ctx, LSSPA_K_COMM);
+  if (p < ctx->pack_from_p) return allreduce_buffer(ctx, ctx->pend.ptr, (size_t)1 + p + (size_t)p * p);
+  const size_t cnt = (size_t)stats_packed_count(p);
+  TRY(dev_alloc(ctx, ctx->pack, cnt));
+  HIPCHK(launch_stats_pack(ctx->pend.ptr, ctx->pack.ptr, p, ctx->stream));
+  TRY(allreduce_buffer(ctx, ctx->pack.ptr, cnt));
+  HIPCHK(launch_stats_unpack(ctx->pack.ptr, ctx->pend.ptr, p, ctx->stream));
+  return LSSPA_OK;
+}
+
+int lsspa_reduce_allreduce(lsspa_ctx* ctx) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->reduce_open) return ctx->fail(LSSPA_ERR_STATE, "no partial reduction in progress");
+  if (!ctx->comm) return ctx->fail(LSSPA_ERR_STATE, "no communicator: call lsspa_comm_init first");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t P1pad = (size_t)round_up(ctx->p + 1, 128);
+  ProfScope ps(ctx, LSSPA_K_COMM);
+  return allreduce_buffer(ctx, ctx->Cred.ptr, 2 * P1pad * P1pad);
+}
+
+int lsspa_error_allreduce(lsspa_ctx* ctx) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (ctx->hist_cap == 0) return ctx->fail(LSSPA_ERR_STATE, "history is not enabled");
+  if (!ctx->comm) return ctx->fail(LSSPA_ERR_STATE, "no communicator: call lsspa_comm_init first");
+  HIPCHK(hipSetDevice(ctx->device));
+  ProfScope ps(ctx, LSSPA_K_COMM);
+  return allreduce_buffer(ctx, ctx->draws.ptr, (size_t)ERR_DRAWS * ctx->ldh());
+}
+
+int lsspa_comm_sum_i64(lsspa_ctx* ctx, int64_t* values, int32_t count) {
+  if (!ctx || !values || count < 1) return LSSPA_ERR_ARG;
+  if (!ctx->comm) return ctx->fail(LSSPA_ERR_STATE, "no communicator: call lsspa_comm_init first");
+  HIPCHK(hipSetDevice(ctx->device));
+  TRY(dev_alloc(ctx, ctx->ibuf, (size_t)count));
+  HIPCHK(hipMemcpyAsync(ctx->ibuf.ptr, values, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
+  std::string err;
+  if (comm_allreduce_i64(ctx->comm, ctx->ibuf.ptr, (size_t)count, ctx->stream, err) != 0)
+    return ctx->fail(LSSPA_ERR_HIP, err.c_str());
+  HIPCHK(hipMemcpyAsync(values, ctx->ibuf.ptr, (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LSSPA_OK;
+}
+
+int lsspa_comm_allgather(lsspa_ctx* ctx, const double* send, int64_t count, double* recv) {
+  if (!ctx || count < 0 || (count > 0 && (!send || !recv))) return LSSPA_ERR_ARG;
+  if (!ctx->comm) return ctx->fail(LSSPA_ERR_STATE, "no communicator: call lsspa_comm_init first");
+  if (count == 0) return LSSPA_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t world = (size_t)comm_world(ctx->comm), cnt = (size_t)count;
+  TRY(dev_alloc(ctx, ctx->xfer, (world + 1) * cnt));
+  double* d_send = ctx->xfer.ptr;
+  double* d_recv = ctx->xfer.ptr + cnt;
+  HIPCHK(hipMemcpyAsync(d_send, send, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+  std::string err;
+  if (comm_allgather_f64(ctx->comm, d_send, d_recv, cnt, ctx->stream, err) != 0)
+    return ctx->fail(LSSPA_ERR_HIP, err.c_str());
+  HIPCHK(hipMemcpyAsync(recv, d_recv, world * cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LSSPA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 int lsspa_profile_enable(lsspa_ctx* ctx, int32_t on) {
   if (!ctx) return LSSPA_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
@@ -1348,6 +1466,12 @@ int lsspa_profile_reset(lsspa_ctx* ctx) {
 int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags) {
   if (!ctx) return LSSPA_ERR_ARG;
   ctx->flags = flags;
+  return LSSPA_OK;
+}
+
+int lsspa_debug_pack_from(lsspa_ctx* ctx, int32_t p_min) {
+  if (!ctx || p_min < 1) return LSSPA_ERR_ARG;
+  ctx->pack_from_p = p_min;
   return LSSPA_OK;
 }
 

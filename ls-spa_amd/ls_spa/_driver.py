@@ -326,7 +326,7 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
 def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_size=2 ** 8,
            tolerance=1e-2, seed=42, perms=None, antithetical=True, return_attribution_history=False, *,
            method=None, num_batches=None, return_history=None, device=0, error_estimator="reference",
-           precision="float64", row_sharded=False, checkpoint=None, _engine=None, _comm=None):
+           precision="float64", row_sharded=False, checkpoint=None, comm=None, _engine=None, _comm=None):
     """Estimates the Shapley attribution of the out-of-sample R^2 of a least-squares fit.
 
     Positional parameters, defaults and behaviour follow cvxgrp/ls-spa
@@ -345,7 +345,11 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         the Gram reduction, lift accumulation and statistics stay float64).
     checkpoint:  path of a state file, written after every error check and resumed from if it exists
         (same data, seed and sampler required); with several ranks every rank keeps ``<path>.rank<r>``.
-    row_sharded:  several ranks only (``_comm``).  False: every rank passes the whole data set.
+    comm:  several GPUs, one process each: the communicator every rank passes -- ``NativeComm.from_env()``
+        (RCCL through the C ABI, no PyTorch) or ``TorchComm()`` (torch.distributed: RCCL, or gloo on CPU in
+        the tests).  The orderings of every chunk are dealt round-robin over the ranks; the only data-path
+        collective is one all-reduce of the packed batch moments per chunk.
+    row_sharded:  several ranks only (``comm``).  False: every rank passes the whole data set.
         True: the four arrays are this rank's ROWS of the training and test sets; the ranks reduce
         their rows and sum the Gram matrices with one all-reduce.  'train': only the training rows are
         sharded, every rank passes all test rows (needed when there are fewer than p test rows).
@@ -365,25 +369,28 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
     if error_estimator not in ("reference", "lowrank", "device"):
         raise ValueError("error_estimator must be 'reference', 'lowrank' or 'device'")
 
+    comm = comm if comm is not None else _comm
     engine = _engine
     owns = engine is None
     if owns:
         from ._engine import HipEngine
         engine = HipEngine(device)
     try:
+        if comm is not None and hasattr(comm, "bind"):
+            comm.bind(engine)      # RCCL communicator on this engine's GPU and stream (collective)
         if precision != "float64" or getattr(engine, "precision", "float64") != "float64":
             engine.set_precision(precision)
         prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
                                     antithetical=antithetical, method=method)
         if row_sharded:
-            engine.load_data_sharded(X_train, X_test, y_train, y_test, reg, _comm or _Comm(),
+            engine.load_data_sharded(X_train, X_test, y_train, y_test, reg, comm or _Comm(),
                                      shard_test=row_sharded != "train")
         else:
             engine.load_data(X_train, X_test, y_train, y_test, reg)
         attribution, feat_err, total_err, err_hist, history, _ = run_estimator(
             engine, p, max_samples=max_samples, batch_size=batch_size, tolerance=tolerance, seed=seed,
             perms=perms, antithetical=antithetical, return_attribution_history=return_attribution_history,
-            method=method, error_estimator=error_estimator, comm=_comm, checkpoint=checkpoint, prepared=prepared)
+            method=method, error_estimator=error_estimator, comm=comm, checkpoint=checkpoint, prepared=prepared)
         theta, r_squared, info = engine.full_fit()
         if info or engine.info():
             warnings.warn("a permuted Gram matrix was not numerically positive definite; the attribution "
@@ -401,6 +408,8 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
                 r_squared = float((2.0 * (pred @ y_test) - pred @ pred) / yy)
     finally:
         if owns:
+            if comm is not None and hasattr(comm, "close"):
+                comm.close()       # the communicator lives on the engine's context
             engine.close()
     return ShapleyResults(attribution=attribution, theta=theta, overall_error=total_err,
                           attribution_errors=feat_err, r_squared=r_squared, error_history=err_hist,

@@ -14,7 +14,7 @@ OK = 0
 F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
 INFO_NOT_PD = 1
-KERNEL_CLASSES = ("gather", "chol_diag", "chol_panel", "strip", "lift", "stats", "gram", "error")
+KERNEL_CLASSES = ("gather", "chol_diag", "chol_panel", "strip", "lift", "stats", "gram", "error", "comm")
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.normpath(os.path.join(_PKG_DIR, "..", "lib", "liblsspa_hip.so"))
@@ -67,6 +67,16 @@ SIGNATURES = {
     "lsspa_set_flags": (C.c_int, [_vp, _i32]),
     "lsspa_set_precision": (C.c_int, [_vp, _i32]),
     "lsspa_debug_fail_alloc": (C.c_int, [_vp, _i32]),
+    "lsspa_debug_pack_from": (C.c_int, [_vp, _i32]),
+    "lsspa_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "lsspa_comm_init": (C.c_int, [_vp, C.POINTER(C.c_uint8), _i32, _i32]),
+    "lsspa_comm_destroy": (C.c_int, [_vp]),
+    "lsspa_comm_info": (C.c_int, [_vp, _pi32, _pi32]),
+    "lsspa_stats_allreduce": (C.c_int, [_vp]),
+    "lsspa_reduce_allreduce": (C.c_int, [_vp]),
+    "lsspa_error_allreduce": (C.c_int, [_vp]),
+    "lsspa_comm_sum_i64": (C.c_int, [_vp, _pi64, _i32]),
+    "lsspa_comm_allgather": (C.c_int, [_vp, _pd, _i64, _pd]),
     "lsspa_mfma_probe": (C.c_int, [_vp, _pd, _pd, _pd, _i32]),
     "lsspa_debug_factor": (C.c_int, [_vp, _pi32, _pd, _pd, _pd, _pi32, _pi32, _pi32]),
 }
@@ -76,29 +86,19 @@ def library_path() -> str:
     return _LIB_PATH
 
 
-def _preload_hip_runtime():
-    """One process must not hold two HIP runtimes.  PyTorch-ROCm wheels bundle their own
-    libamdhip64; if that PyTorch is installed, bind to ITS runtime (without importing torch), so
-    that a later ``import torch`` -- bench.py and the torch.distributed layer do that -- finds the
-    runtime it expects already loaded instead of a second, system-wide one ("No HIP GPUs are
-    available").  Without PyTorch the system ROCm runtime is used."""
-    import importlib.util
-    import sys
-    if "torch" in sys.modules:
+def _explicit_hip_runtime():
+    """``LSSPA_HIP_RUNTIME=/path/to/libamdhip64.so``: bind the engine to that HIP runtime instead of the one the
+    dynamic loader finds (the system ROCm).  One process must not hold two HIP runtimes; a host application that
+    bundles its own (a PyTorch-ROCm wheel does) and is imported AFTER this package would load a second one.  Either
+    import that application first -- the engine then shares its runtime, nothing to set -- or name its runtime
+    here.  The package itself never looks for PyTorch."""
+    path = os.environ.get("LSSPA_HIP_RUNTIME")
+    if not path:
         return
     try:
-        spec = importlib.util.find_spec("torch")
-    except Exception:
-        spec = None
-    if spec is None or not spec.submodule_search_locations:
-        return
-    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
-    cand = os.path.join(libdir, "libamdhip64.so")
-    if os.path.exists(cand):
-        try:
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError as exc:
+        raise LSSPANativeError(f"LSSPA_HIP_RUNTIME={path}: {exc}") from exc
 
 
 def load():
@@ -110,7 +110,7 @@ def load():
         raise LSSPANativeError(
             f"{_LIB_PATH} is missing: build it with `python ls-spa_amd/build.py` "
             "(needs hipcc; there is no CPU fallback)")
-    _preload_hip_runtime()
+    _explicit_hip_runtime()
     try:
         lib = C.CDLL(_LIB_PATH)
     except OSError as exc:  # e.g. libamdhip64 not found

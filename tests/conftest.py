@@ -4,6 +4,14 @@ import sys
 import numpy as np
 import pytest
 
+# Some GPU tests use PyTorch next to the engine (device-resident test data, the torch.distributed transport).  A
+# PyTorch-ROCm wheel bundles its own HIP runtime and one process must hold only one: imported first, PyTorch's is
+# the one the engine library binds to as well (ls_spa/_native.py).  The product path itself never imports torch.
+try:
+    import torch  # noqa: F401
+except Exception:   # pragma: no cover - PyTorch is optional for the CPU tests
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for sub in ("ls-spa_amd", "oracle"):
     path = os.path.join(ROOT, sub)

@@ -25,20 +25,20 @@ def _worker(rank, world, port, out_dir):
     d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
     eng = OracleEngine()
     res = ls_spa(*d, perms=g["perms64"][:50], batch_size=16, tolerance=0.0,
-                 return_attribution_history=True, _engine=eng, _comm=TorchComm())
+                 return_attribution_history=True, _engine=eng, comm=TorchComm())
     # thin-form estimator with the samples spread over the ranks: partial draws + one all-reduce
     eng2 = OracleEngine()
     dev = ls_spa(*d, perms=g["perms64"][:50], batch_size=16, tolerance=0.0, error_estimator="device",
-                 _engine=eng2, _comm=TorchComm())
+                 _engine=eng2, comm=TorchComm())
     # row-sharded reduction: this rank holds every second row of both sets
     eng3 = OracleEngine()
     shard = ls_spa(d[0][rank::world], d[1][rank::world], d[2][rank::world], d[3][rank::world],
                    perms=g["perms64"][:20], batch_size=16, tolerance=0.0, row_sharded=True,
-                   _engine=eng3, _comm=TorchComm())
+                   _engine=eng3, comm=TorchComm())
     # only the training rows sharded, every rank holds all test rows
     eng4 = OracleEngine()
     shard_tr = ls_spa(d[0][rank::world], d[1], d[2][rank::world], d[3], perms=g["perms64"][:20], batch_size=16,
-                      tolerance=0.0, row_sharded="train", _engine=eng4, _comm=TorchComm())
+                      tolerance=0.0, row_sharded="train", _engine=eng4, comm=TorchComm())
     # checkpoint / resume with two ranks: one state file per rank, killed in the third batch, resumed
     class Dies(OracleEngine):
         def run_batch(self, *a, **k):
@@ -49,7 +49,7 @@ def _worker(rank, world, port, out_dir):
     kw = dict(perms=None, method="argsort", seed=3, max_samples=80, batch_size=16, tolerance=0.0,
               error_estimator="device")
     try:
-        ls_spa(*d, checkpoint=ck, _engine=Dies(), _comm=TorchComm(), **kw)
+        ls_spa(*d, checkpoint=ck, _engine=Dies(), comm=TorchComm(), **kw)
     except KeyboardInterrupt:
         pass
     # ... and between the two ranks' renames of the second check: rank 1 is left one generation behind (its newest
@@ -58,11 +58,11 @@ def _worker(rank, world, port, out_dir):
     if rank == 1:
         os.replace(ck + ".rank1.prev", ck + ".rank1")
     dist.barrier()
-    resumed = ls_spa(*d, checkpoint=ck, _engine=OracleEngine(), _comm=TorchComm(), **kw)
+    resumed = ls_spa(*d, checkpoint=ck, _engine=OracleEngine(), comm=TorchComm(), **kw)
     # a rank whose files are gone next to a rank that has them: every rank raises, nobody runs ahead alone
     ck2 = os.path.join(out_dir, "state2.npz")
     try:
-        ls_spa(*d, checkpoint=ck2, _engine=Dies(), _comm=TorchComm(), **kw)
+        ls_spa(*d, checkpoint=ck2, _engine=Dies(), comm=TorchComm(), **kw)
     except KeyboardInterrupt:
         pass
     dist.barrier()
@@ -71,7 +71,7 @@ def _worker(rank, world, port, out_dir):
         os.remove(ck2 + ".rank1.prev")
     dist.barrier()
     try:
-        ls_spa(*d, checkpoint=ck2, _engine=OracleEngine(), _comm=TorchComm(), **kw)
+        ls_spa(*d, checkpoint=ck2, _engine=OracleEngine(), comm=TorchComm(), **kw)
         lonely = "ran"
     except ValueError as exc:
         lonely = "refused" if "no common state" in str(exc) else str(exc)

@@ -30,7 +30,7 @@ def test_pending_buffer_is_a_zero_copy_device_tensor_and_allreduce_runs(golden):
         lifts = eng.run_batch(g["perms64"][:16], True, want_lifts=True, accumulate=True)
         eng.synchronize()
         comm = TorchComm()
-        t = comm._as_tensor(eng.pending_buffer())
+        t = comm._as_tensor(eng.pending_buffer(), eng)
         assert t.is_cuda and t.dtype == torch.float64 and t.numel() == 1 + 12 + 144
         host = t.cpu().numpy()
         assert host[0] == 16.0
@@ -68,14 +68,14 @@ def test_pending_buffer_is_a_zero_copy_device_tensor_and_allreduce_runs(golden):
         all_l.close()
         # full driver through the communicator == without it
         a = ls_spa(*d, perms=g["perms64"], batch_size=16, tolerance=0.0, return_attribution_history=True,
-                   _comm=TorchComm())
+                   comm=TorchComm())
         b = ls_spa(*d, perms=g["perms64"], batch_size=16, tolerance=0.0, return_attribution_history=True)
         np.testing.assert_array_equal(a.attribution, b.attribution)
         np.testing.assert_array_equal(a.attribution_history, b.attribution_history)
         # row-sharded reduction and the device-side estimator through the collective path (forced, world of 1)
         cf = TorchComm(force_collective=True)
         c = ls_spa(*d, perms=g["perms64"], batch_size=16, tolerance=0.0, row_sharded=True,
-                   error_estimator="device", _comm=cf)
+                   error_estimator="device", comm=cf)
         e = ls_spa(*d, perms=g["perms64"], batch_size=16, tolerance=0.0, error_estimator="lowrank")
         np.testing.assert_allclose(c.attribution, b.attribution, rtol=0, atol=1e-13)
         np.testing.assert_allclose(c.theta, b.theta, rtol=1e-12)

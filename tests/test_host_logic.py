@@ -336,3 +336,61 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(base, f)).read()
                 assert "lsspa_oracle" not in text and "oracle_engine" not in text, f
+
+
+def test_unique_id_rendezvous_three_ranks():
+    """exchange_unique_id: rank 0 makes the id once and serves it, the others fetch it (started BEFORE the server is
+    up, so they retry); a stray connection that does not speak the protocol is ignored."""
+    import socket
+    import threading
+    from ls_spa._rccl import ID_BYTES, exchange_unique_id
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    made = []
+
+    def make_id():
+        made.append(1)
+        return bytes(range(ID_BYTES))
+
+    got = {}
+
+    def run(rank, delay):
+        import time
+        time.sleep(delay)
+        got[rank] = exchange_unique_id(rank, 3, "127.0.0.1", port, make_id, timeout=30.0)
+
+    def stray():
+        import time
+        time.sleep(0.25)
+        try:
+            with socket.create_connection(("127.0.0.1", port), timeout=5.0) as c:
+                c.sendall(b"GET / HTTP/1.0\r\n\r\n")
+        except OSError:
+            pass
+
+    threads = [threading.Thread(target=run, args=(1, 0.0)), threading.Thread(target=run, args=(2, 0.4)),
+               threading.Thread(target=stray), threading.Thread(target=run, args=(0, 0.2))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert len(made) == 1
+    assert got[0] == got[1] == got[2] == bytes(range(ID_BYTES))
+    assert exchange_unique_id(0, 1, "127.0.0.1", port, make_id) == bytes(range(ID_BYTES))   # world of one: no socket
+
+
+def test_gather_ints_by_sum():
+    from ls_spa._driver import gather_ints_by_sum
+
+    class Two:
+        world = 2
+
+        def __init__(self, rank, other):
+            self.rank, self.other = rank, other
+
+        def sum_ints(self, flat):
+            return [a + b for a, b in zip(flat, self.other)]
+
+    # rank 1 contributes [7, -1] in its slot, rank 0 [3, 5]
+    assert gather_ints_by_sum(Two(0, [0, 0, 7, -1]), [3, 5]) == [[3, 5], [7, -1]]
