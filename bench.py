@@ -49,6 +49,12 @@ def parse():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--collective", choices=("native", "torch"), default="native",
                     help="transport of the all-reduce with several ranks: RCCL through the C ABI, or torch.distributed")
+    ap.add_argument("--lookahead", type=int, default=0,
+                    help="steps whose orderings are launched as one GPU batch and then accumulated / all-reduced / merged "
+                         "step by step (what ls_spa(lookahead=k) does); 0 = 4 when a rank's step has <= 32 samples, else 1")
+    ap.add_argument("--lanes", type=int, choices=(1, 2), default=1,
+                    help="batches in flight on the engine (lsspa_set_lanes): 2 = the next step's kernels run beside this one's")
+    ap.add_argument("--no-probe", action="store_true", help="skip the strong-scaling probe (clean rocprof averages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ttt", action="store_true", help="skip the time-to-tolerance runs")
     return ap.parse_args()
@@ -287,18 +293,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step(k):
-        eng.run_batch(my_perms[k], True, want_lifts=False, accumulate=True)
-        comm.allreduce_pending(eng)
-        eng.merge()
+    D = args.lookahead if args.lookahead > 0 else (4 if B_rank <= 32 else 1)
+
+    class Steps:
+        """step(k) = one batch of B_rank samples into the statistics.  With D > 1 the kernels of D consecutive steps
+        are launched together (one gather / factorisation / solve sequence over D * B_rank samples) and each step
+        then folds its own B_rank lift vectors into the pending buffer, all-reduces and merges -- the reference's
+        per-batch order, a fuller GPU.  Groups start at the first step of a region."""
+
+        def __init__(self):
+            self.ticket, self.base, self.end = None, 0, 0
+
+        def region(self, k0, k1):
+            self.base, self.end = k0, k1
+
+        def __call__(self, k):
+            if D == 1:
+                eng.run_batch(my_perms[k], True, want_lifts=False, accumulate=True)
+            else:
+                j = (k - self.base) % D
+                if j == 0:
+                    hi = min(k + D, self.end)
+                    self.ticket = eng.launch_batch(my_perms[k:hi].reshape(-1, p), True)
+                eng.collect_batch(self.ticket, want_lifts=False, accumulate=True, first=j * B_rank, count=B_rank)
+            comm.allreduce_pending(eng)
+            eng.merge()
+
+    step = Steps()
 
     # pass 1: the timed region proper (no events between the launches: an event record costs a
     # ~10 us bubble per kernel boundary)
     eng.profile(False)
     eng.reset_stats()
+    step.region(0, args.warmup)
     for k in range(args.warmup):
         step(k)
     barrier()
+    step.region(args.warmup, total_steps)
     t0 = time.perf_counter()
     for k in range(args.warmup, total_steps):
         step(k)
@@ -310,9 +341,11 @@ def main():
         elapsed = float(t.item())
     n_seen, mean, _ = eng.stats(want_cov=False)
     # pass 2: the same K steps again with a HIP-event pair around every launch on the engine's
-    # stream -> per-kernel durations for the roofline figures
+    # stream -> per-kernel durations for the roofline figures (one lane: each kernel alone on the GPU)
+    eng.set_lanes(1)
     eng.profile(True)
     eng.profile_reset()
+    step.region(args.warmup, total_steps)
     for k in range(args.warmup, total_steps):
         step(k)
     barrier()
@@ -321,23 +354,34 @@ def main():
 
     # what one of 8 ranks runs per step under strong scaling (C4): batch_size / 8 samples on this GPU
     probe = None
-    if world == 1 and B >= 16 and args.scaling == "weak":
-        b8 = B // 8
-        sub = np.ascontiguousarray(my_perms[0][:b8])
-        for _ in range(3):
-            eng.run_batch(sub, True, want_lifts=False, accumulate=True)
-            eng.merge()
-        eng.synchronize()
-        reps = 20
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            eng.run_batch(sub, True, want_lifts=False, accumulate=True)
-            eng.merge()
-        eng.synchronize()
-        ms8 = 1e3 * (time.perf_counter() - t0) / reps
-        probe = {"samples_per_step": b8, "orderings_per_step": 2 * b8, "ms_per_step": ms8,
-                 "orderings_per_s": 2 * b8 / (ms8 * 1e-3),
-                 "note": "the per-rank step of an 8-GPU run with the global batch dealt over the ranks (--scaling strong)"}
+    if world == 1 and B >= 16 and args.scaling == "weak" and not args.no_probe:
+        eng.set_lanes(args.lanes)
+        b8, dd, reps = B // 8, 4, 24
+        pool = np.ascontiguousarray(my_perms[:2].reshape(-1, p)[: dd * b8])
+
+        def probe_steps(group):
+            for r in range(reps):
+                j = r % group
+                if group == 1:
+                    eng.run_batch(pool[:b8], True, want_lifts=False, accumulate=True)
+                else:
+                    if j == 0:
+                        tk = eng.launch_batch(pool[: group * b8], True)
+                    eng.collect_batch(tk, want_lifts=False, accumulate=True, first=j * b8, count=b8)
+                eng.merge()
+            eng.synchronize()
+
+        res = {}
+        for group in (1, dd):
+            probe_steps(group)
+            t0 = time.perf_counter()
+            probe_steps(group)
+            res[group] = 1e3 * (time.perf_counter() - t0) / reps
+        probe = {"samples_per_step": b8, "orderings_per_step": 2 * b8, "ms_per_step": res[dd],
+                 "orderings_per_s": 2 * b8 / (res[dd] * 1e-3), "lookahead": dd, "ms_per_step_without_lookahead": res[1],
+                 "note": "the per-rank step of an 8-GPU run with the global batch dealt over the ranks (--scaling strong): "
+                         "kernels of 4 steps launched together, statistics / all-reduce / merge per step"}
+        eng.set_lanes(1)
 
     out = None
     if rank == 0:
@@ -376,7 +420,7 @@ def main():
                                    f"{'fp64' if args.dtype == 'f64' else 'fp32 data and per-ordering work / fp64 accumulation'}",
                        "p": p, "N": rows, "M": rows, "reg": reg, "batch_size": B, "global_batch": B * world if
                        args.scaling == "weak" else B, "orderings_per_step_per_gpu": n_ord,
-                       "path": "tri" if eng.tri else "rect", "collective": collective,
+                       "path": "tri" if eng.tri else "rect", "collective": collective, "lanes": args.lanes, "lookahead": D,
                        "data_generator": "BASELINE.md section 3: default_rng(0) on the host, moved to HBM before timing"},
             "roofline": roofline,
             "kernels": per_class,

@@ -100,6 +100,24 @@ int lsspa_get_factors(lsspa_ctx* ctx, double* R_tr, double* q_tr, double* F_te, 
  * moments about the running mean to the pending-batch buffer (a4). */
 int lsspa_lift_batch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t antithetical,
                      double* lifts_out, int32_t accumulate);
+/* The two halves of lsspa_lift_batch.  lsspa_lift_launch enqueues every kernel of a batch up to its lift vectors and
+ * returns a ticket; nothing it does touches the running statistics.  lsspa_lift_collect folds `count` samples of the
+ * ticket's batch, from sample `first` on, into the pending buffer (accumulate) and / or copies their lift vectors out
+ * (count <= 0: all the rest); the parts of a batch are taken front to back.  lsspa_lift_discard drops what is left.
+ * Why: the reference evaluates its stop rule after every batch_size samples (ls_spa/ls_spa.py:222-230); a batch
+ * that small may fill a fraction of the GPU (16 samples per rank when 128 are dealt over 8 GPUs).  The driver
+ * therefore launches several chunks of a QMC sampler's orderings as ONE batch, accumulates and checks them chunk by
+ * chunk in the reference's order, and discards the chunks beyond a stop -- same results, a fuller GPU.  With two
+ * lanes (lsspa_set_lanes) a second batch may be launched before the first is fully collected. */
+int lsspa_lift_launch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t antithetical, int32_t* ticket);
+int lsspa_lift_collect(lsspa_ctx* ctx, int32_t ticket, int32_t first, int32_t count, double* lifts_out,
+                       int32_t accumulate);
+int lsspa_lift_discard(lsspa_ctx* ctx, int32_t ticket);
+/* 1 (default): every batch runs on the context's stream, one after the other.  2: successive batches alternate
+ * between two workspaces on two streams, staggered by half a batch, so that the memory-bound stages (gather, lifts)
+ * and the launch tails of one batch run beside the matrix-pipe-bound stages of the other; statistics, collectives
+ * and merges stay in batch order on the context's stream.  Results do not depend on the setting. */
+int lsspa_set_lanes(lsspa_ctx* ctx, int32_t n);
 int lsspa_get_info(lsspa_ctx* ctx, int32_t* info);
 
 /* a4 -- replaces merge_sample_mean / merge_sample_cov (ls_spa/ls_spa.py:103-119, :212-216).

@@ -36,6 +36,45 @@ struct DevBuf {
 
 }  // namespace
 
+// One lane = everything a batch of orderings needs while its kernels run: work matrices, solve results, staged
+// orderings, its lift vectors.  With one lane (default) every batch runs on the context's stream, one after the
+// other.  With two lanes (lsspa_set_lanes) successive batches alternate between two workspaces on two streams: the
+// kernels of batch k+1 are in flight while batch k drains its launch tails, runs its memory-bound stages or waits
+// for its collective -- the statistics (pending buffer, all-reduce, merge) stay in batch order on the context's
+// stream.  A lane's batch starts when the other lane's batch is about half done (ev_mid), so the two are in
+// different stages (gather / early panels of one beside the late panels / strip of the other) instead of in step.
+struct Lane {
+  hipStream_t st = nullptr;          // own stream (two-lane mode)
+  int cap_ord = 0;                   // orderings the workspace can hold
+  int cap_samples = 0;               // samples the lifts buffer can hold
+  DevBuf<char> A, V, Dinv;           // raw bytes: esz() per element
+  DevBuf<double> Ppart, lifts, diag0;
+  DevBuf<int32_t> perms_d;
+  // pinned staging of the orderings: two buffers in turn, each guarded by the event of its last
+  // H2D copy, so the host can prepare batch k+1 while the GPU still runs batch k (no stream sync)
+  int32_t* perms_h[2] = {nullptr, nullptr};
+  hipEvent_t perms_ev[2] = {nullptr, nullptr};
+  bool perms_busy[2] = {false, false};
+  int perms_turn = 0;
+  size_t perms_h_count = 0;
+  // the device side is double-buffered too ([2][cap_ord][p]) and fed by a copy stream, so the H2D copy of
+  // batch k+1 runs under the kernels of batch k instead of between two batches on the compute stream
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t perms_used[2] = {nullptr, nullptr};   // the kernels that read device slot b have run
+  bool perms_used_valid[2] = {false, false};
+  const int32_t* perms_cur = nullptr;              // device slot of the batch being launched
+  // second stream for the two-slice schedule of a batch (developer flag 32)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // two-lane hand-offs
+  hipEvent_t ev_mid = nullptr, ev_done = nullptr, ev_consumed = nullptr, ev_main = nullptr;
+  bool mid_valid = false, done_valid = false, consumed_valid = false;
+  bool mid_armed = false;            // the batch being launched still has to record ev_mid
+  int64_t problem_seen = -1;         // ctx->problem_epoch this lane's stream has been ordered behind
+  int B = 0, per = 1, taken = 0;     // the batch in flight (launched, `taken` of its B samples collected so far)
+  bool in_flight = false;
+};
+
 struct lsspa_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -50,27 +89,19 @@ struct lsspa_ctx {
   DevBuf<float> Gf, Hf;        // fp32 copies of G / H for the fp32 gather, made on first use
   bool src_f32_valid = false;
 
-  // per-batch workspace
-  int cap_ord = 0;      // orderings the workspace can hold
-  int cap_samples = 0;  // samples the lifts buffer can hold
+  // per-batch workspace: one or two LANES (struct Lane above), used in turn by successive batches
   int f32 = 0;          // element type of the per-ordering work matrices (0: double, 1: float)
-  DevBuf<char> A, V, Dinv;   // raw bytes: esz() per element
-  DevBuf<double> Ppart, lifts, diag0;
   size_t esz() const { return f32 ? 4 : 8; }
-  DevBuf<int32_t> perms_d, info_d;
-  // pinned staging of the orderings: two buffers in turn, each guarded by the event of its last
-  // H2D copy, so the host can prepare batch k+1 while the GPU still runs batch k (no stream sync)
-  int32_t* perms_h[2] = {nullptr, nullptr};
-  hipEvent_t perms_ev[2] = {nullptr, nullptr};
-  bool perms_busy[2] = {false, false};
-  int perms_turn = 0;
-  size_t perms_h_count = 0;
-  // the device side is double-buffered too ([2][cap_ord][p]) and fed by a copy stream, so the H2D copy of
-  // batch k+1 runs under the kernels of batch k instead of between two batches on the compute stream
-  hipStream_t copy_stream = nullptr;
-  hipEvent_t perms_used[2] = {nullptr, nullptr};   // the kernels that read device slot b have run
-  bool perms_used_valid[2] = {false, false};
-  const int32_t* perms_cur = nullptr;              // device slot of the batch being launched
+  DevBuf<int32_t> info_d;
+  Lane lanes[2];
+  int n_lanes = 1;      // lsspa_set_lanes
+  int lane_turn = 0;    // lane of the next batch
+  int lane_last = 0;    // lane of the most recent batch (its lifts are what lsspa_full_fit etc. read)
+  hipStream_t lane_stream(const Lane& L) const { return n_lanes == 1 ? stream : L.st; }
+  // two lanes: what the lanes' streams must see of the context's stream -- the loaded problem and its fp32 copies.
+  // An event recorded there whenever those change (problem_epoch counts the changes).
+  hipEvent_t ev_problem = nullptr;
+  int64_t problem_epoch = 0;
 
   // running statistics
   DevBuf<double> mean, M2, pend, state_n, stat_parts;
@@ -80,9 +111,6 @@ struct lsspa_ctx {
   // row-sharded reduction in progress: summed Gram buffers [2][P1pad][P1pad]
   DevBuf<double> Cred;
   bool reduce_open = false;
-  // second stream for the two-slice schedule of a batch
-  hipStream_t side_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int64_t hist_cap = 0, hist_n = 0;
   int ldh() const { return ((p + 127) / 128) * 128; }
   int flags = 0;
@@ -155,27 +183,31 @@ struct ProfScope {
   lsspa_ctx* ctx;
   ProfRec rec;
   bool live;
-  ProfScope(lsspa_ctx* c, int cls) : ctx(c), live(false) {
+  hipStream_t st;
+  ProfScope(lsspa_ctx* c, int cls, hipStream_t on = nullptr) : ctx(c), live(false), st(on) {
     if (!c || !c->prof_on) return;
+    if (!st) st = c->stream;
     rec.cls = cls;
     if (hipEventCreate(&rec.beg) != hipSuccess) return;
     if (hipEventCreate(&rec.end) != hipSuccess) {
       (void)hipEventDestroy(rec.beg);
       return;
     }
-    (void)hipEventRecord(rec.beg, c->stream);
+    (void)hipEventRecord(rec.beg, st);
     live = true;
   }
   ~ProfScope() {
     if (!live) return;
-    (void)hipEventRecord(rec.end, ctx->stream);
+    (void)hipEventRecord(rec.end, st);
     ctx->prof_recs.push_back(rec);
   }
 };
 
+int sync_all(lsspa_ctx* ctx);
+
 int prof_collect(lsspa_ctx* ctx) {
   if (ctx->prof_recs.empty()) return LSSPA_OK;
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  TRY(sync_all(ctx));
   for (auto& r : ctx->prof_recs) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.beg, r.end) == hipSuccess) {
@@ -219,24 +251,39 @@ __global__ void sumsq_kernel(const double* __restrict__ v, int n, double* __rest
 // ---- problem set-up -----------------------------------------------------------------------
 // Drop the per-batch workspace (it is re-created on demand).  The capacities are zeroed FIRST, so that a context
 // whose next allocation fails is left with "no workspace", never with a capacity that points at freed buffers.
+void free_lane_workspace(Lane& L) {
+  L.cap_ord = 0;
+  L.cap_samples = 0;
+  L.perms_used_valid[0] = L.perms_used_valid[1] = false;
+  dev_free(L.A);
+  dev_free(L.V);
+  dev_free(L.Dinv);
+  dev_free(L.diag0);
+  dev_free(L.Ppart);
+  dev_free(L.perms_d);
+  dev_free(L.lifts);
+}
+
 void free_workspace(lsspa_ctx* ctx) {
-  ctx->cap_ord = 0;
-  ctx->cap_samples = 0;
-  ctx->perms_used_valid[0] = ctx->perms_used_valid[1] = false;
-  dev_free(ctx->A);
-  dev_free(ctx->V);
-  dev_free(ctx->Dinv);
-  dev_free(ctx->diag0);
-  dev_free(ctx->Ppart);
-  dev_free(ctx->perms_d);
-  dev_free(ctx->lifts);
+  for (Lane& L : ctx->lanes) free_lane_workspace(L);
   dev_free(ctx->stat_parts);
+}
+
+// wait for everything this context has in flight: the lanes' streams and the context's own
+int sync_all(lsspa_ctx* ctx) {
+  for (Lane& L : ctx->lanes) {
+    if (L.st) HIPCHK(hipStreamSynchronize(L.st));
+    if (L.copy_stream) HIPCHK(hipStreamSynchronize(L.copy_stream));
+    if (L.side_stream) HIPCHK(hipStreamSynchronize(L.side_stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LSSPA_OK;
 }
 
 int set_dims(lsspa_ctx* ctx, int p, int m, int tri) {
   if (p < 1 || m < 1) return ctx->fail(LSSPA_ERR_ARG, "p and m must be positive");
   if (tri && m != p) return ctx->fail(LSSPA_ERR_ARG, "tri mode needs m == p");
-  HIPCHK(hipStreamSynchronize(ctx->stream));  // buffers below may be re-allocated
+  TRY(sync_all(ctx));  // buffers below may be re-allocated
   ctx->have_problem = false;
   ctx->src_f32_valid = false;
   // a workspace sized for another shape is released now: kept, it would count as unavailable memory when the
@@ -319,62 +366,76 @@ size_t bytes_per_ordering(const lsspa_ctx* ctx) {
          (size_t)(ctx->m_pad / 64) * pp * 8 + (size_t)ctx->p * 8;
 }
 
-int ensure_workspace(lsspa_ctx* ctx, int want_ord, int want_samples) {
+int ensure_workspace(lsspa_ctx* ctx, Lane& L, int want_ord, int want_samples) {
   want_ord = (want_ord + 1) & ~1;  // antithetical pairs stay together
-  if (want_ord > ctx->cap_ord || want_samples > ctx->cap_samples)
-    HIPCHK(hipStreamSynchronize(ctx->stream));  // work in flight still uses the old buffers
-  if (want_ord > ctx->cap_ord) {
+  if (want_ord > L.cap_ord || want_samples > L.cap_samples)
+    TRY(sync_all(ctx));  // work in flight still uses the old buffers
+  if (want_ord > L.cap_ord) {
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     // memory already held by the old workspace comes back when it is re-allocated
     const size_t per = bytes_per_ordering(ctx);
-    size_t budget = (size_t)(0.85 * (double)free_b) + (size_t)ctx->cap_ord * per;
+    size_t budget = (size_t)(0.85 * (double)free_b) + (size_t)L.cap_ord * per;
+    if (ctx->n_lanes == 2 && &L == &ctx->lanes[0] && ctx->lanes[1].cap_ord == 0)
+      budget /= 2;   // leave the second lane its share
     int cap = (int)std::min<size_t>((size_t)want_ord, budget / per);
     cap = std::min(cap, 4096);
     cap &= ~1;  // keep antithetical pairs together
     if (cap < 2) return ctx->fail(LSSPA_ERR_NOMEM, "not enough device memory for two orderings");
-    if (cap > ctx->cap_ord) {
+    if (cap > L.cap_ord) {
       // capacity 0 while the buffers are being replaced: if one allocation fails (LSSPA_ERR_NOMEM) the caller may
       // retry with a smaller batch and must then find "no workspace", not the old capacity over freed buffers
-      const int samples_kept = ctx->cap_samples;
-      DevBuf<double> lifts_kept = ctx->lifts;
-      ctx->lifts = DevBuf<double>();
-      free_workspace(ctx);
-      ctx->lifts = lifts_kept;
-      ctx->cap_samples = samples_kept;
+      const int samples_kept = L.cap_samples;
+      DevBuf<double> lifts_kept = L.lifts;
+      L.lifts = DevBuf<double>();
+      free_lane_workspace(L);
+      L.lifts = lifts_kept;
+      L.cap_samples = samples_kept;
       const size_t pp = ctx->p_pad, nblk = pp / NB;
       const size_t nm = ctx->tri ? 2 : 1;
       const size_t es = ctx->esz();
-      TRY(dev_alloc(ctx, ctx->A, nm * cap * pp * pp * es));
-      TRY(dev_alloc(ctx, ctx->V, (size_t)cap * (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad) * es));
-      TRY(dev_alloc(ctx, ctx->Dinv, nm * cap * nblk * 4096 * es));
-      TRY(dev_alloc(ctx, ctx->diag0, nm * cap * pp));
-      TRY(dev_alloc(ctx, ctx->Ppart, (size_t)cap * (ctx->m_pad / 64) * pp));
-      TRY(dev_alloc(ctx, ctx->perms_d, (size_t)2 * cap * ctx->p));
-      ctx->cap_ord = cap;
+      TRY(dev_alloc(ctx, L.A, nm * cap * pp * pp * es));
+      TRY(dev_alloc(ctx, L.V, (size_t)cap * (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad) * es));
+      TRY(dev_alloc(ctx, L.Dinv, nm * cap * nblk * 4096 * es));
+      TRY(dev_alloc(ctx, L.diag0, nm * cap * pp));
+      TRY(dev_alloc(ctx, L.Ppart, (size_t)cap * (ctx->m_pad / 64) * pp));
+      TRY(dev_alloc(ctx, L.perms_d, (size_t)2 * cap * ctx->p));
+      L.cap_ord = cap;
     }
   }
-  if (want_samples > ctx->cap_samples) {
-    ctx->cap_samples = 0;   // dev_alloc releases the old buffer before it asks for the new one
-    TRY(dev_alloc(ctx, ctx->lifts, (size_t)want_samples * ctx->p));
-    ctx->cap_samples = want_samples;
+  if (want_samples > L.cap_samples) {
+    L.cap_samples = 0;   // dev_alloc releases the old buffer before it asks for the new one
+    TRY(dev_alloc(ctx, L.lifts, (size_t)want_samples * ctx->p));
+    L.cap_samples = want_samples;
   }
   return LSSPA_OK;
 }
 
-int ensure_pinned(lsspa_ctx* ctx, size_t count) {
-  if (ctx->perms_h_count >= count) return LSSPA_OK;
-  HIPCHK(hipStreamSynchronize(ctx->stream));  // pending copies still read the old buffers
-  ctx->perms_h_count = 0;
+int ensure_pinned(lsspa_ctx* ctx, Lane& L, size_t count) {
+  if (L.perms_h_count >= count) return LSSPA_OK;
+  TRY(sync_all(ctx));  // pending copies still read the old buffers
+  L.perms_h_count = 0;
   for (int b = 0; b < 2; ++b) {
-    if (ctx->perms_h[b]) (void)hipHostFree(ctx->perms_h[b]);
-    ctx->perms_h[b] = nullptr;
-    ctx->perms_busy[b] = false;
-    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ctx->perms_h[b]), count * sizeof(int32_t), 0);
+    if (L.perms_h[b]) (void)hipHostFree(L.perms_h[b]);
+    L.perms_h[b] = nullptr;
+    L.perms_busy[b] = false;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&L.perms_h[b]), count * sizeof(int32_t), 0);
     if (e != hipSuccess) return ctx->fail(LSSPA_ERR_NOMEM, "hipHostMalloc", e);
-    if (!ctx->perms_ev[b]) HIPCHK(hipEventCreateWithFlags(&ctx->perms_ev[b], hipEventDisableTiming));
+    if (!L.perms_ev[b]) HIPCHK(hipEventCreateWithFlags(&L.perms_ev[b], hipEventDisableTiming));
   }
-  ctx->perms_h_count = count;
+  L.perms_h_count = count;
+  return LSSPA_OK;
+}
+
+// streams and events of a lane, made on first use
+int ensure_lane(lsspa_ctx* ctx, Lane& L) {
+  if (!L.ev_done) {
+    HIPCHK(hipEventCreateWithFlags(&L.ev_mid, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&L.ev_consumed, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&L.ev_main, hipEventDisableTiming));
+  }
+  if (ctx->n_lanes == 2 && !L.st) HIPCHK(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
   return LSSPA_OK;
 }
 
@@ -383,20 +444,20 @@ int ensure_pinned(lsspa_ctx* ctx, size_t count) {
 // Orderings [ord_off, ord_off + n_ord) of the staged batch on stream st.  Each slice owns its part of every
 // workspace buffer (a slice's matrices are laid out [source][ordering] inside its own region), so two
 // slices can run on two streams at once.
-int run_slice(lsspa_ctx* ctx, int ord_off, int n_ord, int per_sample, int s_off, hipStream_t st) {
+int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, int s_off, hipStream_t st) {
   const int p = ctx->p, p_pad = ctx->p_pad, m_pad = ctx->m_pad, nblk = p_pad / NB;
   const int n_src = ctx->tri ? 2 : 1;
   const int n_mats = n_ord * n_src;
   const size_t es = ctx->esz(), pp2 = (size_t)p_pad * p_pad;
-  char* const A_s = ctx->A.ptr + (size_t)ord_off * n_src * pp2 * es;
-  char* const Dinv_s = ctx->Dinv.ptr + (size_t)ord_off * n_src * nblk * 4096 * es;
-  double* const diag0_s = ctx->diag0.ptr + (size_t)ord_off * n_src * p_pad;
-  char* const V_s = ctx->V.ptr + (size_t)ord_off * (size_t)v_rows_of(p) * (size_t)ldv_of(m_pad) * es;
-  double* const Ppart_s = ctx->Ppart.ptr + (size_t)ord_off * (m_pad / 64) * p_pad;
-  const int32_t* const perms_s = ctx->perms_cur + (size_t)ord_off * p;
-  const bool timed = (st == ctx->stream);   // the profiling events live on the context's stream
+  char* const A_s = L.A.ptr + (size_t)ord_off * n_src * pp2 * es;
+  char* const Dinv_s = L.Dinv.ptr + (size_t)ord_off * n_src * nblk * 4096 * es;
+  double* const diag0_s = L.diag0.ptr + (size_t)ord_off * n_src * p_pad;
+  char* const V_s = L.V.ptr + (size_t)ord_off * (size_t)v_rows_of(p) * (size_t)ldv_of(m_pad) * es;
+  double* const Ppart_s = L.Ppart.ptr + (size_t)ord_off * (m_pad / 64) * p_pad;
+  const int32_t* const perms_s = L.perms_cur + (size_t)ord_off * p;
+  const bool timed = (st == ctx->lane_stream(L));   // the profiling events live on the lane's main stream
   {
-    ProfScope ps(timed ? ctx : nullptr, LSSPA_K_GATHER);
+    ProfScope ps(timed ? ctx : nullptr, LSSPA_K_GATHER, st);
     GatherArgs ga;
     ga.S[0] = ctx->G.ptr;
     ga.s[0] = ctx->g.ptr;
@@ -426,30 +487,39 @@ int run_slice(lsspa_ctx* ctx, int ord_off, int n_ord, int per_sample, int s_off,
   const double piv_tol = 16.0 * (double)p * (ctx->f32 ? 1.1920929e-07 : 2.220446049250313e-16);
   if (!(ctx->flags & 8)) {
     {
-      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_DIAG);
+      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_DIAG, st);
       HIPCHK(launch_chol2_diag(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, n_mats,
                                ctx->f32, st));
     }
-    for (int Jo = 0; Jo + 1 < p_pad / 128; ++Jo) {
-      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_PANEL);
-      HIPCHK(launch_chol2_panel(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, Jo,
-                                n_mats, ctx->f32, st, ctx->flags));
+    const int n_panel = p_pad / 128 - 1;
+    for (int Jo = 0; Jo < n_panel; ++Jo) {
+      {
+        ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_PANEL, st);
+        HIPCHK(launch_chol2_panel(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, Jo,
+                                  n_mats, ctx->f32, st, ctx->flags));
+      }
+      // two lanes: the other lane's next batch may start once this one is about half done
+      if (L.mid_armed && timed && Jo == n_panel / 2) {
+        HIPCHK(hipEventRecord(L.ev_mid, st));
+        L.mid_valid = true;
+        L.mid_armed = false;
+      }
     }
   }
   for (int J = 0; J < nblk && (ctx->flags & 8); ++J) {   // A/B switch: the one-level scheme
     if (J == 0 || !fused) {
-      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_DIAG);
+      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_DIAG, st);
       HIPCHK(launch_chol_diag(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, J,
                               n_mats, ctx->f32, st));
     }
     if (J + 1 < nblk) {
-      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_PANEL);
+      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_PANEL, st);
       HIPCHK(launch_chol_panel(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, J,
                                n_mats, ctx->flags, ctx->f32, st));
     }
   }
   {
-    ProfScope ps(timed ? ctx : nullptr, LSSPA_K_STRIP);
+    ProfScope ps(timed ? ctx : nullptr, LSSPA_K_STRIP, st);
     StripArgs sa;
     sa.A = A_s;
     sa.Dinv = Dinv_s;
@@ -467,7 +537,7 @@ int run_slice(lsspa_ctx* ctx, int ord_off, int n_ord, int per_sample, int s_off,
     HIPCHK(launch_strip(sa, st));
   }
   {
-    ProfScope ps(timed ? ctx : nullptr, LSSPA_K_LIFT);
+    ProfScope ps(timed ? ctx : nullptr, LSSPA_K_LIFT, st);
     LiftArgs la;
     la.A = A_s;
     la.At = ctx->tri ? A_s + (size_t)n_ord * pp2 * es : nullptr;
@@ -476,7 +546,7 @@ int run_slice(lsspa_ctx* ctx, int ord_off, int n_ord, int per_sample, int s_off,
     la.V = V_s;
     la.perms = perms_s;
     la.Ppart = Ppart_s;
-    la.lifts = ctx->lifts.ptr + (size_t)s_off * p;
+    la.lifts = L.lifts.ptr + (size_t)s_off * p;
     la.y_norm_sq = ctx->y_norm_sq;
     la.p = p;
     la.p_pad = p_pad;
@@ -487,6 +557,14 @@ int run_slice(lsspa_ctx* ctx, int ord_off, int n_ord, int per_sample, int s_off,
     la.paired = (per_sample == 2) ? 1 : 0;   // stage_and_run builds the second ordering as the reverse of the first
     HIPCHK(launch_lift(la, st));
   }
+  return LSSPA_OK;
+}
+
+// the problem (or a derived copy of it) changed on the context's stream: lanes order themselves behind this point
+int mark_problem(lsspa_ctx* ctx) {
+  if (!ctx->ev_problem) HIPCHK(hipEventCreateWithFlags(&ctx->ev_problem, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(ctx->ev_problem, ctx->stream));
+  ++ctx->problem_epoch;
   return LSSPA_OK;
 }
 
@@ -502,43 +580,44 @@ int ensure_f32_sources(lsspa_ctx* ctx) {
     HIPCHK(launch_to_f32(ctx->H.ptr, ctx->Hf.ptr, (int64_t)cnt, ctx->stream));
   }
   ctx->src_f32_valid = true;
-  return LSSPA_OK;
+  return mark_problem(ctx);
 }
 
 // Run gather -> factorisation -> strip -> lift for n_ord orderings already resident in perms_d.
 // lifts for sample s land in lifts_d[(s_off + s)][p].  With developer flag 32 a large batch is cut into
 // two slices on two streams (the launches of a slice depend on each other, so while one slice drains the
 // tail of a launch the other slice's workgroups take the idle CUs).
-int run_orderings(lsspa_ctx* ctx, int n_ord, int per_sample, int s_off) {
-  TRY(ensure_f32_sources(ctx));
+int run_orderings(lsspa_ctx* ctx, Lane& L, int n_ord, int per_sample, int s_off) {
+  const hipStream_t st = ctx->lane_stream(L);
   const int half = ((n_ord / 2) / per_sample) * per_sample;
   // opt-in (developer flag 32): measured gain 0.8 % at p = 1000 -- not worth two launch shapes per kernel in the traces
-  if (ctx->prof_on || !(ctx->flags & 32) || half < 32) return run_slice(ctx, 0, n_ord, per_sample, s_off, ctx->stream);
-  if (!ctx->side_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  if (ctx->prof_on || !(ctx->flags & 32) || half < 32) return run_slice(ctx, L, 0, n_ord, per_sample, s_off, st);
+  if (!L.side_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&L.side_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
   }
-  HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));          // the orderings are on the device
-  HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
-  TRY(run_slice(ctx, 0, half, per_sample, s_off, ctx->stream));
-  TRY(run_slice(ctx, half, n_ord - half, per_sample, s_off + half / per_sample, ctx->side_stream));
-  HIPCHK(hipEventRecord(ctx->ev_join, ctx->side_stream));
-  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  HIPCHK(hipEventRecord(L.ev_fork, st));          // the orderings are on the device
+  HIPCHK(hipStreamWaitEvent(L.side_stream, L.ev_fork, 0));
+  TRY(run_slice(ctx, L, 0, half, per_sample, s_off, st));
+  TRY(run_slice(ctx, L, half, n_ord - half, per_sample, s_off + half / per_sample, L.side_stream));
+  HIPCHK(hipEventRecord(L.ev_join, L.side_stream));
+  HIPCHK(hipStreamWaitEvent(st, L.ev_join, 0));
   return LSSPA_OK;
 }
 
-// Stage `count` orderings (with their reverses when per_sample == 2) and run them.
-int stage_and_run(lsspa_ctx* ctx, const int32_t* perms, int n_samples, int per_sample, int s_off) {
+// Stage `count` orderings (with their reverses when per_sample == 2) on lane L and run them.
+int stage_and_run(lsspa_ctx* ctx, Lane& L, const int32_t* perms, int n_samples, int per_sample, int s_off) {
   const int p = ctx->p;
   const int n_ord = n_samples * per_sample;
-  const int turn = ctx->perms_turn;
-  ctx->perms_turn ^= 1;
-  if (ctx->perms_busy[turn]) {  // the copy that last read this buffer must have run
-    HIPCHK(hipEventSynchronize(ctx->perms_ev[turn]));
-    ctx->perms_busy[turn] = false;
+  const hipStream_t st = ctx->lane_stream(L);
+  const int turn = L.perms_turn;
+  L.perms_turn ^= 1;
+  if (L.perms_busy[turn]) {  // the copy that last read this buffer must have run
+    HIPCHK(hipEventSynchronize(L.perms_ev[turn]));
+    L.perms_busy[turn] = false;
   }
-  int32_t* hp = ctx->perms_h[turn];
+  int32_t* hp = L.perms_h[turn];
   for (int s = 0; s < n_samples; ++s) {
     const int32_t* src = perms + (size_t)s * p;
     int32_t* d0 = hp + (size_t)s * per_sample * p;
@@ -552,21 +631,109 @@ int stage_and_run(lsspa_ctx* ctx, const int32_t* perms, int n_samples, int per_s
       for (int j = 0; j < p; ++j) d1[j] = src[p - 1 - j];
     }
   }
-  if (!ctx->copy_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    for (int b = 0; b < 2; ++b) HIPCHK(hipEventCreateWithFlags(&ctx->perms_used[b], hipEventDisableTiming));
+  if (!L.copy_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&L.copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) HIPCHK(hipEventCreateWithFlags(&L.perms_used[b], hipEventDisableTiming));
   }
-  int32_t* dp = ctx->perms_d.ptr + (size_t)turn * ctx->cap_ord * p;
-  if (ctx->perms_used_valid[turn]) HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->perms_used[turn], 0));
-  HIPCHK(hipMemcpyAsync(dp, hp, sizeof(int32_t) * (size_t)n_ord * p, hipMemcpyHostToDevice, ctx->copy_stream));
-  HIPCHK(hipEventRecord(ctx->perms_ev[turn], ctx->copy_stream));
-  ctx->perms_busy[turn] = true;
-  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->perms_ev[turn], 0));
-  ctx->perms_cur = dp;
-  const int rc = run_orderings(ctx, n_ord, per_sample, s_off);
+  int32_t* dp = L.perms_d.ptr + (size_t)turn * L.cap_ord * p;
+  if (L.perms_used_valid[turn]) HIPCHK(hipStreamWaitEvent(L.copy_stream, L.perms_used[turn], 0));
+  HIPCHK(hipMemcpyAsync(dp, hp, sizeof(int32_t) * (size_t)n_ord * p, hipMemcpyHostToDevice, L.copy_stream));
+  HIPCHK(hipEventRecord(L.perms_ev[turn], L.copy_stream));
+  L.perms_busy[turn] = true;
+  HIPCHK(hipStreamWaitEvent(st, L.perms_ev[turn], 0));
+  L.perms_cur = dp;
+  const int rc = run_orderings(ctx, L, n_ord, per_sample, s_off);
   if (rc != LSSPA_OK) return rc;
-  HIPCHK(hipEventRecord(ctx->perms_used[turn], ctx->stream));
-  ctx->perms_used_valid[turn] = true;
+  HIPCHK(hipEventRecord(L.perms_used[turn], st));
+  L.perms_used_valid[turn] = true;
+  return LSSPA_OK;
+}
+
+// Launch a batch on the next lane: every kernel up to the lift vectors.  Nothing here touches the running statistics,
+// so a batch can be launched before the previous one has been accumulated (or is ever accumulated: lift_discard).
+int lift_launch(lsspa_ctx* ctx, const int32_t* perms, int B, int per, Lane** out) {
+  const int p = ctx->p;
+  Lane& L = ctx->lanes[ctx->n_lanes == 2 ? ctx->lane_turn : 0];
+  if (L.in_flight) return ctx->fail(LSSPA_ERR_STATE, "both lanes hold a launched batch: collect or discard one first");
+  TRY(ensure_lane(ctx, L));
+  TRY(ensure_f32_sources(ctx));   // on the context's stream ...
+  // orderings per launch sequence: everything at once up to ~8 GB of workspace or 4096 orderings
+  const size_t per_ord = bytes_per_ordering(ctx);
+  const int want = (int)std::max<size_t>(2, std::min<size_t>(4096, ((size_t)8 << 30) / per_ord));
+  TRY(ensure_workspace(ctx, L, std::min(B * per, std::max(want, 512)), B));
+  const int sub = std::max(1, L.cap_ord / per);
+  TRY(ensure_pinned(ctx, L, (size_t)std::min(sub, (int)B) * per * p));
+  const hipStream_t st = ctx->lane_stream(L);
+  if (ctx->n_lanes == 2) {
+    Lane& other = ctx->lanes[1 - ctx->lane_turn];
+    // ... which the lane's stream has to see (fp32 sources, a freshly loaded problem, a reset)
+    if (L.problem_seen != ctx->problem_epoch) {
+      // NOT an event recorded now: the context's stream already holds the statistics of the previous batch, which
+      // wait for that batch's kernels -- waiting on "now" would chain this batch behind the whole previous one
+      HIPCHK(hipStreamWaitEvent(st, ctx->ev_problem, 0));
+      L.problem_seen = ctx->problem_epoch;
+    }
+    // this lane's previous lift vectors have been read by the statistics
+    if (L.consumed_valid) HIPCHK(hipStreamWaitEvent(st, L.ev_consumed, 0));
+    // stagger: start when the other lane's batch is half way
+    if (other.mid_valid) HIPCHK(hipStreamWaitEvent(st, other.ev_mid, 0));
+    L.mid_armed = true;
+  }
+  for (int s0 = 0; s0 < B; s0 += sub) {
+    const int ns = std::min(sub, B - s0);
+    TRY(stage_and_run(ctx, L, perms + (size_t)s0 * p, ns, per, s0));
+  }
+  if (ctx->n_lanes == 2) {
+    if (L.mid_armed) {   // one-level path or a single panel: no mid point was met
+      HIPCHK(hipEventRecord(L.ev_mid, st));
+      L.mid_valid = true;
+      L.mid_armed = false;
+    }
+    HIPCHK(hipEventRecord(L.ev_done, st));
+    L.done_valid = true;
+    ctx->lane_turn ^= 1;
+  }
+  L.B = B;
+  L.per = per;
+  L.taken = 0;
+  L.in_flight = true;
+  ctx->lane_last = (int)(&L - ctx->lanes);
+  if (out) *out = &L;
+  return LSSPA_OK;
+}
+
+// Fold `count` samples of a launched batch, from sample `first` on, into the pending statistics (accumulate) and /
+// or copy their lift vectors out -- on the context's stream, in order.  The parts of a batch are taken front to
+// back; the lane is given back with the last one.
+int lift_collect(lsspa_ctx* ctx, Lane& L, int first, int count, double* lifts_out, int accumulate) {
+  if (!L.in_flight) return ctx->fail(LSSPA_ERR_STATE, "no launched batch on this lane");
+  const int p = ctx->p;
+  if (count <= 0) count = L.B - first;
+  if (first != L.taken || count < 1 || first + count > L.B)
+    return ctx->fail(LSSPA_ERR_ARG, "parts of a launched batch are collected front to back, without gaps");
+  const double* src = L.lifts.ptr + (size_t)first * p;
+  if (ctx->n_lanes == 2 && first == 0) HIPCHK(hipStreamWaitEvent(ctx->stream, L.ev_done, 0));
+  if (accumulate) {
+    ProfScope ps(ctx, LSSPA_K_STATS);
+    const int nz = stats_batch_slices(count, p);
+    if (nz > 1) TRY(dev_alloc(ctx, ctx->stat_parts, (size_t)nz * ((size_t)1 + p + (size_t)p * p)));
+    HIPCHK(launch_stats_batch(src, ctx->mean.ptr, ctx->pend.ptr, count, p, ctx->pend_dirty ? 1 : 0,
+                              nz > 1 ? ctx->stat_parts.ptr : nullptr, ctx->stream));
+    ctx->pend_dirty = true;
+    if (ctx->hist_cap > 0) TRY(hist_append(ctx, src, count, hipMemcpyDeviceToDevice));
+  }
+  if (lifts_out) {
+    HIPCHK(hipMemcpyAsync(lifts_out, src, sizeof(double) * (size_t)count * p, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  L.taken = first + count;
+  if (L.taken == L.B) {
+    if (ctx->n_lanes == 2) {
+      HIPCHK(hipEventRecord(L.ev_consumed, ctx->stream));
+      L.consumed_valid = true;
+    }
+    L.in_flight = false;
+  }
   return LSSPA_OK;
 }
 
@@ -634,37 +801,44 @@ int lsspa_create(int32_t device, lsspa_ctx** out) {
 int lsspa_destroy(lsspa_ctx* ctx) {
   if (!ctx) return LSSPA_OK;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)sync_all(ctx);
   for (auto& r : ctx->prof_recs) {
     (void)hipEventDestroy(r.beg);
     (void)hipEventDestroy(r.end);
   }
   dev_free(ctx->G); dev_free(ctx->g); dev_free(ctx->H); dev_free(ctx->h); dev_free(ctx->Ft);
-  dev_free(ctx->ytil); dev_free(ctx->scal); dev_free(ctx->A); dev_free(ctx->V); dev_free(ctx->Dinv);
-  dev_free(ctx->Ppart); dev_free(ctx->lifts); dev_free(ctx->diag0); dev_free(ctx->perms_d); dev_free(ctx->info_d);
+  dev_free(ctx->ytil); dev_free(ctx->scal); dev_free(ctx->info_d);
   dev_free(ctx->mean); dev_free(ctx->M2); dev_free(ctx->pend); dev_free(ctx->state_n);
   dev_free(ctx->Cred);
-  dev_free(ctx->stat_parts);
   dev_free(ctx->Gf); dev_free(ctx->Hf);
-  if (ctx->copy_stream) {
-    (void)hipStreamSynchronize(ctx->copy_stream);
-    (void)hipStreamDestroy(ctx->copy_stream);
-    for (int b = 0; b < 2; ++b) (void)hipEventDestroy(ctx->perms_used[b]);
-  }
-  if (ctx->side_stream) {
-    (void)hipStreamSynchronize(ctx->side_stream);
-    (void)hipStreamDestroy(ctx->side_stream);
-    (void)hipEventDestroy(ctx->ev_fork);
-    (void)hipEventDestroy(ctx->ev_join);
+  free_workspace(ctx);
+  for (Lane& L : ctx->lanes) {
+    if (L.copy_stream) {
+      (void)hipStreamDestroy(L.copy_stream);
+      for (int b = 0; b < 2; ++b) (void)hipEventDestroy(L.perms_used[b]);
+    }
+    if (L.side_stream) {
+      (void)hipStreamDestroy(L.side_stream);
+      (void)hipEventDestroy(L.ev_fork);
+      (void)hipEventDestroy(L.ev_join);
+    }
+    if (L.ev_done) {
+      (void)hipEventDestroy(L.ev_mid);
+      (void)hipEventDestroy(L.ev_done);
+      (void)hipEventDestroy(L.ev_consumed);
+      (void)hipEventDestroy(L.ev_main);
+    }
+    if (L.st) (void)hipStreamDestroy(L.st);
+    for (int b = 0; b < 2; ++b) {
+      if (L.perms_h[b]) (void)hipHostFree(L.perms_h[b]);
+      if (L.perms_ev[b]) (void)hipEventDestroy(L.perms_ev[b]);
+    }
   }
   dev_free(ctx->hist); dev_free(ctx->xi_d); dev_free(ctx->draws); dev_free(ctx->err_out);
+  if (ctx->ev_problem) (void)hipEventDestroy(ctx->ev_problem);
   comm_destroy(ctx->comm);
   ctx->comm = nullptr;
   dev_free(ctx->pack); dev_free(ctx->xfer); dev_free(ctx->ibuf);
-  for (int b = 0; b < 2; ++b) {
-    if (ctx->perms_h[b]) (void)hipHostFree(ctx->perms_h[b]);
-    if (ctx->perms_ev[b]) (void)hipEventDestroy(ctx->perms_ev[b]);
-  }
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return LSSPA_OK;
@@ -673,7 +847,7 @@ int lsspa_destroy(lsspa_ctx* ctx) {
 int lsspa_set_stream(lsspa_ctx* ctx, void* hip_stream) {
   if (!ctx) return LSSPA_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  TRY(sync_all(ctx));
   if (hip_stream) {
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -688,7 +862,23 @@ int lsspa_set_stream(lsspa_ctx* ctx, void* hip_stream) {
 int lsspa_synchronize(lsspa_ctx* ctx) {
   if (!ctx) return LSSPA_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return sync_all(ctx);
+}
+
+int lsspa_set_lanes(lsspa_ctx* ctx, int32_t n) {
+  if (!ctx || (n != 1 && n != 2)) return LSSPA_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  for (const Lane& L : ctx->lanes)
+    if (L.in_flight) return ctx->fail(LSSPA_ERR_STATE, "a launched batch is still to be collected");
+  TRY(sync_all(ctx));
+  if (n == 1) free_lane_workspace(ctx->lanes[1]);   // the second workspace goes back to the pool
+  ctx->n_lanes = n;
+  ctx->lane_turn = 0;
+  for (Lane& L : ctx->lanes) {
+    L.mid_valid = L.done_valid = L.consumed_valid = false;
+    L.problem_seen = -1;
+  }
+  if (n == 2 && !ctx->ev_problem) TRY(mark_problem(ctx));
   return LSSPA_OK;
 }
 
@@ -891,6 +1081,7 @@ static int reduce_finalize(lsspa_ctx* ctx, int64_t N_total, double reg) {
   if (!(ctx->y_norm_sq > 0.0)) return ctx->fail(LSSPA_ERR_ARG, "y_test is identically zero (or NaN)");
   TRY(stats_reset(ctx));
   ctx->have_problem = true;
+  TRY(mark_problem(ctx));
   ctx->reduce_open = false;
   dev_free(ctx->Cred);
   return LSSPA_OK;
@@ -982,6 +1173,7 @@ int lsspa_set_reduced(lsspa_ctx* ctx, int32_t p, const double* G, const double* 
   ctx->y_norm_sq = y_norm_sq;
   TRY(stats_reset(ctx));
   ctx->have_problem = true;
+  TRY(mark_problem(ctx));
   return LSSPA_OK;
 }
 
@@ -1023,12 +1215,19 @@ static int fetch_elems(lsspa_ctx* ctx, const char* base, size_t off, size_t coun
 // factor the identity ordering into workspace slot 0 (lifts into lifts_d row 0)
 static int factor_identity(lsspa_ctx* ctx, const int32_t* perm_or_null) {
   const int p = ctx->p;
-  TRY(ensure_workspace(ctx, 2, 1));
-  TRY(ensure_pinned(ctx, (size_t)2 * p));
+  for (const Lane& L : ctx->lanes)
+    if (L.in_flight) return ctx->fail(LSSPA_ERR_STATE, "a launched batch is still to be collected");
+  TRY(sync_all(ctx));
+  Lane& L = ctx->lanes[0];
+  TRY(ensure_lane(ctx, L));
+  TRY(ensure_f32_sources(ctx));
+  TRY(ensure_workspace(ctx, L, 2, 1));
+  TRY(ensure_pinned(ctx, L, (size_t)2 * p));
   std::vector<int32_t> id(p);
   for (int j = 0; j < p; ++j) id[j] = perm_or_null ? perm_or_null[j] : j;
-  TRY(stage_and_run(ctx, id.data(), 1, 1, 0));
-  HIPCHK(hipStreamSynchronize(ctx->stream));  // callers read results with blocking copies
+  TRY(sync_all(ctx));                       // the conversion above ran on the context's stream
+  TRY(stage_and_run(ctx, L, id.data(), 1, 1, 0));
+  TRY(sync_all(ctx));                       // callers read results with blocking copies
   return LSSPA_OK;
 }
 
@@ -1038,6 +1237,7 @@ int lsspa_full_fit(lsspa_ctx* ctx, double* theta, double* r_squared, int32_t* in
   HIPCHK(hipSetDevice(ctx->device));
   const int p = ctx->p;
   int32_t saved = 0, now = 0;
+  TRY(sync_all(ctx));
   HIPCHK(hipMemcpy(&saved, ctx->info_d.ptr, 4, hipMemcpyDeviceToHost));
   HIPCHK(hipMemset(ctx->info_d.ptr, 0, 4));
   TRY(factor_identity(ctx, nullptr));
@@ -1048,7 +1248,7 @@ int lsspa_full_fit(lsspa_ctx* ctx, double* theta, double* r_squared, int32_t* in
   if (theta) {
     DevBuf<double> th;
     TRY(dev_alloc(ctx, th, (size_t)p));
-    hipError_t e = launch_backsolve(ctx->A.ptr, th.ptr, p, ctx->p_pad, ctx->f32, ctx->stream);
+    hipError_t e = launch_backsolve(ctx->lanes[0].A.ptr, th.ptr, p, ctx->p_pad, ctx->f32, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(theta, th.ptr, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     dev_free(th);
@@ -1056,7 +1256,7 @@ int lsspa_full_fit(lsspa_ctx* ctx, double* theta, double* r_squared, int32_t* in
   }
   if (r_squared) {
     std::vector<double> l(p);
-    HIPCHK(hipMemcpy(l.data(), ctx->lifts.ptr, sizeof(double) * p, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(l.data(), ctx->lanes[0].lifts.ptr, sizeof(double) * p, hipMemcpyDeviceToHost));
     double s = 0.0;
     for (int j = 0; j < p; ++j) s += l[j];
     *r_squared = s;
@@ -1072,7 +1272,7 @@ int lsspa_get_factors(lsspa_ctx* ctx, double* R_tr, double* q_tr, double* F_te, 
   const size_t mat = (size_t)ppad * ppad;       // chunk-major factor matrices (tiles.h: cm_off)
   TRY(factor_identity(ctx, nullptr));
   std::vector<double> L(mat);
-  TRY(fetch_elems(ctx, ctx->A.ptr, 0, mat, L.data()));
+  TRY(fetch_elems(ctx, ctx->lanes[0].A.ptr, 0, mat, L.data()));
   if (R_tr)
     for (int a = 0; a < p; ++a)
       for (int b = 0; b < p; ++b) R_tr[(size_t)a * p + b] = (b >= a) ? L[cm_off(ppad, b, a)] : 0.0;
@@ -1081,7 +1281,7 @@ int lsspa_get_factors(lsspa_ctx* ctx, double* R_tr, double* q_tr, double* F_te, 
   if (ctx->tri) {
     if (F_te || q_te) {
       // slot layout of run_orderings: the test matrices follow the n_ord = 1 train matrices
-      TRY(fetch_elems(ctx, ctx->A.ptr, mat, mat, L.data()));
+      TRY(fetch_elems(ctx, ctx->lanes[0].A.ptr, mat, mat, L.data()));
       if (F_te)
         for (int a = 0; a < p; ++a)
           for (int b = 0; b < p; ++b) F_te[(size_t)a * p + b] = (b >= a) ? L[cm_off(ppad, b, a)] : 0.0;
@@ -1116,31 +1316,43 @@ int lsspa_lift_batch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t an
       if (!is_permutation(perms + (size_t)s * p, p, seen))
         return ctx->fail(LSSPA_ERR_ARG, "perms: a row is not a permutation of 0..p-1");
   }
-  // orderings per launch sequence: everything at once up to ~8 GB of workspace or 4096 orderings
-  const size_t per_ord = bytes_per_ordering(ctx);
-  const int want = (int)std::max<size_t>(2, std::min<size_t>(4096, ((size_t)8 << 30) / per_ord));
-  TRY(ensure_workspace(ctx, std::min(B * per, std::max(want, 512)), B));
-  const int sub = std::max(1, ctx->cap_ord / per);
-  TRY(ensure_pinned(ctx, (size_t)std::min(sub, (int)B) * per * p));
-  for (int s0 = 0; s0 < B; s0 += sub) {
-    const int ns = std::min(sub, B - s0);
-    TRY(stage_and_run(ctx, perms + (size_t)s0 * p, ns, per, s0));
+  Lane* L = nullptr;
+  TRY(lift_launch(ctx, perms, B, per, &L));
+  return lift_collect(ctx, *L, 0, B, lifts_out, accumulate);
+}
+
+// The two halves of lsspa_lift_batch, for callers that want a batch in flight while they decide what to do with
+// the previous one (the driver launches batch k+1 before it evaluates the stop rule on batch k).
+int lsspa_lift_launch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t antithetical, int32_t* ticket) {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  if (!perms || B < 1 || !ticket) return ctx->fail(LSSPA_ERR_ARG, "perms / B / ticket");
+  HIPCHK(hipSetDevice(ctx->device));
+  {
+    std::vector<char> seen;
+    for (int s = 0; s < B; ++s)
+      if (!is_permutation(perms + (size_t)s * ctx->p, ctx->p, seen))
+        return ctx->fail(LSSPA_ERR_ARG, "perms: a row is not a permutation of 0..p-1");
   }
-  if (accumulate) {
-    ProfScope ps(ctx, LSSPA_K_STATS);
-    const int nz = stats_batch_slices(B, p);
-    if (nz > 1) TRY(dev_alloc(ctx, ctx->stat_parts, (size_t)nz * ((size_t)1 + p + (size_t)p * p)));
-    HIPCHK(launch_stats_batch(ctx->lifts.ptr, ctx->mean.ptr, ctx->pend.ptr, B, p, ctx->pend_dirty ? 1 : 0,
-                              nz > 1 ? ctx->stat_parts.ptr : nullptr,
-                              ctx->stream));
-    ctx->pend_dirty = true;
-    if (ctx->hist_cap > 0) TRY(hist_append(ctx, ctx->lifts.ptr, B, hipMemcpyDeviceToDevice));
-  }
-  if (lifts_out) {
-    HIPCHK(hipMemcpyAsync(lifts_out, ctx->lifts.ptr, sizeof(double) * (size_t)B * p, hipMemcpyDeviceToHost,
-                          ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-  }
+  Lane* L = nullptr;
+  TRY(lift_launch(ctx, perms, B, antithetical ? 2 : 1, &L));
+  *ticket = (int32_t)(L - ctx->lanes);
+  return LSSPA_OK;
+}
+
+int lsspa_lift_collect(lsspa_ctx* ctx, int32_t ticket, int32_t first, int32_t count, double* lifts_out,
+                       int32_t accumulate) {
+  if (!ctx || ticket < 0 || ticket > 1 || first < 0) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  return lift_collect(ctx, ctx->lanes[ticket], first, count, lifts_out, accumulate);
+}
+
+int lsspa_lift_discard(lsspa_ctx* ctx, int32_t ticket) {
+  if (!ctx || ticket < 0 || ticket > 1) return LSSPA_ERR_ARG;
+  Lane& L = ctx->lanes[ticket];
+  if (!L.in_flight) return ctx->fail(LSSPA_ERR_STATE, "no launched batch on this lane");
+  L.in_flight = false;    // its kernels run to completion in stream order; nothing reads their output
   return LSSPA_OK;
 }
 
@@ -1148,6 +1360,7 @@ int lsspa_get_info(lsspa_ctx* ctx, int32_t* info) {
   if (!ctx || !info) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
+  TRY(sync_all(ctx));   // the flag is raised by kernels on the lanes' streams
   HIPCHK(hipMemcpyAsync(info, ctx->info_d.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return LSSPA_OK;
@@ -1525,7 +1738,7 @@ int lsspa_debug_factor(lsspa_ctx* ctx, const int32_t* perm, double* L, double* L
   // the device matrices are chunk-major; hand them out dense row-major
   auto unpack = [&](size_t mat_index, double* dst) -> int {
     std::vector<double> tmp(pp * pp);
-    TRY(fetch_elems(ctx, ctx->A.ptr, mat_index * pp * pp, pp * pp, tmp.data()));
+    TRY(fetch_elems(ctx, ctx->lanes[0].A.ptr, mat_index * pp * pp, pp * pp, tmp.data()));
     for (size_t r = 0; r < pp; ++r)
       for (size_t c = 0; c < pp; ++c) dst[r * pp + c] = tmp[cm_off((int)pp, (int)r, (int)c)];
     return LSSPA_OK;
@@ -1535,7 +1748,7 @@ int lsspa_debug_factor(lsspa_ctx* ctx, const int32_t* perm, double* L, double* L
   if (V) {
     const size_t rows = n_iblk * NB;
     std::vector<double> tmp(rows * ldv);
-    TRY(fetch_elems(ctx, ctx->V.ptr, 0, rows * ldv, tmp.data()));
+    TRY(fetch_elems(ctx, ctx->lanes[0].V.ptr, 0, rows * ldv, tmp.data()));
     for (size_t r = 0; r < rows; ++r)
       for (size_t c = 0; c < mp; ++c) V[r * mp + c] = tmp[r * ldv + c];
   }

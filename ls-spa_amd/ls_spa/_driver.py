@@ -182,7 +182,7 @@ def prepare_sampling(p, *, max_samples, batch_size, seed, perms, antithetical, m
 
 def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms, antithetical,
                   return_attribution_history, method, error_estimator, comm=None, chunk_cap=None,
-                  checkpoint=None, prepared=None):
+                  checkpoint=None, prepared=None, lookahead=1):
     """The sampling loop on an engine whose problem is already loaded.  Returns
     (attribution, attribution_errors, overall_error, error_history, attribution_history, n).
 
@@ -266,20 +266,56 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
                 feat_err, total_err = error_estimates(rng, cov_b * n / (n - 1) / n)
         err_hist.append(total_err)
 
+    # lookahead > 1 (QMC samplers only: their stream is nobody else's): the orderings of several chunks are launched
+    # as ONE batch -- a chunk of batch_size / world samples may fill a fraction of the GPU -- and then accumulated,
+    # all-reduced and checked chunk by chunk in the reference's order (ls_spa/ls_spa.py:212-230).  When the stop
+    # rule fires, the chunks launched beyond it are dropped: nothing of them ever reaches the statistics.  The next
+    # group is launched BEFORE the rule is evaluated on the last chunk of the current one, so the GPU works while
+    # the collective, the host's estimate and the decision run.
+    group = max(1, int(lookahead)) if (hasattr(engine, "launch_batch") and source.independent and not chunk_cap) else 1
+    queue = []
+
+    def refill(i_now):
+        entries, cursor = [], i_now
+        for _ in range(group):
+            if cursor >= max_samples:
+                break
+            target = _next_check(cursor, batch_size, max_samples)
+            want = min(target, max_samples) - cursor
+            if chunk_cap:
+                want = min(want, chunk_cap)
+            chunk = source.take(want)
+            if len(chunk) == 0:
+                break
+            entries.append([chunk, chunk[comm.rank::comm.world], want])   # dealt round-robin over the ranks
+            cursor += len(chunk)
+            if len(chunk) < want:
+                break
+        ticket = None
+        if group > 1 and entries:
+            mine_all = np.concatenate([e[1] for e in entries])
+            if len(mine_all):
+                ticket = engine.launch_batch(mine_all, antithetical)
+        first = 0
+        for e in entries:
+            e += [ticket, first]
+            first += len(e[1])
+        queue.extend(entries)
+
     while not stop:
-        target = _next_check(i, batch_size, max_samples)
-        want = min(target, max_samples) - i
-        if chunk_cap:
-            want = min(want, chunk_cap)
-        chunk = source.take(want)
-        n_new = len(chunk)
-        if n_new == 0:
+        if not queue:
+            refill(i)
+        if not queue:
             break
-        # deal the chunk round-robin over the ranks; every rank draws the same orderings
-        mine = chunk[comm.rank::comm.world]
+        chunk, mine, want, ticket, first = queue.pop(0)
+        n_new = len(chunk)
         local = None
         if len(mine):
-            local = engine.run_batch(mine, antithetical, want_lifts=keep_lifts, accumulate=True)
+            if ticket is not None:
+                local = engine.collect_batch(ticket, want_lifts=keep_lifts, accumulate=True, first=first,
+                                             count=len(mine))
+            else:
+                local = engine.run_batch(mine, antithetical, want_lifts=keep_lifts, accumulate=True)
             if on_device:
                 local_idx.append(np.arange(i + comm.rank, i + n_new, comm.world))
         comm.allreduce_pending(engine)
@@ -303,7 +339,10 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
         pending = True
         if n_new < want and not chunk_cap:
             stop = True  # the source ran dry inside a chunk
-        if estimate and (i % batch_size == 0 or i == max_samples - 1):
+        check = estimate and (i % batch_size == 0 or i == max_samples - 1)
+        if group > 1 and check and not queue and not stop and i < max_samples:
+            refill(i)      # in flight while the stop rule below is evaluated
+        if check:
             _, mean, _ = engine.stats(want_cov=False)
             estimate_now(i)
             pending = False
@@ -313,6 +352,8 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
                 break
         if i >= max_samples:
             break
+    for tk in {id(e[3]): e[3] for e in queue if e[3] is not None}.values():
+        engine.discard_batch(tk)     # launched, never accumulated
 
     n, mean, _ = engine.stats(want_cov=False)
     if estimate and pending and n > 0:
@@ -326,7 +367,8 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
 def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_size=2 ** 8,
            tolerance=1e-2, seed=42, perms=None, antithetical=True, return_attribution_history=False, *,
            method=None, num_batches=None, return_history=None, device=0, error_estimator="reference",
-           precision="float64", row_sharded=False, checkpoint=None, comm=None, _engine=None, _comm=None):
+           precision="float64", row_sharded=False, checkpoint=None, comm=None, lookahead=1, _engine=None,
+           _comm=None):
     """Estimates the Shapley attribution of the out-of-sample R^2 of a least-squares fit.
 
     Positional parameters, defaults and behaviour follow cvxgrp/ls-spa
@@ -345,6 +387,10 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         the Gram reduction, lift accumulation and statistics stay float64).
     checkpoint:  path of a state file, written after every error check and resumed from if it exists
         (same data, seed and sampler required); with several ranks every rank keeps ``<path>.rank<r>``.
+    lookahead:  QMC samplers ('argsort', 'permutohedron') only.  k > 1 launches the orderings of k chunks as one GPU
+        batch (a chunk of batch_size / n_gpus samples may fill a fraction of the GPU), accumulates and checks them
+        chunk by chunk in the reference's order and drops the chunks beyond a stop.  Same results; at most k - 1
+        chunks of wasted work at the end of a run.
     comm:  several GPUs, one process each: the communicator every rank passes -- ``NativeComm.from_env()``
         (RCCL through the C ABI, no PyTorch) or ``TorchComm()`` (torch.distributed: RCCL, or gloo on CPU in
         the tests).  The orderings of every chunk are dealt round-robin over the ranks; the only data-path
@@ -380,6 +426,8 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
             comm.bind(engine)      # RCCL communicator on this engine's GPU and stream (collective)
         if precision != "float64" or getattr(engine, "precision", "float64") != "float64":
             engine.set_precision(precision)
+        if int(lookahead) < 1:
+            raise ValueError("lookahead must be >= 1")
         prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
                                     antithetical=antithetical, method=method)
         if row_sharded:
@@ -390,7 +438,8 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         attribution, feat_err, total_err, err_hist, history, _ = run_estimator(
             engine, p, max_samples=max_samples, batch_size=batch_size, tolerance=tolerance, seed=seed,
             perms=perms, antithetical=antithetical, return_attribution_history=return_attribution_history,
-            method=method, error_estimator=error_estimator, comm=comm, checkpoint=checkpoint, prepared=prepared)
+            method=method, error_estimator=error_estimator, comm=comm, checkpoint=checkpoint, prepared=prepared,
+            lookahead=lookahead)
         theta, r_squared, info = engine.full_fit()
         if info or engine.info():
             warnings.warn("a permuted Gram matrix was not numerically positive definite; the attribution "

@@ -51,6 +51,7 @@ class HipEngine:
         self.tri = False
         self.y_norm_sq = float("nan")
         self.precision = "float64"
+        self.lanes = 1
         if stream is not None:
             self._check(self._lib.lsspa_set_stream(self._h, C.c_void_p(int(stream))))
 
@@ -197,6 +198,35 @@ class HipEngine:
         self._check(self._lib.lsspa_lift_batch(self._h, N.iptr(perms), B, int(bool(antithetical)),
                                                N.dptr(out), int(bool(accumulate))))
         return out
+
+    def set_lanes(self, n: int):
+        """1: batches run one after the other (default).  2: successive batches alternate between two workspaces on
+        two streams (include/lsspa.h, lsspa_set_lanes)."""
+        self._check(self._lib.lsspa_set_lanes(self._h, int(n)))
+        self.lanes = int(n)
+
+    def launch_batch(self, perms, antithetical: bool):
+        """Enqueue a batch up to its lift vectors; returns a ticket for collect_batch / discard_batch."""
+        perms = np.ascontiguousarray(perms, dtype=np.int32)
+        if perms.ndim != 2 or perms.shape[1] != self.p:
+            raise ValueError(f"perms must have shape (B, {self.p})")
+        t = C.c_int32()
+        self._check(self._lib.lsspa_lift_launch(self._h, N.iptr(perms), perms.shape[0], int(bool(antithetical)),
+                                                C.byref(t)))
+        return (t.value, perms.shape[0])
+
+    def collect_batch(self, ticket, want_lifts: bool = False, accumulate: bool = True, first: int = 0,
+                      count: int | None = None):
+        """Accumulate (and / or fetch) ``count`` samples of a launched batch starting at sample ``first`` (default:
+        all of it).  Parts are taken front to back."""
+        t, B = ticket
+        count = B - first if count is None else int(count)
+        out = np.empty((count, self.p)) if want_lifts else None
+        self._check(self._lib.lsspa_lift_collect(self._h, t, int(first), count, N.dptr(out), int(bool(accumulate))))
+        return out
+
+    def discard_batch(self, ticket):
+        self._check(self._lib.lsspa_lift_discard(self._h, ticket[0]))
 
     def info(self) -> int:
         v = C.c_int32()

@@ -49,6 +49,10 @@ SIGNATURES = {
     "lsspa_full_fit": (C.c_int, [_vp, _pd, _pd, _pi32]),
     "lsspa_get_factors": (C.c_int, [_vp, _pd, _pd, _pd, _pd]),
     "lsspa_lift_batch": (C.c_int, [_vp, _pi32, _i32, _i32, _pd, _i32]),
+    "lsspa_lift_launch": (C.c_int, [_vp, _pi32, _i32, _i32, _pi32]),
+    "lsspa_lift_collect": (C.c_int, [_vp, _i32, _i32, _i32, _pd, _i32]),
+    "lsspa_lift_discard": (C.c_int, [_vp, _i32]),
+    "lsspa_set_lanes": (C.c_int, [_vp, _i32]),
     "lsspa_get_info": (C.c_int, [_vp, _pi32]),
     "lsspa_stats_reset": (C.c_int, [_vp]),
     "lsspa_stats_pending": (C.c_int, [_vp, C.POINTER(_vp), _pi64]),

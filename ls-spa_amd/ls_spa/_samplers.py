@@ -29,6 +29,11 @@ class OrderingSource:
     """Hands out up to ``count`` orderings at a time as an (n, p) integer array;
     an empty array means exhausted."""
 
+    # True when drawing orderings ahead of time changes nothing anybody can observe (the source owns its stream).
+    # False for the caller's iterable (the reference pulls it lazily, ls_spa/ls_spa.py:197) and for the shared
+    # generator (the error estimator draws from it between batches, SURVEY.md 3.3).
+    independent = False
+
     def take(self, count):  # pragma: no cover - interface
         raise NotImplementedError
 
@@ -105,6 +110,8 @@ class _BackgroundBuild:
 
 
 class ArgsortSource(OrderingSource):
+    independent = True
+
     def __init__(self, p, seed, limit):
         from scipy.stats.qmc import Sobol
         self._build, self._p, self._left = _BackgroundBuild(lambda: Sobol(p, seed=seed)), p, limit

@@ -11,6 +11,43 @@ class OracleEngine:
     def __init__(self):
         self.p = 0
         self.calls = []
+        self.lanes = 1
+        self.launched, self.discarded = 0, 0
+        self._tickets = {}
+        self._taken = {}
+
+    # two-lane interface (lsspa_lift_launch / _collect / _discard): a launched batch is evaluated at once here;
+    # what matters to the driver logic is WHEN it enters the statistics, and that a discarded one never does
+    def set_lanes(self, n):
+        self.lanes = int(n)
+
+    def launch_batch(self, perms, antithetical):
+        assert len(self._tickets) < 2, "both lanes busy"
+        perms = np.asarray(perms)
+        lifts = np.array([O.sample_lift(*self._red, self.y_norm_sq, o, antithetical) for o in perms])
+        self.launched += 1
+        t = self.launched
+        self._tickets[t] = lifts
+        return t
+
+    def collect_batch(self, ticket, want_lifts=False, accumulate=True, first=0, count=None):
+        assert ticket == min(self._tickets), "tickets are collected in launch order"
+        done = self._taken.get(ticket, 0)
+        assert first == done, "parts are taken front to back"
+        lifts_all = self._tickets[ticket]
+        count = len(lifts_all) - first if count is None else count
+        lifts = lifts_all[first:first + count]
+        self._taken[ticket] = first + count
+        if first + count == len(lifts_all):
+            del self._tickets[ticket]
+        self.calls.append(len(lifts))
+        if accumulate:
+            self._accumulate(lifts)
+        return lifts if want_lifts else None
+
+    def discard_batch(self, ticket):
+        self._tickets.pop(ticket)
+        self.discarded += 1
 
     def load_data(self, Xa, Xe, ya, ye, reg):
         Xa, Xe, ya, ye = (np.asarray(a, dtype=np.float64) for a in (Xa, Xe, ya, ye))
@@ -66,14 +103,17 @@ class OracleEngine:
         self.calls.append(len(perms))
         lifts = np.array([O.sample_lift(*self._red, self.y_norm_sq, o, antithetical) for o in perms])
         if accumulate:
-            p = self.p
-            D = lifts - self._mean
-            self._pend[0] += len(D)
-            self._pend[1:1 + p] += D.sum(0)
-            self._pend[1 + p:] += (D.T @ D).ravel()
-            if self._hist is not None:
-                self._hist.append(lifts)
+            self._accumulate(lifts)
         return lifts if want_lifts else None
+
+    def _accumulate(self, lifts):
+        p = self.p
+        D = lifts - self._mean
+        self._pend[0] += len(D)
+        self._pend[1:1 + p] += D.sum(0)
+        self._pend[1 + p:] += (D.T @ D).ravel()
+        if self._hist is not None:
+            self._hist.append(lifts)
 
     def pending_buffer(self):
         return self._pend

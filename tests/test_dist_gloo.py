@@ -39,6 +39,17 @@ def _worker(rank, world, port, out_dir):
     eng4 = OracleEngine()
     shard_tr = ls_spa(d[0][rank::world], d[1], d[2][rank::world], d[3], perms=g["perms64"][:20], batch_size=16,
                       tolerance=0.0, row_sharded="train", _engine=eng4, comm=TorchComm())
+    # lookahead: three chunks of a QMC sampler launched as one batch per rank, accumulated / all-reduced / checked
+    # chunk by chunk; a tolerance that stops the run inside a group (the rest of the group is dropped on both ranks)
+    eng5 = OracleEngine()
+    la = ls_spa(*d, method="argsort", seed=5, max_samples=96, batch_size=16, tolerance=0.0, lookahead=3,
+                error_estimator="lowrank", _engine=eng5, comm=TorchComm())
+    eng6 = OracleEngine()
+    la_stop = ls_spa(*d, method="argsort", seed=5, max_samples=96, batch_size=16, tolerance=float(la.error_history[1]) * 1.0000001,
+                     lookahead=3, error_estimator="lowrank", _engine=eng6, comm=TorchComm())
+    np.savez(os.path.join(out_dir, f"l{rank}.npz"), attribution=la.attribution, err=la.error_history,
+             calls=np.array(eng5.calls), launched=eng5.launched, stop_attr=la_stop.attribution,
+             stop_checks=len(la_stop.error_history), stop_discarded=eng6.discarded, stop_calls=np.array(eng6.calls))
     # checkpoint / resume with two ranks: one state file per rank, killed in the third batch, resumed
     class Dies(OracleEngine):
         def run_batch(self, *a, **k):
@@ -128,4 +139,17 @@ def test_two_ranks_match_single_process(tmp_path):
         s = np.load(tmp_path / f"s{rk}.npz")
         np.testing.assert_allclose(s["res_attr"], straight.attribution, rtol=0, atol=1e-13)
         np.testing.assert_allclose(s["res_err"], straight.error_history, rtol=1e-9)
+    # lookahead over two ranks == single process without it
+    la1 = ls_spa(*d, method="argsort", seed=5, max_samples=96, batch_size=16, tolerance=0.0,
+                 error_estimator="lowrank", _engine=OracleEngine())
+    la1_stop = ls_spa(*d, method="argsort", seed=5, max_samples=96, batch_size=16, error_estimator="lowrank",
+                      tolerance=float(la1.error_history[1]) * 1.0000001, _engine=OracleEngine())
+    for rk in (0, 1):
+        l = np.load(tmp_path / f"l{rk}.npz")
+        np.testing.assert_allclose(l["attribution"], la1.attribution, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(l["err"], la1.error_history, rtol=1e-9)
+        assert list(l["calls"]) == [8, 8, 8, 8, 8, 8 - rk, 1 - rk] and int(l["launched"]) == 3
+        np.testing.assert_allclose(l["stop_attr"], la1_stop.attribution, rtol=0, atol=1e-13)
+        assert int(l["stop_checks"]) == len(la1_stop.error_history) == 2
+        assert int(l["stop_discarded"]) == 1 and list(l["stop_calls"]) == [8, 8]
     # and the reference itself agrees (fixture made from it on the first 48... full 64 run differs)

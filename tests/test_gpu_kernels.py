@@ -333,3 +333,106 @@ def test_failed_allocation_leaves_the_context_usable():
         np.testing.assert_allclose(got2, want2, rtol=0, atol=1e-10)
     finally:
         eng.close()
+
+
+def test_two_lanes_same_results():
+    """lsspa_set_lanes(2): successive batches alternate between two workspaces on two streams, staggered; the
+    statistics stay in batch order.  Lift vectors and running statistics are those of one lane, bit for bit."""
+    from ls_spa._engine import HipEngine
+    d = O.gaussian_workload(150, 600, 500, seed=8)
+    rng = np.random.default_rng(5)
+    perms = np.array([rng.permutation(150) for _ in range(6 * 24)])
+    res = {}
+    for lanes in (1, 2):
+        eng = HipEngine(0)
+        try:
+            eng.load_data(*d, 0.0)
+            eng.set_lanes(lanes)
+            lifts = []
+            for k in range(6):
+                lifts.append(eng.run_batch(perms[24 * k:24 * k + 24], True, want_lifts=(k % 2 == 0), accumulate=True))
+                eng.merge()
+            n, mean, cov = eng.stats()
+            th, r2, info = eng.full_fit()
+            res[lanes] = (n, mean, cov, [l for l in lifts if l is not None], th, r2)
+            assert info == 0 and eng.info() == 0
+        finally:
+            eng.close()
+    assert res[1][0] == res[2][0] == 144
+    np.testing.assert_array_equal(res[1][1], res[2][1])
+    np.testing.assert_array_equal(res[1][2], res[2][2])
+    for a, b in zip(res[1][3], res[2][3]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(res[1][4], res[2][4])
+    red = O.reduce(*d, 0.0)
+    yy = float(d[3] @ d[3])
+    want = np.array([O.sample_lift(*red, yy, o, True) for o in perms[:24]])
+    np.testing.assert_allclose(res[2][3][0], want, rtol=0, atol=1e-10)
+
+
+def test_launch_collect_discard():
+    """The two halves of lsspa_lift_batch: a batch launched ahead and then discarded leaves no trace in the
+    statistics; two may be in flight with two lanes, a third is refused; collect order = launch order."""
+    from ls_spa._engine import HipEngine
+    from ls_spa._native import LSSPANativeError
+    d = O.gaussian_workload(60, 300, 200, seed=9)
+    rng = np.random.default_rng(6)
+    perms = np.array([rng.permutation(60) for _ in range(48)])
+    eng = HipEngine(0)
+    try:
+        eng.load_data(*d, 0.0)
+        ref_a = eng.run_batch(perms[:16], True, want_lifts=True, accumulate=False)
+        ref_b = eng.run_batch(perms[16:32], True, want_lifts=True, accumulate=False)
+        eng.set_lanes(2)
+        t1 = eng.launch_batch(perms[:16], True)
+        t2 = eng.launch_batch(perms[16:32], True)
+        with pytest.raises(LSSPANativeError):
+            eng.launch_batch(perms[32:], True)          # both lanes hold a batch
+        a = eng.collect_batch(t1, want_lifts=True, accumulate=True)
+        eng.merge()
+        t3 = eng.launch_batch(perms[32:], True)         # lane of t1 is free again
+        b = eng.collect_batch(t2, want_lifts=True, accumulate=True)
+        eng.merge()
+        eng.discard_batch(t3)
+        with pytest.raises(LSSPANativeError):
+            eng.collect_batch(t3)                       # nothing to collect any more
+        np.testing.assert_array_equal(a, ref_a)
+        np.testing.assert_array_equal(b, ref_b)
+        n, mean, cov = eng.stats()
+        both = np.concatenate([ref_a, ref_b])
+        assert n == 32
+        np.testing.assert_allclose(mean, both.mean(0), rtol=0, atol=1e-14)
+        np.testing.assert_allclose(cov, np.cov(both, rowvar=False, bias=True), rtol=0, atol=1e-15)
+        eng.set_lanes(1)
+        c = eng.run_batch(perms[:16], True, want_lifts=True, accumulate=False)
+        np.testing.assert_array_equal(c, ref_a)
+    finally:
+        eng.close()
+
+
+def test_driver_lookahead_on_the_device():
+    """Chunks of 8 samples launched four at a time: partial collects of one launched batch (lsspa_lift_collect with
+    first / count), checks in the reference's order, the rest of the last group discarded at the stop."""
+    from ls_spa import ls_spa
+    d = O.gaussian_workload(40, 300, 200, seed=3)
+    kw = dict(method="argsort", seed=11, max_samples=72, batch_size=8, tolerance=0.0, error_estimator="device")
+    one = ls_spa(*d, **kw)
+    four = ls_spa(*d, lookahead=4, **kw)
+    np.testing.assert_array_equal(four.attribution, one.attribution)
+    np.testing.assert_allclose(four.error_history, one.error_history, rtol=1e-12)
+    assert len(four.error_history) == 10      # 8 .. 64, 71, 72
+    tol = float(one.error_history[2]) * 1.0000001
+    if one.error_history[0] > tol and one.error_history[1] > tol:
+        a = ls_spa(*d, **dict(kw, tolerance=tol))
+        b = ls_spa(*d, lookahead=4, **dict(kw, tolerance=tol))
+        assert len(a.error_history) == len(b.error_history) == 3
+        np.testing.assert_array_equal(b.attribution, a.attribution)
+    # also through the lanes: two batches in flight
+    from ls_spa._engine import HipEngine
+    eng = HipEngine(0)
+    try:
+        eng.set_lanes(2)
+        c = ls_spa(*d, lookahead=2, _engine=eng, **kw)
+        np.testing.assert_array_equal(c.attribution, one.attribution)
+    finally:
+        eng.close()

@@ -394,3 +394,45 @@ def test_gather_ints_by_sum():
 
     # rank 1 contributes [7, -1] in its slot, rank 0 [3, 5]
     assert gather_ints_by_sum(Two(0, [0, 0, 7, -1]), [3, 5]) == [[3, 5], [7, -1]]
+
+
+def test_lookahead_keeps_the_reference_order(golden):
+    """lookahead=k: the orderings of k chunks of a QMC sampler are launched as one batch, accumulated and checked
+    chunk by chunk, and dropped beyond a stop.  Same attribution, error history and stop index as lookahead=1; a
+    user's iterable and the shared generator are never drawn ahead."""
+    from oracle_engine import OracleEngine
+    g = golden("p12")
+    d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+    for method in ("argsort", "permutohedron"):
+        kw = dict(method=method, seed=5, max_samples=96, batch_size=16, tolerance=0.0)
+        e1, e3 = OracleEngine(), OracleEngine()
+        one = ls_spa(*d, _engine=e1, **kw)
+        three = ls_spa(*d, _engine=e3, lookahead=3, **kw)
+        np.testing.assert_array_equal(three.attribution, one.attribution)
+        np.testing.assert_array_equal(three.error_history, one.error_history)
+        assert e3.calls == e1.calls == [16, 16, 16, 16, 16, 15, 1]     # checks at 16 .. 80, 95, 96
+        assert e3.launched == 3 and e3.discarded == 0                   # 7 chunks in groups of 3, 3, 1
+    # a tolerance that stops the run at the second check: the third chunk of the group (and nothing else) is dropped
+    first = ls_spa(*d, method="argsort", seed=5, max_samples=96, batch_size=16, tolerance=0.0, _engine=OracleEngine())
+    tol = float(first.error_history[1]) * 1.0000001
+    assert first.error_history[0] > tol
+    e1, e3 = OracleEngine(), OracleEngine()
+    kw = dict(method="argsort", seed=5, max_samples=96, batch_size=16, tolerance=tol)
+    one = ls_spa(*d, _engine=e1, **kw)
+    three = ls_spa(*d, _engine=e3, lookahead=3, **kw)
+    assert len(one.error_history) == len(three.error_history) == 2
+    np.testing.assert_array_equal(three.attribution, one.attribution)
+    assert e3.discarded == 1 and e3.launched == 1 and sum(e3.calls) == sum(e1.calls) == 32
+    # the group ends exactly at a check: the next group is launched before the rule is evaluated, then dropped
+    e2 = OracleEngine()
+    two = ls_spa(*d, _engine=e2, lookahead=2, **kw)
+    np.testing.assert_array_equal(two.attribution, one.attribution)
+    assert e2.launched == 2 and e2.discarded == 1 and sum(e2.calls) == 32
+    # sources somebody else reads are not drawn ahead
+    for kw in (dict(perms=iter(g["perms64"]), batch_size=16, tolerance=0.0),
+               dict(max_samples=48, batch_size=16, tolerance=0.0, seed=3)):
+        e4 = OracleEngine()
+        ls_spa(*d, _engine=e4, lookahead=4, **kw)
+        assert e4.launched == 0 and e4.discarded == 0
+    with pytest.raises(ValueError):
+        ls_spa(*d, lookahead=0, _engine=OracleEngine())
