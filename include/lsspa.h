@@ -194,7 +194,8 @@ int lsspa_comm_allgather(lsspa_ctx* ctx, const double* send, int64_t count, doub
 #define LSSPA_K_GRAM 6
 #define LSSPA_K_ERROR 7
 #define LSSPA_K_COMM 8
-#define LSSPA_K_COUNT 9
+#define LSSPA_K_SMALL 9     /* fused small-p kernel: gather .. lifts of one ordering in one workgroup */
+#define LSSPA_K_COUNT 10
 int lsspa_profile_enable(lsspa_ctx* ctx, int32_t on);
 int lsspa_profile_get(lsspa_ctx* ctx, int32_t kernel_class, double* total_ms, int64_t* launches);
 int lsspa_profile_reset(lsspa_ctx* ctx);
@@ -204,6 +205,7 @@ int lsspa_profile_reset(lsspa_ctx* ctx);
  *     4  one-level strip kernel (64-row steps)          8  one-level panel / diagonal kernels (64-wide panels)
  *    32  two half-batches on two streams               64  plain (matrix, tile) dispatch order in the panel kernel
  *   256  unpaired gather                              512  256-column strips (512-thread workgroups)
+ *  1024  general path also for small problems (p + 1 <= 128 normally takes the fused one-workgroup kernel)
  * Every combination computes the same lifts (tests/test_gpu_kernels.py). */
 int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);
 

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIBNAME = "liblsspa_hip.so"
-SOURCES = ["k_factor.hip", "k_lift.hip", "k_gram.hip", "k_error.hip", "lsspa_comm.hip", "lsspa_api.hip"]
+SOURCES = ["k_factor.hip", "k_small.hip", "k_lift.hip", "k_gram.hip", "k_error.hip", "lsspa_comm.hip", "lsspa_api.hip"]
 HEADERS = ["tiles.h", "kernels.h", "comm.h", os.path.join("..", "..", "include", "lsspa.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

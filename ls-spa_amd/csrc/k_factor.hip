@@ -758,45 +758,6 @@ __device__ long long g_stamps[32];
 constexpr int XD_LD = 17;
 constexpr int FB_SX_ELEMS = 4 * 16 * XD_LD + 16;
 
-template <typename T>
-__device__ __forceinline__ T bcast_lane(T v, int src) {   // value of v in lane src (uniform src)
-  if constexpr (sizeof(T) == 8) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint((double)v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint((double)v), src);
-    return (T)__hiloint2double(hi, lo);
-  } else {
-    return (T)__int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)v), src));
-  }
-}
-
-// 1 / d to working precision without the division sequence: hardware reciprocal + two Newton steps
-// (the elimination's critical path runs through this once per pivot)
-template <typename T>
-__device__ __forceinline__ T fast_recip(T d) {
-  if constexpr (sizeof(T) == 8) {
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(fma(-d, r, 1.0), r, r);
-    r = fma(fma(-d, r, 1.0), r, r);
-    return r;
-  } else {
-    float r = __builtin_amdgcn_rcpf(d);
-    r = fmaf(fmaf(-d, r, 1.0f), r, r);
-    return r;
-  }
-}
-
-// value of v in the lane whose byte address (4 * lane) is addr
-template <typename T>
-__device__ __forceinline__ T bperm(int addr, T v) {
-  if constexpr (sizeof(T) == 8) {
-    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint((double)v));
-    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint((double)v));
-    return (T)__hiloint2double(hi, lo);
-  } else {
-    return (T)__int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int((float)v)));
-  }
-}
-
 // one wave: factor the 16 x 16 block at s_blk (stride DI_LD, lower part valid) in place (L, zeros above the
 // diagonal) and write its inverse to s_inv (16 x XD_LD).  d0: the 16 original diagonal entries (pivot scale).
 // Lane (i = lane & 15, q = lane >> 4) keeps T[i][4q..4q+3] of the FULL symmetric block and Y[i][4q..4q+3].

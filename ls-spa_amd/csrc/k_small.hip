@@ -1,0 +1,375 @@
+// Fused per-ordering kernel for small problems (p + 1 <= 128, fp64, test Gram available): ONE workgroup takes one
+// ordering from the permuted gather to its lift vector with both work matrices resident in LDS -- nothing but the
+// source Gram matrices is read and nothing but the p lifts is written.
+//
+// What it replaces in the reference (cvxgrp/ls-spa, ls_spa/ls_spa.py:256-287, square_shapley), in the Gram form of
+// DESIGN.md section 3:   G_pi = L L^T, H_pi = L_t L_t^T (augmented rows carry z = L^-1 g_pi, y~ = L_t^-1 h_pi),
+// V = L^-1 L_t,  lift_j = z_j V[j,:] . (2 y~ - N_j - N_{j-1}) / ||y_test||^2  with  N_j = sum_{k<=j} z_k V[k,:].
+// The large-p path runs the same steps as five kernel classes with HBM round trips in between; at p = 100 those are
+// latency-bound launches of a few dozen microseconds each.
+//
+// Layout in LDS: each matrix as its lower 16 x 16 blocks only (block (i, j), i >= j, at i (i + 1) / 2 + j), 2 KB a
+// block, columns XOR-swizzled by the row pair so that the MFMA operand and result patterns are conflict free without
+// padding -- two 128 x 128 lower triangles are 144 KB of the CU's 160 KB.
+// 512 threads: waves 0-3 factor the training matrix while waves 4-7 factor the test matrix (same control flow, so
+// the workgroup barriers pair up); then each wave solves one 16-column block of V by forward substitution (MFMA for
+// the block products, lane shuffles for the 16 x 16 triangular solves -- no stored inverses); then the lift scan.
+#include "kernels.h"
+#include "tiles.h"
+
+namespace lsspa {
+
+// phase time stamps of workgroup 0 (tools/small_probe.hip builds this file with LSSPA_SMALL_STAMPS)
+#ifdef LSSPA_SMALL_STAMPS
+__device__ long long g_small_stamps[16];
+#define SSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_small_stamps[i] = wall_clock64(); } while (0)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
+
+namespace {
+
+__device__ __forceinline__ int sw(int r, int c) { return r * 16 + (c ^ ((r >> 1) << 1)); }
+__device__ __forceinline__ int tri_blk(int i, int j) { return i * (i + 1) / 2 + j; }   // i >= j
+
+constexpr int SINV_LD = 17;
+
+// One wave: factor the 16 x 16 diagonal block blk (swizzled, lower part valid) in place -- L below and on the
+// diagonal, zeros above -- and write its inverse to s_inv (16 x SINV_LD) and 1 / L[i][i] to s_rd[0..15].
+// Same elimination as wave_factor16 of k_factor.hip (carried identity, lane permutes, Newton reciprocal).
+__device__ __forceinline__ void wave_factor16_sw(double* blk, double* s_inv, double* s_rd, const double* d0,
+                                                 double piv_tol, int lane, int& bad) {
+  const int i = lane & 15, q = lane >> 4;
+  double t[4], y[4], lcol[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = 4 * q + e;
+    t[e] = (j <= i) ? blk[sw(i, j)] : blk[sw(j, i)];   // upper part: mirrored (whatever is stored there is ignored)
+    y[e] = (j == i) ? 1.0 : 0.0;
+    lcol[e] = 0.0;
+  }
+  const double tol_i = piv_tol * d0[i];
+  double dmine = 1.0;
+  const int a_row = 64 * q;
+  const int a_col = 4 * i;
+#pragma unroll 1
+  for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+    for (int ke = 0; ke < 4; ++ke) {
+      const int k = 4 * kq + ke;
+      double d = bcast_lane<double>(t[ke], k + 16 * kq);
+      const double tol = bcast_lane<double>(tol_i, k);
+      if (!(d > tol)) {   // numerically not positive definite (or NaN): flag it, go on
+        d = 1.0;
+        bad = 1;
+      }
+      if (i == k) dmine = d;
+      if (q == kq) lcol[ke] = t[ke];
+      const double cik = bperm<double>(a_col + 64 * kq, t[ke]);
+      double tk[4], yk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        tk[e] = bperm<double>(a_row + 4 * k, t[e]);
+        yk[e] = bperm<double>(a_row + 4 * k, y[e]);
+      }
+      const double f = (i > k) ? cik * fast_recip<double>(d) : 0.0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        t[e] -= f * tk[e];
+        y[e] -= f * yk[e];
+      }
+    }
+  if (q == 0) s_rd[i] = 1.0 / sqrt(dmine);   // 1 / L[i][i]
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = 4 * q + e;
+    double lv = 0.0, xv = 0.0;
+    if (j < i) lv = lcol[e] * s_rd[j];
+    if (j == i) lv = 1.0 / s_rd[j];
+    if (j <= i) xv = y[e] * s_rd[i];
+    if (j <= i) blk[sw(i, j)] = lv;
+    if (j < i) blk[sw(j, i)] = xv;      // (L_d^-1)[i][j] lives at the mirrored position; its diagonal is s_rd
+    s_inv[i * SINV_LD + j] = xv;
+  }
+}
+
+// element (m, k) of the inverse of a factored diagonal block (see wave_factor16_sw)
+__device__ __forceinline__ double inv_elem(const double* blk, const double* rd, int m, int k) {
+  const double off = blk[sw(min(m, k), max(m, k))];
+  return (k < m) ? off : (k == m ? rd[m] : 0.0);
+}
+
+// 16 x 16 x 16 products of one wave on up to NT tiles at once (independent accumulators: the MFMA chains overlap):
+//   T[q] -= A[q] B[q]^T  with A[q], B[q] row blocks of the current panel
+template <int NT>
+__device__ __forceinline__ void trailing_tiles(double* const (&Tb)[NT], const double* const (&Ab)[NT],
+                                               const double* const (&Bb)[NT], int n, int l15, int l4) {
+  d4 o[NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q) o[q] = d4_zero();
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int kx = 4 * kk + l4;
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+      if (q < n) o[q] = mfma(Ab[q][sw(l15, kx)], Bb[q][sw(l15, kx)], o[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < NT; ++q)
+    if (q < n) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Tb[q][sw(acc_row(l4, r), l15)] -= o[q][r];
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512) void small_p_kernel(SmallArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int nb = a.nb, p = a.p;
+  const int ntri = nb * (nb + 1) / 2;
+  double* const M0 = smem;                     // training matrix -> L -> lift terms
+  double* const M1 = M0 + ntri * 256;          // test matrix -> L_t -> V
+  double* const s_inv = M1 + ntri * 256;       // [2][16 * SINV_LD]: inverse of the current diagonal block
+  double* const s_rdb = s_inv + 2 * 16 * SINV_LD;   // [2][128]: 1 / L[i][i]
+  double* const s_d0 = s_rdb + 256;            // [2][128]: permuted diagonals before any update (pivot scale)
+  double* const s_z = s_d0 + 256;              // [128]
+  double* const s_y = s_z + 128;               // [128]
+  int32_t* const s_perm = reinterpret_cast<int32_t*>(s_y + 128);   // [128]
+  __shared__ int s_bad;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int half = wv >> 2, w = wv & 3, t2 = tid & 255;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int ord = blockIdx.x;
+  const int32_t* perm = a.perms + (int64_t)ord * p;
+
+  SSTAMP(0);
+  if (tid < 128) s_perm[tid] = (tid < p) ? perm[tid] : 0;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  SSTAMP(1);
+
+  // ---- permuted gather of both matrices (lower blocks), augmented row p, identity below ----------------------
+  {
+    double* const M = half ? M1 : M0;
+    const double* __restrict__ S = a.S[half];
+    const double* __restrict__ sv = a.s[half];
+    const double aug = a.aug[half];
+    const int r = t2 >> 4, c = t2 & 15;
+    const int swrc = sw(r, c);
+    for (int bi = 0; bi < nb; ++bi) {
+      const int i = 16 * bi + r;
+      const int64_t rowoff = (int64_t)s_perm[min(i, p - 1)] * a.ld_src;
+#pragma unroll 4
+      for (int bj = 0; bj <= bi; ++bj) {
+        const int j = 16 * bj + c;
+        // unconditional clamped loads, value selected afterwards (a guarded load is a branch and a wait per element)
+        const double gv = S[rowoff + s_perm[min(j, p - 1)]];
+        const double av = sv[s_perm[min(j, p - 1)]];
+        double v;
+        if (i < p) v = (j <= i) ? gv : 0.0;
+        else if (i == p) v = (j < p) ? av : (j == p ? aug : 0.0);
+        else v = (i == j) ? 1.0 : 0.0;
+        M[tri_blk(bi, bj) * 256 + swrc] = v;
+      }
+    }
+    if (t2 < 128) {
+      const int i = t2;
+      s_d0[half * 128 + i] = (i < p) ? S[(int64_t)s_perm[i] * a.ld_src + s_perm[i]] : (i == p ? aug : 1.0);
+    }
+  }
+  __syncthreads();
+  SSTAMP(2);
+
+  // ---- blocked Cholesky of both matrices at once (right-looking, 16 x 16 blocks) ------------------------------
+  {
+    double* const M = half ? M1 : M0;
+    double* const inv = s_inv + half * 16 * SINV_LD;
+    double* const rd = s_rdb + half * 128;
+    const double* const d0 = s_d0 + half * 128;
+    int bad = 0;
+    // the wave that factors the diagonal blocks: wave 0 of the training half, wave 1 of the test half -- waves 0 and 4
+    // would sit on the same SIMD and take turns on its issue slots
+    const int fw = half;
+    if (w == fw) wave_factor16_sw(M, inv, rd, d0, a.piv_tol, lane, bad);
+    __syncthreads();
+    for (int kb = 0; kb < nb; ++kb) {
+      // panel: L[ib][kb] = T[ib][kb] Ld^-T, in place
+      for (int ib = kb + 1 + w; ib < nb; ib += 4) {
+        double* const Tb = M + tri_blk(ib, kb) * 256;
+        d4 o = d4_zero();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int kx = 4 * kk + l4;
+          o = mfma(Tb[sw(l15, kx)], inv[l15 * SINV_LD + kx], o);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tb[sw(acc_row(l4, r), l15)] = o[r];
+      }
+      __syncthreads();
+      if (kb + 1 == nb) break;
+      // trailing update T[ib][jb] -= L[ib][kb] L[jb][kb]^T (kb < jb <= ib) with look-ahead: the factoring wave takes
+      // the next diagonal tile alone and factors it at once, the other three share the rest four tiles at a time
+      if (w == fw) {
+        double* const Tb[1] = {M + tri_blk(kb + 1, kb + 1) * 256};
+        const double* const Ab[1] = {M + tri_blk(kb + 1, kb) * 256};
+        trailing_tiles<1>(Tb, Ab, Ab, 1, l15, l4);
+        __builtin_amdgcn_wave_barrier();
+        wave_factor16_sw(Tb[0], inv, rd + 16 * (kb + 1), d0 + 16 * (kb + 1), a.piv_tol, lane, bad);
+      } else {
+        const int me = (w + 3 - fw) % 4 - 0;      // 0, 1, 2 among the three helpers
+        double* Tb[4];
+        const double *Ab[4], *Bb[4];
+        int have = 0, tcount = 0;
+        for (int ib = kb + 1; ib < nb; ++ib)
+          for (int jb = kb + 1; jb <= ib; ++jb) {
+            if (ib == kb + 1) continue;            // (kb+1, kb+1): the factoring wave's
+            if ((tcount++ % 3) != me) continue;
+            Tb[have] = M + tri_blk(ib, jb) * 256;
+            Ab[have] = M + tri_blk(ib, kb) * 256;
+            Bb[have] = M + tri_blk(jb, kb) * 256;
+            if (++have == 4) {
+              trailing_tiles<4>(reinterpret_cast<double* const(&)[4]>(Tb), reinterpret_cast<const double* const(&)[4]>(Ab),
+                                reinterpret_cast<const double* const(&)[4]>(Bb), 4, l15, l4);
+              have = 0;
+            }
+          }
+        if (have)
+          trailing_tiles<4>(reinterpret_cast<double* const(&)[4]>(Tb), reinterpret_cast<const double* const(&)[4]>(Ab),
+                            reinterpret_cast<const double* const(&)[4]>(Bb), have, l15, l4);
+      }
+      __syncthreads();
+    }
+    if (bad && lane == 0) s_bad = 1;
+  }
+
+  SSTAMP(3);
+  // ---- z = row p of L, y~ = row p of L_t (V overwrites L_t below) ---------------------------------------------
+  {
+    const int pb = p >> 4, pr = p & 15;
+    if (tid < 128) {
+      const int j = tid;
+      s_z[j] = (j < p) ? M0[tri_blk(pb, j >> 4) * 256 + sw(pr, j & 15)] : 0.0;
+      s_y[j] = (j < p) ? M1[tri_blk(pb, j >> 4) * 256 + sw(pr, j & 15)] : 0.0;
+    }
+  }
+  __syncthreads();
+
+  SSTAMP(4);
+  // ---- V = L^-1 L_t: wave cb solves the 16-column block cb, top down, in place of L_t -------------------------
+  if (wv < nb) {
+    const int cb = wv;
+    for (int i = cb; i < nb; ++i) {
+      d4 acc = d4_zero();
+      for (int k = cb; k < i; ++k) {
+        const double* const Ab = M0 + tri_blk(i, k) * 256;
+        const double* const Bb = M1 + tri_blk(k, cb) * 256;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int kx = 4 * kk + l4;
+          acc = mfma(Ab[sw(l15, kx)], Bb[sw(kx, l15)], acc);
+        }
+      }
+      double* const Tb = M1 + tri_blk(i, cb) * 256;
+      double t[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[r] = Tb[sw(acc_row(l4, r), l15)] - acc[r];
+      if (i == cb) {   // L_t's diagonal block is lower triangular; its upper positions hold other data by now
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (l15 > acc_row(l4, r)) t[r] = 0.0;
+      }
+      // X = L_d^-1 t: the accumulator registers are, as they stand, the B operand of the k-steps {4 r .. 4 r + 3}
+      // (tiles.h); L_d^-1 sits in the diagonal block's upper triangle and in s_rdb (wave_factor16_sw)
+      const double* const Ld = M0 + tri_blk(i, i) * 256;
+      const double* const rd = s_rdb + 16 * i;
+      d4 x = d4_zero();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x = mfma(inv_elem(Ld, rd, l15, 4 * r + l4), t[r], x);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[r] = x[r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Tb[sw(acc_row(l4, r), l15)] = t[r];
+    }
+  }
+  __syncthreads();
+  SSTAMP(5);
+
+  // ---- lift terms: thread c walks column c of V downwards, w[j][c] = V[j][c] (2 y~_c - N_j - N_{j-1}) ---------
+  if (tid < p) {
+    const int c = tid, cbk = c >> 4, cc = c & 15;
+    const double y2 = 2.0 * s_y[c];
+    double N = 0.0;
+    int j = c;
+    for (; j + 3 < p; j += 4) {
+      int off[4];
+      double v[4], zz[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        off[u] = tri_blk((j + u) >> 4, cbk) * 256 + sw((j + u) & 15, cc);
+        v[u] = M1[off[u]];
+        zz[u] = s_z[j + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double Nn = fma(zz[u], v[u], N);
+        M0[off[u]] = v[u] * (y2 - Nn - N);      // L is dead: its storage takes the terms
+        N = Nn;
+      }
+    }
+    for (; j < p; ++j) {
+      const int off = tri_blk(j >> 4, cbk) * 256 + sw(j & 15, cc);
+      const double v = M1[off];
+      const double Nn = fma(s_z[j], v, N);
+      M0[off] = v * (y2 - Nn - N);
+      N = Nn;
+    }
+  }
+  __syncthreads();
+  SSTAMP(6);
+
+  // ---- lift_j = z_j / ||y||^2 * sum_{c <= j} w[j][c]; four threads per row ------------------------------------
+  {
+    const int j = tid >> 2, q = tid & 3;
+    double sacc = 0.0;
+    if (j < p)
+      for (int c = q; c <= j; c += 4) sacc += M0[tri_blk(j >> 4, c >> 4) * 256 + sw(j & 15, c & 15)];
+    sacc += __shfl_xor(sacc, 1);
+    sacc += __shfl_xor(sacc, 2);
+    if (j < p && q == 0) {
+      const double lift = s_z[j] * sacc / a.y_norm_sq;
+      double* dst = a.lifts + (int64_t)(ord / a.per_sample) * p + s_perm[j];
+      if (a.per_sample == 2) atomicAdd(dst, 0.5 * lift);   // the pair's two terms commute: order-independent sum
+      else *dst = lift;
+    }
+  }
+  if (tid == 0 && s_bad) atomicOr(a.info, 1);
+  SSTAMP(7);
+}
+
+size_t small_p_lds_bytes(int nb) {
+  const size_t ntri = (size_t)nb * (nb + 1) / 2;
+  return (2 * ntri * 256 + 2 * 16 * SINV_LD + 256 + 256 + 128 + 128) * sizeof(double) + 128 * sizeof(int32_t);
+}
+
+bool small_p_eligible(int p) { return p >= 1 && p + 1 <= 128; }
+
+hipError_t launch_small_p(const SmallArgs& a, hipStream_t st) {
+  if (!small_p_eligible(a.p) || a.nb != (a.p + 1 + 15) / 16 || a.n_ord < 1 || (a.per_sample != 1 && a.per_sample != 2) ||
+      (a.n_ord % a.per_sample) != 0 || !a.S[0] || !a.S[1] || !a.perms || !a.lifts)
+    return hipErrorInvalidValue;
+  const size_t bytes = small_p_lds_bytes(a.nb);
+  static size_t configured = 0;
+  if (bytes > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(small_p_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    configured = bytes;
+  }
+  hipLaunchKernelGGL(small_p_kernel, dim3(a.n_ord), dim3(512), bytes, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace lsspa

@@ -30,6 +30,25 @@ hipError_t launch_gather(const GatherArgs& a, hipStream_t st);
 // dst[i] = (float)src[i]
 hipError_t launch_to_f32(const double* src, float* dst, int64_t count, hipStream_t st);
 
+// Fused small-p path (k_small.hip): one workgroup per ordering, gather -> two Choleskys -> V -> lifts in LDS.
+// fp64, tri mode, p + 1 <= 128.  With per_sample == 2 orderings 2 s and 2 s + 1 each add half their lift vector
+// to sample s (lifts must be zero beforehand); with 1 the lift vector is stored.
+struct SmallArgs {
+  const double* S[2];      // source Gram matrices (train, test), row-major, stride ld_src
+  const double* s[2];      // source right-hand sides (g, h)
+  double aug[2];           // diagonal value of the augmented row
+  int64_t ld_src;
+  const int32_t* perms;    // [n_ord][p]
+  int p, nb, n_ord, per_sample;   // nb = ceil((p + 1) / 16)
+  double* lifts;           // [n_ord / per_sample][p]
+  double y_norm_sq;
+  double piv_tol;
+  int32_t* info;
+};
+bool small_p_eligible(int p);
+size_t small_p_lds_bytes(int nb);
+hipError_t launch_small_p(const SmallArgs& a, hipStream_t st);
+
 // Blocked Cholesky.  diag0 / piv_tol: a pivot d counts as non-positive (LSSPA_INFO_NOT_PD) when
 // d <= piv_tol * diag0.  chol_diag factors diagonal block J stand-alone (only block 0 needs it);
 // panel step J computes L[I,J] for the tiles below and, unless flags & 2, its tile-0 workgroups

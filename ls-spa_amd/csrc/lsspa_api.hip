@@ -119,6 +119,7 @@ struct lsspa_ctx {
   DevBuf<double> pack, xfer;     // packed moments; staging of host-side all-gathers
   DevBuf<int64_t> ibuf;
   int pack_from_p = 2048;        // the moments travel as an upper triangle from this p on
+  bool general_path_once = false;   // set while the factors themselves are wanted (full_fit, get_factors, debug_factor)
   int fail_alloc_in = 0;   // test hook (lsspa_debug_fail_alloc): the n-th device allocation from now fails
 
   // profiling
@@ -456,6 +457,32 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
   double* const Ppart_s = L.Ppart.ptr + (size_t)ord_off * (m_pad / 64) * p_pad;
   const int32_t* const perms_s = L.perms_cur + (size_t)ord_off * p;
   const bool timed = (st == ctx->lane_stream(L));   // the profiling events live on the lane's main stream
+  // a1: small problems take the fused kernel (developer flag 1024 forces the general path, which full_fit,
+  // get_factors and debug_factor also need: they read the factors back from the work matrices)
+  if (ctx->tri && !ctx->f32 && small_p_eligible(p) && !(ctx->flags & 1024) && !ctx->general_path_once) {
+    ProfScope ps(timed ? ctx : nullptr, LSSPA_K_SMALL, st);
+    SmallArgs sa;
+    sa.S[0] = ctx->G.ptr;
+    sa.S[1] = ctx->H.ptr;
+    sa.s[0] = ctx->g.ptr;
+    sa.s[1] = ctx->h.ptr;
+    sa.aug[0] = 2.0 * ctx->aug_train + 1.0;
+    sa.aug[1] = 2.0 * ctx->y_norm_sq + 1.0;
+    sa.ld_src = p_pad;
+    sa.perms = perms_s;
+    sa.p = p;
+    sa.nb = (p + 1 + 15) / 16;
+    sa.n_ord = n_ord;
+    sa.per_sample = per_sample;
+    sa.lifts = L.lifts.ptr + (size_t)s_off * p;
+    sa.y_norm_sq = ctx->y_norm_sq;
+    sa.piv_tol = 16.0 * (double)p * 2.220446049250313e-16;
+    sa.info = ctx->info_d.ptr;
+    if (per_sample == 2)
+      HIPCHK(hipMemsetAsync(sa.lifts, 0, sizeof(double) * (size_t)(n_ord / 2) * p, st));
+    HIPCHK(launch_small_p(sa, st));
+    return LSSPA_OK;
+  }
   {
     ProfScope ps(timed ? ctx : nullptr, LSSPA_K_GATHER, st);
     GatherArgs ga;
@@ -1226,7 +1253,10 @@ static int factor_identity(lsspa_ctx* ctx, const int32_t* perm_or_null) {
   std::vector<int32_t> id(p);
   for (int j = 0; j < p; ++j) id[j] = perm_or_null ? perm_or_null[j] : j;
   TRY(sync_all(ctx));                       // the conversion above ran on the context's stream
-  TRY(stage_and_run(ctx, L, id.data(), 1, 1, 0));
+  ctx->general_path_once = true;            // the callers read L back from the work matrices
+  const int rc = stage_and_run(ctx, L, id.data(), 1, 1, 0);
+  ctx->general_path_once = false;
+  if (rc != LSSPA_OK) return rc;
   TRY(sync_all(ctx));                       // callers read results with blocking copies
   return LSSPA_OK;
 }

@@ -272,6 +272,46 @@ __device__ __forceinline__ void block64_put(const DenseBlock64Regs<T, NT>& b, T*
   }
 }
 
+// ---- lane-level helpers of the in-register 16 x 16 eliminations (k_factor.hip, k_small.hip) ----------------
+template <typename T>
+__device__ __forceinline__ T bcast_lane(T v, int src) {   // value of v in lane src (uniform src)
+  if constexpr (sizeof(T) == 8) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint((double)v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint((double)v), src);
+    return (T)__hiloint2double(hi, lo);
+  } else {
+    return (T)__int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)v), src));
+  }
+}
+
+// 1 / d to working precision without the division sequence: hardware reciprocal + two Newton steps
+// (the elimination's critical path runs through this once per pivot)
+template <typename T>
+__device__ __forceinline__ T fast_recip(T d) {
+  if constexpr (sizeof(T) == 8) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+  } else {
+    float r = __builtin_amdgcn_rcpf(d);
+    r = fmaf(fmaf(-d, r, 1.0f), r, r);
+    return r;
+  }
+}
+
+// value of v in the lane whose byte address (4 * lane) is addr
+template <typename T>
+__device__ __forceinline__ T bperm(int addr, T v) {
+  if constexpr (sizeof(T) == 8) {
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint((double)v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint((double)v));
+    return (T)__hiloint2double(hi, lo);
+  } else {
+    return (T)__int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int((float)v)));
+  }
+}
+
 // fp64 helpers kept for the Gram kernel (always fp64 accumulation)
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return Tr<double>::mfma(a, b, c); }
 __device__ __forceinline__ int acc_row(int l4, int r) { return Tr<double>::acc_row(l4, r); }

@@ -14,7 +14,7 @@ OK = 0
 F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
 INFO_NOT_PD = 1
-KERNEL_CLASSES = ("gather", "chol_diag", "chol_panel", "strip", "lift", "stats", "gram", "error", "comm")
+KERNEL_CLASSES = ("gather", "chol_diag", "chol_panel", "strip", "lift", "stats", "gram", "error", "comm", "small_p")
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.normpath(os.path.join(_PKG_DIR, "..", "lib", "liblsspa_hip.so"))

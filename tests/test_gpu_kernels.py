@@ -436,3 +436,64 @@ def test_driver_lookahead_on_the_device():
         np.testing.assert_array_equal(c.attribution, one.attribution)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("p,n,m", [(3, 50, 50), (9, 80, 60), (15, 90, 70), (16, 90, 70), (63, 300, 200), (100, 400, 300),
+                                   (126, 500, 400), (127, 500, 400)])
+def test_fused_small_p_kernel(p, n, m):
+    """p + 1 <= 128: the one-workgroup kernel (gather -> two Choleskys -> V -> lifts in LDS) against the oracle and
+    against the general multi-kernel path (developer flag 1024), single orderings and antithetical pairs."""
+    from ls_spa._engine import HipEngine
+    d = problem(20 + p, p, n, m)
+    rng = np.random.default_rng(p)
+    perms = np.array([rng.permutation(p) for _ in range(24)])
+    perms[0] = np.arange(p)
+    perms[1] = np.arange(p)[::-1]
+    red = O.reduce(*d, 0.0)
+    yy = float(d[3] @ d[3])
+    eng = HipEngine(0)
+    try:
+        eng.load_data(*d, 0.0)
+        eng.profile(True)
+        single = eng.run_batch(perms, False, want_lifts=True, accumulate=False)
+        paired = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        used = eng.profile_read()
+        assert used["small_p"][1] == 2 and used["gather"][1] == 0, used      # the fused kernel ran, nothing else
+        eng.profile(False)
+        assert eng.info() == 0
+        want1 = np.array([O.ordering_lift(*red, yy, o) for o in perms])
+        want2 = np.array([O.sample_lift(*red, yy, o, True) for o in perms])
+        np.testing.assert_allclose(single, want1, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(paired, want2, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(single.sum(1), single[0].sum(), rtol=0, atol=1e-11)   # every ordering: the full R^2
+        eng.set_flags(1024)
+        general = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        eng.set_flags(0)
+        np.testing.assert_allclose(paired, general, rtol=0, atol=1e-12)
+        # statistics through the fused path
+        eng.reset_stats()
+        eng.run_batch(perms, True, accumulate=True)
+        eng.merge()
+        nacc, mean, cov = eng.stats()
+        assert nacc == 24
+        np.testing.assert_allclose(mean, want2.mean(0), rtol=0, atol=1e-11)
+        theta, r2, info = eng.full_fit()        # reads the factors back: takes the general path
+        assert info == 0 and abs(r2 - single[0].sum()) < 1e-11
+    finally:
+        eng.close()
+
+
+def test_fused_small_p_flags_collinear_features():
+    from ls_spa._engine import HipEngine
+    d = list(problem(5, 20, 200, 150))
+    d[0] = d[0].copy()
+    d[1] = d[1].copy()
+    d[0][:, 7] = d[0][:, 3]       # feature 7 duplicates feature 3 in both sets
+    d[1][:, 7] = d[1][:, 3]
+    eng = HipEngine(0)
+    try:
+        eng.load_data(*d, 0.0)
+        eng.run_batch(np.arange(20)[None, :], False, want_lifts=True, accumulate=False)
+        assert eng.info() & 1      # LSSPA_INFO_NOT_PD, as on the general path
+    finally:
+        eng.close()
