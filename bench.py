@@ -51,7 +51,8 @@ def parse():
                     help="transport of the all-reduce with several ranks: RCCL through the C ABI, or torch.distributed")
     ap.add_argument("--lookahead", type=int, default=0,
                     help="steps whose orderings are launched as one GPU batch and then accumulated / all-reduced / merged "
-                         "step by step (what ls_spa(lookahead=k) does); 0 = 4 when a rank's step has <= 32 samples, else 1")
+                         "step by step (what ls_spa(lookahead=k) does); 0 = auto: 8 for p <= 126, 4 when a rank's step "
+                         "has <= 32 samples, else 1")
     ap.add_argument("--lanes", type=int, choices=(1, 2), default=1,
                     help="batches in flight on the engine (lsspa_set_lanes): 2 = the next step's kernels run beside this one's")
     ap.add_argument("--no-probe", action="store_true", help="skip the strong-scaling probe (clean rocprof averages)")
@@ -293,7 +294,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    D = args.lookahead if args.lookahead > 0 else (4 if B_rank <= 32 else 1)
+    # auto: a step that fills a fraction of the GPU (few samples per rank, or the one-workgroup-per-ordering kernel
+    # of small problems) is launched in groups
+    D = args.lookahead if args.lookahead > 0 else (8 if p + 1 <= 128 else (4 if B_rank <= 32 else 1))
 
     class Steps:
         """step(k) = one batch of B_rank samples into the statistics.  With D > 1 the kernels of D consecutive steps
@@ -302,25 +305,37 @@ def main():
         per-batch order, a fuller GPU.  Groups start at the first step of a region."""
 
         def __init__(self):
-            self.ticket, self.base, self.end = None, 0, 0
+            self.tickets, self.base, self.end = {}, 0, 0
 
         def region(self, k0, k1):
-            self.base, self.end = k0, k1
+            for tk in self.tickets.values():      # a group launched ahead across a region boundary
+                eng.discard_batch(tk)
+            self.tickets, self.base, self.end = {}, k0, k1
+
+        def launch(self, g):
+            lo = self.base + g * D
+            if lo < self.end and g not in self.tickets:
+                self.tickets[g] = eng.launch_batch(my_perms[lo:min(lo + D, self.end)].reshape(-1, p), True)
 
         def __call__(self, k):
             if D == 1:
                 eng.run_batch(my_perms[k], True, want_lifts=False, accumulate=True)
             else:
-                j = (k - self.base) % D
+                g, j = divmod(k - self.base, D)
                 if j == 0:
-                    hi = min(k + D, self.end)
-                    self.ticket = eng.launch_batch(my_perms[k:hi].reshape(-1, p), True)
-                eng.collect_batch(self.ticket, want_lifts=False, accumulate=True, first=j * B_rank, count=B_rank)
+                    self.launch(g)
+                    if eng.lanes == 2:
+                        self.launch(g + 1)       # the second lane holds the next group: its upload and kernels run
+                                                 # while this group is accumulated step by step
+                eng.collect_batch(self.tickets[g], want_lifts=False, accumulate=True, first=j * B_rank, count=B_rank)
+                if j == D - 1 or k == self.end - 1:
+                    del self.tickets[g]
             comm.allreduce_pending(eng)
             eng.merge()
 
     step = Steps()
 
+    eng.set_lanes(args.lanes)
     # pass 1: the timed region proper (no events between the launches: an event record costs a
     # ~10 us bubble per kernel boundary)
     eng.profile(False)

@@ -252,7 +252,62 @@ __global__ __launch_bounds__(256) void stats_reduce_kernel(const double* __restr
   }
 }
 
+// Batch moments for small p on the matrix pipe: one wave per lower 16 x 16 tile of Q = D^T D (D = lifts - mean,
+// n_samples x p), operands straight from memory (16 consecutive features of one sample = one 128-byte segment),
+// the tile and its mirror stored together (Q stays exactly symmetric).  The last workgroup sums the columns (S) and
+// writes n_b.  A few microseconds where the 64 x 64-tile kernel above, with a handful of workgroups, takes forty.
+__global__ __launch_bounds__(64) void stats_small_kernel(const double* __restrict__ lifts,
+                                                         const double* __restrict__ mean, double* __restrict__ buf,
+                                                         int n_samples, int p, int accumulate) {
+  const int lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
+  double* S = buf + 1;
+  double* Q = buf + 1 + p;
+  int ti = 0, t = blockIdx.x;
+  while (t >= ti + 1) {
+    t -= ti + 1;
+    ++ti;
+  }
+  const int tj = t;
+  const bool diag = ti == tj;
+  const int a = 16 * ti + l15, b = 16 * tj + l15;
+  const int ac = a < p ? a : p - 1, bc = b < p ? b : p - 1;     // clamped addresses, value selected afterwards
+  const double mua = mean[ac], mub = mean[bc];
+  d4 acc = d4_zero(), colsum = d4_zero();
+  // 32 samples per trip: 16 independent loads per lane in flight, then 8 (+8) MFMAs
+  for (int s0 = 0; s0 < n_samples; s0 += 32) {
+    double av[8], bv[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int s = s0 + 4 * kk + l4;
+      const int sc = s < n_samples ? s : n_samples - 1;
+      const double xa = lifts[(int64_t)sc * p + ac] - mua, xb = lifts[(int64_t)sc * p + bc] - mub;
+      av[kk] = (s < n_samples && a < p) ? xa : 0.0;
+      bv[kk] = (s < n_samples && b < p) ? xb : 0.0;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      acc = mfma(av[kk], bv[kk], acc);
+      if (diag) colsum = mfma(av[kk], 1.0, colsum);     // every column of the result = sum over the samples of D[., a]
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ai = 16 * ti + acc_row(l4, r), bi = 16 * tj + l15;
+    if (ai < p && bi < p) {
+      const int64_t o = (int64_t)ai * p + bi, om = (int64_t)bi * p + ai;
+      const double v = accumulate ? Q[o] + acc[r] : acc[r];
+      Q[o] = v;
+      if (!diag) Q[om] = v;
+    }
+    if (diag && l15 == 0 && ai < p) S[ai] = accumulate ? S[ai] + colsum[r] : colsum[r];
+  }
+  if (blockIdx.x == 0 && lane == 0) buf[0] = accumulate ? buf[0] + (double)n_samples : (double)n_samples;
+}
+
 int stats_batch_slices(int n_samples, int p) {
+  // a handful of tiles and a few hundred samples: one launch beats slices plus their reduction (every launch
+  // costs the host more than this kernel runs)
+  if (p <= 128 && n_samples <= 512) return 1;
   const int nt = (p + 63) / 64;
   int z = 512 / (nt * nt);                       // aim at ~2 workgroups per CU
   z = z < (n_samples + 63) / 64 ? z : (n_samples + 63) / 64;   // at least 64 samples per slice
@@ -262,6 +317,12 @@ int stats_batch_slices(int n_samples, int p) {
 hipError_t launch_stats_batch(const double* lifts, const double* mean, double* buf, int n_samples, int p,
                               int accumulate, double* parts, hipStream_t st) {
   if (n_samples < 1 || p < 1) return hipErrorInvalidValue;
+  if (p <= 128 && n_samples <= 512) {
+    const int t16 = (p + 15) / 16, n_tiles = t16 * (t16 + 1) / 2;
+    hipLaunchKernelGGL(stats_small_kernel, dim3(n_tiles), dim3(64), 0, st, lifts, mean, buf, n_samples, p,
+                       accumulate);
+    return hipGetLastError();
+  }
   const int nt = (p + 63) / 64;
   const int nz = parts ? stats_batch_slices(n_samples, p) : 1;
   const int per = (((n_samples + nz - 1) / nz + 15) / 16) * 16;
@@ -355,10 +416,63 @@ __global__ __launch_bounds__(256) void stats_advance_kernel(const double* __rest
   if (threadIdx.x == 0) state_n[0] = n + nb;
 }
 
-hipError_t launch_stats_merge(const double* buf, double* state_n, double* mean, double* M2, int p,
-                              hipStream_t st) {
+// The same merge as ONE launch, for small p (where three launches cost the host more than they run): every
+// workgroup updates its share of M2 and clears the part of the pending buffer it consumed; the workgroup that
+// finishes LAST (ticket in state[1], agent-scope fences around it) advances mean and n and clears n_b and S, which
+// all the others have read by then.  state: [n, ticket, ...].
+__global__ __launch_bounds__(256) void stats_merge_fused_kernel(double* __restrict__ buf, double* __restrict__ state,
+                                                                double* __restrict__ mean, double* __restrict__ M2,
+                                                                int p) {
+  __shared__ int s_last;
+  const double nb = buf[0];
+  const double n = state[0];
+  double* S = buf + 1;
+  double* Q = buf + 1 + p;
+  if (nb > 0.0) {
+    const double coef = n * nb / (n + nb) - nb;
+    const double inv = 1.0 / nb;
+    const int64_t total = (int64_t)p * p;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+      const int ai = (int)(o / p), bi = (int)(o - (int64_t)ai * p);
+      M2[o] += Q[o] + coef * (S[ai] * inv) * (S[bi] * inv);
+      Q[o] = 0.0;
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(state + 1);
+    s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (nb > 0.0) {
+    const double wgt = 1.0 / (n + nb);
+    for (int i = threadIdx.x; i < p; i += 256) {
+      mean[i] += S[i] * wgt;
+      S[i] = 0.0;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (nb > 0.0) state[0] = n + nb;
+    buf[0] = 0.0;
+    *reinterpret_cast<unsigned int*>(state + 1) = 0u;
+  }
+}
+
+hipError_t launch_stats_merge(double* buf, double* state_n, double* mean, double* M2, int p, hipStream_t st,
+                              bool* cleared) {
   if (p < 1) return hipErrorInvalidValue;
   const int64_t total = (int64_t)p * p;
+  if (p <= 256) {
+    const int grid = (int)((total + 255) / 256 < 64 ? (total + 255) / 256 : 64);
+    hipLaunchKernelGGL(stats_merge_fused_kernel, dim3(grid), dim3(256), 0, st, buf, state_n, mean, M2, p);
+    if (cleared) *cleared = true;
+    return hipGetLastError();
+  }
+  if (cleared) *cleared = false;
   const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(stats_merge_m2_kernel, dim3(grid), dim3(256), 0, st, buf, state_n, M2, p);
   hipError_t e = hipGetLastError();

@@ -96,9 +96,10 @@ hipError_t launch_lift(const LiftArgs& a, hipStream_t st);
 int stats_batch_slices(int n_samples, int p);
 hipError_t launch_stats_batch(const double* lifts, const double* mean, double* buf, int n_samples, int p,
                               int accumulate, double* parts, hipStream_t st);
-// Chan merge of the pending batch into (n, mean, M2); n lives in state[0]
-hipError_t launch_stats_merge(const double* buf, double* state_n, double* mean, double* M2, int p,
-                              hipStream_t st);
+// Chan merge of the pending batch into (n, mean, M2); n lives in state[0] (state[1] is the fused kernel's ticket and
+// must start at zero).  *cleared: the launch also zeroed the pending buffer (small p: one fused kernel)
+hipError_t launch_stats_merge(double* buf, double* state_n, double* mean, double* M2, int p, hipStream_t st,
+                              bool* cleared);
 
 // upper-triangle packing of the pending-batch buffer for the all-reduce (Q is symmetric):
 // packed = [n_b, S (p), Q[i][i..p-1] ...], stats_packed_count(p) = 1 + p + p (p + 1) / 2 elements

@@ -119,6 +119,7 @@ struct lsspa_ctx {
   DevBuf<double> pack, xfer;     // packed moments; staging of host-side all-gathers
   DevBuf<int64_t> ibuf;
   int pack_from_p = 2048;        // the moments travel as an upper triangle from this p on
+  std::vector<int32_t> perm_mark;   // scratch of the ordering validation
   bool general_path_once = false;   // set while the factors themselves are wanted (full_fit, get_factors, debug_factor)
   int fail_alloc_in = 0;   // test hook (lsspa_debug_fail_alloc): the n-th device allocation from now fails
 
@@ -648,23 +649,31 @@ int stage_and_run(lsspa_ctx* ctx, Lane& L, const int32_t* perms, int n_samples, 
   for (int s = 0; s < n_samples; ++s) {
     const int32_t* src = perms + (size_t)s * p;
     int32_t* d0 = hp + (size_t)s * per_sample * p;
-    for (int j = 0; j < p; ++j) {
-      const int32_t f = src[j];
-      if (f < 0 || f >= p) return ctx->fail(LSSPA_ERR_ARG, "ordering entry out of range");
-      d0[j] = f;
-    }
+    std::memcpy(d0, src, sizeof(int32_t) * (size_t)p);   // validated by the caller (all_permutations)
     if (per_sample == 2) {
       int32_t* d1 = d0 + p;
       for (int j = 0; j < p; ++j) d1[j] = src[p - 1 - j];
     }
   }
+  int32_t* dp = L.perms_d.ptr + (size_t)turn * L.cap_ord * p;
+  const size_t bytes = sizeof(int32_t) * (size_t)n_ord * p;
+  if (bytes <= ((size_t)1 << 20)) {
+    // a small upload rides on the lane's own stream: one copy and one event (the pinned buffer's reuse guard)
+    // instead of a hand-off to the copy stream and back -- four stream operations that cost the host more than
+    // the copy costs the GPU
+    HIPCHK(hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(L.perms_ev[turn], st));
+    L.perms_busy[turn] = true;
+    L.perms_cur = dp;
+    L.perms_used_valid[turn] = false;    // stream order protects the device slot
+    return run_orderings(ctx, L, n_ord, per_sample, s_off);
+  }
   if (!L.copy_stream) {
     HIPCHK(hipStreamCreateWithFlags(&L.copy_stream, hipStreamNonBlocking));
     for (int b = 0; b < 2; ++b) HIPCHK(hipEventCreateWithFlags(&L.perms_used[b], hipEventDisableTiming));
   }
-  int32_t* dp = L.perms_d.ptr + (size_t)turn * L.cap_ord * p;
   if (L.perms_used_valid[turn]) HIPCHK(hipStreamWaitEvent(L.copy_stream, L.perms_used[turn], 0));
-  HIPCHK(hipMemcpyAsync(dp, hp, sizeof(int32_t) * (size_t)n_ord * p, hipMemcpyHostToDevice, L.copy_stream));
+  HIPCHK(hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, L.copy_stream));
   HIPCHK(hipEventRecord(L.perms_ev[turn], L.copy_stream));
   L.perms_busy[turn] = true;
   HIPCHK(hipStreamWaitEvent(st, L.perms_ev[turn], 0));
@@ -770,6 +779,21 @@ bool is_permutation(const int32_t* perm, int p, std::vector<char>& seen) {
     const int32_t f = perm[j];
     if (f < 0 || f >= p || seen[f]) return false;
     seen[f] = 1;
+  }
+  return true;
+}
+
+// the same for B rows with one scratch array: row s marks its entries with the stamp s + 1
+bool all_permutations(const int32_t* perms, int B, int p, std::vector<int32_t>& mark) {
+  mark.assign(p, 0);
+  for (int s = 0; s < B; ++s) {
+    const int32_t* row = perms + (size_t)s * p;
+    const int32_t stamp = s + 1;
+    for (int j = 0; j < p; ++j) {
+      const uint32_t f = (uint32_t)row[j];
+      if (f >= (uint32_t)p || mark[f] == stamp) return false;
+      mark[f] = stamp;
+    }
   }
   return true;
 }
@@ -1340,12 +1364,8 @@ int lsspa_lift_batch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t an
   const int p = ctx->p;
   const int per = antithetical ? 2 : 1;
   // validate before anything is launched: a repeated index would make a permuted Gram singular
-  {
-    std::vector<char> seen;
-    for (int s = 0; s < B; ++s)
-      if (!is_permutation(perms + (size_t)s * p, p, seen))
-        return ctx->fail(LSSPA_ERR_ARG, "perms: a row is not a permutation of 0..p-1");
-  }
+  if (!all_permutations(perms, B, p, ctx->perm_mark))
+    return ctx->fail(LSSPA_ERR_ARG, "perms: a row is not a permutation of 0..p-1");
   Lane* L = nullptr;
   TRY(lift_launch(ctx, perms, B, per, &L));
   return lift_collect(ctx, *L, 0, B, lifts_out, accumulate);
@@ -1358,12 +1378,8 @@ int lsspa_lift_launch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t a
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   if (!perms || B < 1 || !ticket) return ctx->fail(LSSPA_ERR_ARG, "perms / B / ticket");
   HIPCHK(hipSetDevice(ctx->device));
-  {
-    std::vector<char> seen;
-    for (int s = 0; s < B; ++s)
-      if (!is_permutation(perms + (size_t)s * ctx->p, ctx->p, seen))
-        return ctx->fail(LSSPA_ERR_ARG, "perms: a row is not a permutation of 0..p-1");
-  }
+  if (!all_permutations(perms, B, ctx->p, ctx->perm_mark))
+    return ctx->fail(LSSPA_ERR_ARG, "perms: a row is not a permutation of 0..p-1");
   Lane* L = nullptr;
   TRY(lift_launch(ctx, perms, B, antithetical ? 2 : 1, &L));
   *ticket = (int32_t)(L - ctx->lanes);
@@ -1415,14 +1431,16 @@ int lsspa_stats_merge(lsspa_ctx* ctx) {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
+  bool cleared = false;
   {
     ProfScope ps(ctx, LSSPA_K_STATS);
-    HIPCHK(launch_stats_merge(ctx->pend.ptr, ctx->state_n.ptr, ctx->mean.ptr, ctx->M2.ptr, ctx->p,
-                              ctx->stream));
+    HIPCHK(launch_stats_merge(ctx->pend.ptr, ctx->state_n.ptr, ctx->mean.ptr, ctx->M2.ptr, ctx->p, ctx->stream,
+                              &cleared));
   }
   // an empty pending buffer (n_b = 0) is what a rank with no samples contributes
-  HIPCHK(hipMemsetAsync(ctx->pend.ptr, 0, sizeof(double) * ((size_t)1 + ctx->p + (size_t)ctx->p * ctx->p),
-                        ctx->stream));
+  if (!cleared)
+    HIPCHK(hipMemsetAsync(ctx->pend.ptr, 0, sizeof(double) * ((size_t)1 + ctx->p + (size_t)ctx->p * ctx->p),
+                          ctx->stream));
   ctx->pend_dirty = false;
   return LSSPA_OK;
 }
