@@ -7,26 +7,100 @@
 // the N rows are cut into n_split slices; one workgroup owns (tile pair, slice) and writes
 // its partial tile to a slab; a second kernel sums the slabs in a fixed order, so the result
 // is bitwise reproducible (no float atomics).
+#include <algorithm>
+
 #include "kernels.h"
 #include "tiles.h"
 
 namespace lsspa {
 
+// One 16-row chunk of a 128-column tile of Z = [X | y], held in registers between its global load and its LDS
+// store: 16-byte vectors, one wave instruction = one contiguous row of the tile (1 KB fp64, 512 B fp32).
 template <typename T>
-__device__ __forceinline__ double zload(const T* __restrict__ X, const T* __restrict__ y, int64_t row,
-                                        int col, int64_t ld, int p, int64_t n) {
-  if (row >= n) return 0.0;
-  if (col < p) return (double)X[row * ld + col];
-  if (col == p) return (double)y[row];
-  return 0.0;
+struct ZRegs {
+  static constexpr int VE = 16 / sizeof(T);     // elements per vector: 2 / 4
+  static constexpr int VPR = 128 / VE;          // vectors per tile row: 64 / 32
+  static constexpr int RPP = 256 / VPR;         // rows per pass: 4 / 8
+  static constexpr int NP = 16 / RPP;           // passes: 4 / 2
+  typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+  // the same vector as it lies in the caller's matrix: rows start at any multiple of sizeof(T) (ld need not be even)
+  typedef T gvec_t __attribute__((ext_vector_type(16 / sizeof(T)), aligned(sizeof(T))));
+  vec_t v[NP];
+};
+
+// Column class of a thread's vector inside its tile (loop invariant): 0 = all VE columns are features (plain
+// vector load), 1 = the vector touches column p (= y) or the end of the features (element-wise), 2 = padding (zeros).
+template <typename T>
+__device__ __forceinline__ int zcol_mode(int col0, int p) {
+  constexpr int VE = ZRegs<T>::VE;
+  if (col0 + VE <= p) return 0;
+  return col0 <= p ? 1 : 2;
 }
 
+// FULL: the tile lies inside the features and the 16 rows exist -- no guards at all.  Otherwise rows at or beyond
+// r_hi and columns beyond y read as zero; addresses stay inside the arrays (clamped rows, per-element columns).
+template <typename T, bool FULL>
+__device__ __forceinline__ void zload(ZRegs<T>& r, const T* __restrict__ X, const T* __restrict__ y, int64_t ld,
+                                      int p, int col_tile0, int64_t row0, int64_t r_hi, int tid, int mode) {
+  typedef ZRegs<T> R;
+  const int vc = tid % R::VPR, k0 = tid / R::VPR;
+  const int col0 = col_tile0 + R::VE * vc;
+#pragma unroll
+  for (int q = 0; q < R::NP; ++q) {
+    const int64_t row = row0 + k0 + R::RPP * q;
+    if constexpr (FULL) {
+      r.v[q] = *reinterpret_cast<const typename R::gvec_t*>(X + row * ld + col0);
+    } else {
+      const int64_t rc = row < r_hi ? row : r_hi - 1;
+      typename R::vec_t v;
+      if (mode == 0) {
+        v = *reinterpret_cast<const typename R::gvec_t*>(X + rc * ld + col0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < R::VE; ++e) {
+          const int c = col0 + e;
+          T val = (T)0;
+          if (mode == 1) {
+            if (c < p) val = X[rc * ld + c];
+            else if (c == p) val = y[rc];
+          }
+          v[e] = val;
+        }
+      }
+      if (row >= r_hi) {
+#pragma unroll
+        for (int e = 0; e < R::VE; ++e) v[e] = (T)0;
+      }
+      r.v[q] = v;
+    }
+  }
+}
+
+// registers -> LDS tile [16 k][KC_LD] of doubles (fp32 data is widened here: the contraction runs in fp64)
 template <typename T>
-__global__ __launch_bounds__(256, 1) void gram_kernel(const T* __restrict__ X, const T* __restrict__ y,
+__device__ __forceinline__ void zstore(const ZRegs<T>& r, double* lds, int tid) {
+  typedef ZRegs<T> R;
+  const int vc = tid % R::VPR, k0 = tid / R::VPR;
+#pragma unroll
+  for (int q = 0; q < R::NP; ++q) {
+    double* dst = lds + (k0 + R::RPP * q) * KC_LD + R::VE * vc;
+#pragma unroll
+    for (int e = 0; e < R::VE; e += 2) {
+      v2d w = {(double)r.v[q][e], (double)r.v[q][e + 1]};
+      *reinterpret_cast<v2d*>(dst + e) = w;
+    }
+  }
+}
+
+// Workgroup = (tile pair, row slice): C_slab[128][128] = Z[rows, tile i]^T Z[rows, tile j] over the slice's rows,
+// 16 rows per k-chunk.  Double-buffered LDS (one barrier per chunk): the global loads of chunk c + 1 are issued
+// before the 64 MFMAs per wave of chunk c and parked in LDS after them.  Two workgroups per CU.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gram_kernel(const T* __restrict__ X, const T* __restrict__ y,
                                                       int64_t n, int64_t ld, int p, int rows_per_split,
                                                       int n_pairs, double* __restrict__ slabs) {
-  __shared__ __attribute__((aligned(16))) double s_i[16 * KC_LD];
-  __shared__ __attribute__((aligned(16))) double s_j[16 * KC_LD];
+  __shared__ __attribute__((aligned(16))) double s_i[2][16 * KC_LD];
+  __shared__ __attribute__((aligned(16))) double s_j[2][16 * KC_LD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   // tile pair index -> (ti >= tj)
@@ -41,6 +115,9 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(const T* __restrict__ X, c
   const int64_t r_lo = (int64_t)blockIdx.y * rows_per_split;
   const int64_t r_hi = (r_lo + rows_per_split < n) ? r_lo + rows_per_split : n;
   const int wi = w >> 1, wj = w & 1;  // wave quadrant: rows 64 wi .., cols 64 wj ..
+  const bool full_i = ci0 + 128 <= p, full_j = cj0 + 128 <= p;     // tile j <= tile i: full_i implies full_j
+  const int mode_i = zcol_mode<T>(ci0 + ZRegs<T>::VE * (tid % ZRegs<T>::VPR), p);
+  const int mode_j = zcol_mode<T>(cj0 + ZRegs<T>::VE * (tid % ZRegs<T>::VPR), p);
 
   d4 acc[4][4];
 #pragma unroll
@@ -48,32 +125,43 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(const T* __restrict__ X, c
 #pragma unroll
     for (int yv = 0; yv < 4; ++yv) acc[x][yv] = d4_zero();
 
-  const int col = tid & 127, kr = tid >> 7;  // 2 k-rows per pass, 8 passes
-  double ri[8], rj[8];
-  auto fetch = [&](int64_t r0) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int64_t row = r0 + kr + 2 * q;
-      ri[q] = (row < r_hi) ? zload<T>(X, y, row, ci0 + col, ld, p, n) : 0.0;
-      if (!diag) rj[q] = (row < r_hi) ? zload<T>(X, y, row, cj0 + col, ld, p, n) : 0.0;
+  const int64_t n_rows = r_hi > r_lo ? r_hi - r_lo : 0;
+  const int n_chunks = (int)((n_rows + 15) / 16);
+  const int n_full = (int)(n_rows / 16);                           // chunks whose 16 rows all exist
+  ZRegs<T> ri, rj;
+  auto fetch = [&](int c) {
+    const int64_t row0 = r_lo + (int64_t)c * 16;
+    if (c < n_full && full_i) {       // wave-uniform
+      zload<T, true>(ri, X, y, ld, p, ci0, row0, r_hi, tid, 0);
+      if (!diag) zload<T, true>(rj, X, y, ld, p, cj0, row0, r_hi, tid, 0);
+    } else {
+      zload<T, false>(ri, X, y, ld, p, ci0, row0, r_hi, tid, mode_i);
+      if (!diag) {
+        if (c < n_full && full_j) zload<T, true>(rj, X, y, ld, p, cj0, row0, r_hi, tid, 0);
+        else zload<T, false>(rj, X, y, ld, p, cj0, row0, r_hi, tid, mode_j);
+      }
     }
   };
-  if (r_lo < r_hi) fetch(r_lo);
-  for (int64_t r0 = r_lo; r0 < r_hi; r0 += 16) {
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      s_i[(kr + 2 * q) * KC_LD + col] = ri[q];
-      if (!diag) s_j[(kr + 2 * q) * KC_LD + col] = rj[q];
-    }
-    __syncthreads();
-    if (r0 + 16 < r_hi) fetch(r0 + 16);
-    const double* sj = diag ? s_i : s_j;
+  if (n_chunks > 0) {
+    fetch(0);
+    zstore<T>(ri, s_i[0], tid);
+    if (!diag) zstore<T>(rj, s_j[0], tid);
+  }
+  __syncthreads();
+  for (int c = 0; c < n_chunks; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < n_chunks) fetch(c + 1);
+    const double* si = s_i[cur];
+    const double* sj = diag ? s_i[cur] : s_j[cur];
+    // diagonal pair: only the lower triangle of the tile is ever read (gram_finalize symmetrises from it), so the
+    // wave that owns the upper 64 x 64 quadrant sits the products out -- its SIMD's matrix pipe goes to the
+    // co-resident workgroup
+    if (!(diag && wi < wj)) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       double av[4], bv[4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) av[x] = s_i[(4 * kk + l4) * KC_LD + 64 * wi + 16 * x + l15];
+      for (int x = 0; x < 4; ++x) av[x] = si[(4 * kk + l4) * KC_LD + 64 * wi + 16 * x + l15];
 #pragma unroll
       for (int yv = 0; yv < 4; ++yv) bv[yv] = sj[(4 * kk + l4) * KC_LD + 64 * wj + 16 * yv + l15];
 #pragma unroll
@@ -81,6 +169,12 @@ __global__ __launch_bounds__(256, 1) void gram_kernel(const T* __restrict__ X, c
 #pragma unroll
         for (int yv = 0; yv < 4; ++yv) acc[x][yv] = mfma(av[x], bv[yv], acc[x][yv]);
     }
+    }
+    if (c + 1 < n_chunks) {
+      zstore<T>(ri, s_i[cur ^ 1], tid);
+      if (!diag) zstore<T>(rj, s_j[cur ^ 1], tid);
+    }
+    __syncthreads();
   }
   double* slab = slabs + ((int64_t)blockIdx.y * n_pairs + blockIdx.x) * (128 * 128);
 #pragma unroll
@@ -139,13 +233,22 @@ size_t gram_workspace_bytes(int p, int n_split) {
 }
 
 int gram_default_split(int64_t n, int p) {
-  // aim at ~4 workgroups per CU, slices of at least 64 rows, multiples of 16 rows
+  // Workgroups = tile pairs x row slices, two resident per CU (512 at a time) and all about equally long: pick
+  // the slice count whose total fills whole rounds of 512 best (36 pairs x 28 slices = 1008 at p = 1000), with
+  // slices of at least 256 rows and at most ~8 rounds
   const int np = n_pairs_of(p);
-  int64_t s = (1024 + np - 1) / np;
-  const int64_t max_s = (n + 63) / 64;
-  if (s > max_s) s = max_s;
-  if (s < 1) s = 1;
-  return (int)s;
+  const int64_t max_s = std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (8 * 512 + np - 1) / np));
+  int best = 1;
+  double best_eff = 0.0;
+  for (int64_t s = 1; s <= max_s; ++s) {
+    const int64_t total = (int64_t)np * s, rounds = (total + 511) / 512;
+    const double eff = (double)total / (double)(rounds * 512);
+    if (eff > best_eff + 1e-9) {
+      best_eff = eff;
+      best = (int)s;
+    }
+  }
+  return best;
 }
 
 hipError_t launch_gram(const GramArgs& a, hipStream_t st) {

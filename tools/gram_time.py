@@ -15,3 +15,16 @@ for rnd in range(4):
     eng.synchronize()
     print("gram (ms, launches)", eng.profile_read()["gram"])
 G = (Xa.T @ Xa / N).cpu().numpy(); print("max err", np.abs(eng.gram()[0] - G).max())
+
+# the C5 shape in float32 (p = 5000, 200000 rows)
+del Xa, Xe, ya, ye
+torch.cuda.empty_cache()
+p, N = 5000, 200000
+Xa = torch.randn(N, p, dtype=torch.float32, device=dev); ya = torch.randn(N, dtype=torch.float32, device=dev)
+torch.cuda.synchronize()
+for rnd in range(2):
+    eng.profile_reset()
+    eng.load_device_data(Xa.data_ptr(), p, ya.data_ptr(), N, Xa.data_ptr(), p, ya.data_ptr(), N, p, 0.01, f32=True)
+    eng.synchronize()
+    ms, cnt = eng.profile_read()["gram"]
+    print("C5 gram (ms, launches)", ms, cnt, "TFLOP/s per side", N * (p + 1) * (p + 2) / (ms / cnt * 1e-3) / 1e12)
