@@ -1797,8 +1797,11 @@ int lsspa_debug_factor(lsspa_ctx* ctx, const int32_t* perm, double* L, double* L
     const size_t rows = n_iblk * NB;
     std::vector<double> tmp(rows * ldv);
     TRY(fetch_elems(ctx, ctx->lanes[0].V.ptr, 0, rows * ldv, tmp.data()));
+    // tri: entries above a 128-column strip's first diagonal block are structurally zero and never written on the
+    // device (strip2_kernel)
     for (size_t r = 0; r < rows; ++r)
-      for (size_t c = 0; c < mp; ++c) V[r * mp + c] = tmp[r * ldv + c];
+      for (size_t c = 0; c < mp; ++c)
+        V[r * mp + c] = (ctx->tri && !(ctx->flags & 4) && r < (c / 128) * 128) ? 0.0 : tmp[r * ldv + c];
   }
   return LSSPA_OK;
 }

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256, 2) void kloop(const double* __restrict__ src, 
   for (int x = 0; x < 8; ++x) for (int y = 0; y < 2; ++y) { acc[x][y] = d4{0, 0, 0, 0}; for (int s = 0; s < 4; ++s) c4[x][y][s] = 0; }
   int bcol[4];
   for (int s = 0; s < 4; ++s) bcol[s] = 4 * ((((lane >> 2) & 3) + s) & 3) + (lane & 3);
-  const long long t0 = clock64();
+  const long long t0 = clock64(), w0 = wall_clock64();
   for (int c = 0; c < nch; ++c) {
     __syncthreads();
 #pragma unroll
@@ -69,11 +69,11 @@ __global__ __launch_bounds__(256, 2) void kloop(const double* __restrict__ src, 
       }
     }
   }
-  const long long t1 = clock64();
+  const long long t1 = clock64(), w1 = wall_clock64();
   double sum = 0;
   for (int x = 0; x < 8; ++x) for (int y = 0; y < 2; ++y) for (int s = 0; s < 4; ++s) sum += acc[x][y][s] + c4[x][y][s];
   out[(size_t)blockIdx.x * 256 + tid] = sum;
-  if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+  if (tid == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = w1 - w0; }
 }
 template <typename F> float timeit(F f) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -110,9 +110,12 @@ int main(int argc, char**) {
       if (m == 1) ms = timeit([&] { hipLaunchKernelGGL(kloop<1>, dim3(grid), dim3(256), 0, 0, src, out, nch, cyc); });
       if (m == 2) ms = timeit([&] { hipLaunchKernelGGL(kloop<2>, dim3(grid), dim3(256), 0, 0, src, out, nch, cyc); });
       if (m == 3) ms = timeit([&] { hipLaunchKernelGGL(kloop<3>, dim3(grid), dim3(256), 0, 0, src, out, nch, cyc); });
-      long long h = 0; (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
-      printf("%-18s %.3f ms  %.1f TFLOP/s  %.2f TB/s operand stream  (wg0 loop: %lld ticks)\n", names[m], ms,
-             flops / ms * 1e-9, (m < 2 ? bytes : 0.0) / ms * 1e-9, h);
+      long long h[2] = {0, 0}; (void)hipMemcpy(h, cyc, 16, hipMemcpyDeviceToHost);
+      // shader clock held inside the loop = shader-cycle counter / 100 MHz wall counter (MI355X_MICROARCH.md, DVFS item 6)
+      const double ghz = h[1] > 0 ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+      printf("%-18s %.3f ms  %.1f TFLOP/s  %.2f TB/s operand stream  (wg0 loop: %lld cycles, clock held %.2f GHz -> "
+             "peak at that clock %.1f TFLOP/s)\n", names[m], ms, flops / ms * 1e-9, (m < 2 ? bytes : 0.0) / ms * 1e-9,
+             h[0], ghz, 78.6 * ghz / 2.4);
     }
   return 0;
 }
