@@ -205,6 +205,7 @@ int lsspa_profile_reset(lsspa_ctx* ctx);
  *     4  one-level strip kernel (64-row steps)          8  one-level panel / diagonal kernels (64-wide panels)
  *    32  two half-batches on two streams               64  plain (matrix, tile) dispatch order in the panel kernel
  *   256  unpaired gather                              512  256-column strips (512-thread workgroups)
+ *  2048  no skipping of the all-padding 16 x 16 tiles in the panel / strip products
  *  1024  general path also for small problems (p + 1 <= 128 normally takes the fused one-workgroup kernel)
  * Every combination computes the same lifts (tests/test_gpu_kernels.py). */
 int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);

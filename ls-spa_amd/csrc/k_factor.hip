@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
                                                                  const double* __restrict__ diag0,
                                                                  double piv_tol, int32_t* __restrict__ info,
                                                                  int p_pad, int Jo, int nblk, int n_mats,
-                                                                 int grouped) {
+                                                                 int grouped, int p_live) {
   typedef typename Tr<T>::acc_t acc_t;
   typedef typename Tr<T>::vec_t vec_t;
   constexpr int VE = Tr<T>::VE;
@@ -1124,6 +1124,12 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
   T* M = A + (int64_t)mt * p_pad * p_pad;
   const int J0 = Jo * 128;
   const int I0 = J0 + 128 + tile * 128;
+  // Rows at or beyond p_live (= p + 1 rounded up to 16) are identity padding: left of the diagonal they are exact
+  // zeros before, during and after every update, so the 16-row accumulator tiles that consist of them only are
+  // left out of every product -- the same bits with fewer instructions (p = 1000 pads to 1024: 1 tile in 64;
+  // p = 5000 to 5120: 7 in 320).
+  const int ylive = min(YT, max(0, (p_live - (I0 + RW * w) + 15) / 16));   // live 16-row tiles of this wave
+  const int tlive = min(8, max(0, (p_live - I0 + 15) / 16));                // live 16-row tiles of the whole tile
 
   const T* srcJ = M + cm_off(p_pad, J0, 0);
   const T* srcI = M + cm_off(p_pad, I0, 0);
@@ -1187,9 +1193,11 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
 #pragma unroll
       for (int y = 0; y < YT; ++y) bv[y] = s_rki[(RW * w + 16 * y + l15) * RK_LD + 4 * kk + l4];
 #pragma unroll
-      for (int x = 0; x < 8; ++x)
+      for (int y = 0; y < YT; ++y)
+        if (y < ylive) {
 #pragma unroll
-        for (int y = 0; y < YT; ++y) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
+          for (int x = 0; x < 8; ++x) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
+        }
     }
   }
 
@@ -1199,6 +1207,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
   auto tri_mult = [&](const int half) {
 #pragma unroll
     for (int y = 0; y < YT; ++y) {
+      if (y >= ylive) continue;   // padding rows: the accumulators are and stay zero
       acc_t t[4];
 #pragma unroll
       for (int xp = 0; xp < 4; ++xp) t[xp] = Tr<T>::zero();
@@ -1239,7 +1248,8 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
       for (int r = 0; r < 4; ++r) {
         const T av = s_dinv[(16 * xp + l15) * DI_LD + 16 * x + Tr<T>::acc_row(l4, r)];
 #pragma unroll
-        for (int y = 0; y < YT; ++y) acc[4 + xp][y] = Tr<T>::mfma(av, acc[x][y][r], acc[4 + xp][y]);
+        for (int y = 0; y < YT; ++y)
+          if (y < ylive) acc[4 + xp][y] = Tr<T>::mfma(av, acc[x][y][r], acc[4 + xp][y]);
       }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -1302,7 +1312,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
       for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
         for (int q = 0; q < NU; ++q) {
-          if (ws + NW * q >= 36) continue;   // wave-uniform
+          if (ws + NW * q >= 36 || ti[q] >= tlive) continue;   // wave-uniform; padding rows add nothing
           const T av = s_out[(16 * ti[q] + l15) * RK_LD + 4 * kk + l4];
           const T bv = s_out[(16 * tj[q] + l15) * RK_LD + 4 * kk + l4];
           upd[q] = Tr<T>::mfma(av, bv, upd[q]);
@@ -1345,7 +1355,8 @@ hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double pi
 }
 
 hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
-                              int Jo, int n_mats, int f32, hipStream_t st, int flags) {
+                              int Jo, int n_mats, int f32, hipStream_t st, int flags, int p_live) {
+  if (p_live <= 0 || p_live > p_pad || (flags & 2048)) p_live = p_pad;   // flag 2048: no padding-tile skipping
   if (p_pad % 128 != 0 || Jo < 0 || Jo >= p_pad / 128 - 1 || n_mats < 1) return hipErrorInvalidValue;
   const int nblk = p_pad / NB;
   const int n_tiles = p_pad / 128 - 1 - Jo;
@@ -1355,10 +1366,10 @@ hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double p
   // slower in both precisions -- the epilogue is bound by its memory traffic, not by latency
   if (f32)
     hipLaunchKernelGGL((chol_panel2_kernel<float, 256>), grid, dim3(256), 0, st, (float*)A, (float*)Dinv, diag0,
-                       piv_tol, info, p_pad, Jo, nblk, n_mats, grouped);
+                       piv_tol, info, p_pad, Jo, nblk, n_mats, grouped, p_live);
   else
     hipLaunchKernelGGL((chol_panel2_kernel<double, 256>), grid, dim3(256), 0, st, (double*)A, (double*)Dinv,
-                       diag0, piv_tol, info, p_pad, Jo, nblk, n_mats, grouped);
+                       diag0, piv_tol, info, p_pad, Jo, nblk, n_mats, grouped, p_live);
   return hipGetLastError();
 }
 
@@ -1418,6 +1429,11 @@ __global__ __launch_bounds__(NT, 2) void strip2_kernel(StripArgs a) {
     for (int x = 0; x < 8; ++x)
 #pragma unroll
       for (int y = 0; y < 2; ++y) acc[x][y] = Tr<T>::zero();
+    // padding: rows at or beyond row_live (identity rows of L: zeros left of the diagonal) and columns at or beyond
+    // col_live (zero columns of the right-hand side, hence of V) only ever add exact zeros in the k-loop: the 16 x 16
+    // tiles made of them are left out of it
+    const int xlive = min(8, max(0, (a.row_live - I0 + 15) / 16));
+    const int ylive = min(2, max(0, (a.col_live - (c0 + 32 * w) + 15) / 16));
 
     const T* srcL = L + cm_off(p_pad, I0, kstart);
     const T* srcV = V + kstart * ldv + c0;
@@ -1450,8 +1466,11 @@ __global__ __launch_bounds__(NT, 2) void strip2_kernel(StripArgs a) {
         for (int y = 0; y < 2; ++y) bv[y] = s_kc[(4 * kk + l4) * KR::LD + 32 * w + 16 * y + l15];
 #pragma unroll
         for (int x = 0; x < 8; ++x)
+          if (x < xlive) {
 #pragma unroll
-          for (int y = 0; y < 2; ++y) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
+            for (int y = 0; y < 2; ++y)
+              if (y < ylive) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
+          }
       }
     }
 
@@ -1575,7 +1594,10 @@ __global__ __launch_bounds__(NT, 2) void strip2_kernel(StripArgs a) {
   }
 }
 
-hipError_t launch_strip(const StripArgs& a, hipStream_t st) {
+hipError_t launch_strip(const StripArgs& a_in, hipStream_t st) {
+  StripArgs a = a_in;
+  if (a.row_live <= 0 || a.row_live > a.p_pad || (a.flags & 2048)) a.row_live = a.p_pad;
+  if (a.col_live <= 0 || a.col_live > a.m_pad || (a.flags & 2048)) a.col_live = a.m_pad;
   if (a.p < 1 || a.p_pad % NB != 0 || a.m_pad % 128 != 0 || a.n_ord < 1) return hipErrorInvalidValue;
   if (a.tri && a.m_pad > a.p_pad + 127) return hipErrorInvalidValue;
   if (a.tri ? (a.rhs == nullptr) : (a.perms == nullptr || a.Ft == nullptr)) return hipErrorInvalidValue;

@@ -58,8 +58,10 @@ hipError_t launch_chol_diag(void* A, void* Dinv, const double* diag0, double piv
 // two-level scheme (128-wide panels, p_pad a multiple of 128): one diagonal launch, then Jo = 0 .. p_pad/128 - 2
 hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
                              int n_mats, int f32, hipStream_t st);
+// p_live: rows at or beyond it are identity padding (p + 1 rounded up to 16; 0 = none known): their all-zero
+// accumulator tiles are left out of the products
 hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
-                              int Jo, int n_mats, int f32, hipStream_t st, int flags = 0);
+                              int Jo, int n_mats, int f32, hipStream_t st, int flags = 0, int p_live = 0);
 hipError_t launch_chol_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
                              int J, int n_mats, int flags, int f32, hipStream_t st);
 
@@ -73,6 +75,8 @@ struct StripArgs {
   int p, p_pad, m_pad, n_ord, tri;
   int flags;               // developer A/B switches
   int f32;
+  int row_live = 0;        // rows at or beyond it are identity padding of L (p + 1 rounded up to 16; 0 = unknown)
+  int col_live = 0;        // columns at or beyond it are zero columns of the right-hand side (0 = unknown)
 };
 hipError_t launch_strip(const StripArgs& a, hipStream_t st);
 

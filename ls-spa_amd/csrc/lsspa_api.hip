@@ -524,7 +524,7 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
       {
         ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_PANEL, st);
         HIPCHK(launch_chol2_panel(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, Jo,
-                                  n_mats, ctx->f32, st, ctx->flags));
+                                  n_mats, ctx->f32, st, ctx->flags, round_up(p + 1, 16)));
       }
       // two lanes: the other lane's next batch may start once this one is about half done
       if (L.mid_armed && timed && Jo == n_panel / 2) {
@@ -562,6 +562,8 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
     sa.n_ord = n_ord;
     sa.tri = ctx->tri;
     sa.flags = ctx->flags;
+    sa.row_live = round_up(p + 1, 16);
+    sa.col_live = ctx->tri ? round_up(p + 1, 16) : round_up(ctx->m, 16);
     HIPCHK(launch_strip(sa, st));
   }
   {

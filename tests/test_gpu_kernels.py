@@ -261,20 +261,45 @@ def test_wide_strip_variant(engine, p, n, m):
 @pytest.mark.parametrize("p,n,m", [(100, 400, 300), (257, 900, 700), (70, 300, 40)])
 def test_two_level_kernels_agree_with_one_level_path(engine, p, n, m):
     """Two independent implementations of the factorisation and the solve live in the library: the two-level
-    kernels (default) and the one-level ones (developer flags 4 | 8 | 2048-free path).  Same inputs, same
+    kernels (default) and the one-level ones (developer flags 4 | 8).  Same inputs, same
     lifts to round-off; the paired / unpaired gather (flag 256) likewise."""
     Xa, Xe, ya, ye = problem(13, p, n, m)
     engine.load_data(Xa, Xe, ya, ye, 1e-3)
     rng = np.random.default_rng(8)
     perms = np.array([rng.permutation(p) for _ in range(6)])
-    base = engine.run_batch(perms, True, want_lifts=True, accumulate=False)
     try:
+        engine.set_flags(1024)            # 1024: the general path also where the fused small-p kernel would run
+        base = engine.run_batch(perms, True, want_lifts=True, accumulate=False)
         for flags in (4 | 8, 256, 4 | 8 | 256 | 2):
-            engine.set_flags(flags)
+            engine.set_flags(flags | 1024)
             other = engine.run_batch(perms, True, want_lifts=True, accumulate=False)
             np.testing.assert_allclose(other, base, rtol=0, atol=5e-13)
     finally:
         engine.set_flags(0)
+
+
+@pytest.mark.parametrize("p,n,m,prec", [(257, 900, 700, "float64"), (257, 900, 700, "float32"), (130, 500, 40, "float64"),
+                                        (1000, 3000, 2500, "float64")])
+def test_padding_tiles_are_skipped_without_a_trace(p, n, m, prec):
+    """Rows / columns beyond p + 1 (rounded up to 16) are identity padding up to the next multiple of 128; the panel
+    and strip products leave their all-zero 16 x 16 tiles out.  Developer flag 2048 computes them: the lift vectors
+    must agree bit for bit (the skipped products only ever add exact zeros), in both modes and precisions."""
+    from ls_spa._engine import HipEngine
+    Xa, Xe, ya, ye = problem(19, p, n, m)
+    rng = np.random.default_rng(10)
+    perms = np.array([rng.permutation(p) for _ in range(4)])
+    eng = HipEngine(0)
+    try:
+        eng.set_precision(prec)
+        eng.load_data(Xa, Xe, ya, ye, 1e-3)
+        eng.set_flags(1024)
+        skipping = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        eng.set_flags(1024 | 2048)
+        full = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        np.testing.assert_array_equal(skipping, full)
+        assert eng.info() == 0
+    finally:
+        eng.close()
 
 
 @pytest.mark.parametrize("anti", [False, True])
