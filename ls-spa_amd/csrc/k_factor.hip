@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
           const ST rv = rowbuf[sperm[min(j + e, i)]];
           v[e] = (j + e <= i) ? (T)rv : (T)0;
         }
-        *reinterpret_cast<vec_t*>(out + cm_off(p_pad, i, j)) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<vec_t*>(out + cm_off(p_pad, i, j)));
       }
       if (tid == 0) d0[i] = rowbuf[sperm[i]];
       if (PAIRED) {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
             const ST rv = rowbuf[sperm[p - 1 - min(j + e, i2)]];
             v[e] = (j + e <= i2) ? (T)rv : (T)0;
           }
-          *reinterpret_cast<vec_t*>(out2 + cm_off(p_pad, i2, j)) = v;
+          __builtin_nontemporal_store(v, reinterpret_cast<vec_t*>(out2 + cm_off(p_pad, i2, j)));
         }
         if (tid == 0) d02[i2] = rowbuf[sperm[i]];
       }

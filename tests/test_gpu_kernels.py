@@ -452,6 +452,10 @@ def test_driver_lookahead_on_the_device():
         b = ls_spa(*d, lookahead=4, **dict(kw, tolerance=tol))
         assert len(a.error_history) == len(b.error_history) == 3
         np.testing.assert_array_equal(b.attribution, a.attribution)
+    # attribution history: partial collects copy the chunk's lift vectors out
+    h1 = ls_spa(*d, return_attribution_history=True, **dict(kw, error_estimator="reference"))
+    h3 = ls_spa(*d, return_attribution_history=True, lookahead=3, **dict(kw, error_estimator="reference"))
+    np.testing.assert_array_equal(h3.attribution_history, h1.attribution_history)
     # also through the lanes: two batches in flight
     from ls_spa._engine import HipEngine
     eng = HipEngine(0)

@@ -436,3 +436,31 @@ def test_lookahead_keeps_the_reference_order(golden):
         assert e4.launched == 0 and e4.discarded == 0
     with pytest.raises(ValueError):
         ls_spa(*d, lookahead=0, _engine=OracleEngine())
+
+
+def test_lookahead_with_history_and_checkpoint(golden, tmp_path):
+    """lookahead composes with the other driver features: the attribution history is the one of lookahead=1, and a
+    run interrupted inside a group resumes (the orderings launched ahead are drawn again) to the same numbers."""
+    from oracle_engine import OracleEngine
+    g = golden("p12")
+    d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+    kw = dict(method="permutohedron", seed=9, max_samples=80, batch_size=16, tolerance=0.0, error_estimator="lowrank")
+    one = ls_spa(*d, return_attribution_history=True, _engine=OracleEngine(), **kw)
+    three = ls_spa(*d, return_attribution_history=True, lookahead=3, _engine=OracleEngine(), **kw)
+    np.testing.assert_array_equal(three.attribution_history, one.attribution_history)
+    np.testing.assert_array_equal(three.error_history, one.error_history)
+
+    class Dies(OracleEngine):
+        def collect_batch(self, *a, **k):
+            if len(self.calls) == 4:          # second chunk of the second group of three
+                raise KeyboardInterrupt
+            return super().collect_batch(*a, **k)
+
+    ck = str(tmp_path / "la.npz")
+    with pytest.raises(KeyboardInterrupt):
+        ls_spa(*d, checkpoint=ck, lookahead=3, _engine=Dies(), **kw)
+    with np.load(ck) as z:
+        assert int(z["n"]) == 64
+    resumed = ls_spa(*d, checkpoint=ck, lookahead=3, _engine=OracleEngine(), **kw)
+    np.testing.assert_allclose(resumed.attribution, one.attribution, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(resumed.error_history, one.error_history, rtol=1e-9)
