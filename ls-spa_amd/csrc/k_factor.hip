@@ -1157,8 +1157,8 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
       for (int xx = 0; xx < 2; ++xx)
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-          t[xx][q] = *reinterpret_cast<const vec_t*>(
-              M + cm_off(p_pad, I0 + RW * w + rr + RPI * q, J0 + 16 * (2 * xh + xx) + VE * ch));
+          t[xx][q] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(
+              M + cm_off(p_pad, I0 + RW * w + rr + RPI * q, J0 + 16 * (2 * xh + xx) + VE * ch)));
 #pragma unroll
       for (int xx = 0; xx < 2; ++xx) {
 #pragma unroll
@@ -1492,8 +1492,8 @@ __global__ __launch_bounds__(NT, 2) void strip2_kernel(StripArgs a) {
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int y = 0; y < 2; ++y)   // column clamped into the rows' own block: always inside the matrix
-              t[r][y] = Lt[cm_off(pp_e, I0 + 16 * x + Tr<T>::acc_row(l4, r),
-                                  min(c0 + 32 * w + 16 * y + l15, blk_end - 1))];
+              t[r][y] = __builtin_nontemporal_load(Lt + cm_off(pp_e, I0 + 16 * x + Tr<T>::acc_row(l4, r),
+                                                               min(c0 + 32 * w + 16 * y + l15, blk_end - 1)));
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void lift_partial_kernel(LiftArgs a) {
     // afterwards: a guarded load becomes a branch, and sixteen of them a latency chain
     T vraw[16];
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) vraw[jj] = V[(j0 + jj) * ldv + c];
+    for (int jj = 0; jj < 16; ++jj) vraw[jj] = __builtin_nontemporal_load(V + (j0 + jj) * ldv + c);
     const T zraw = L[cm_off(p_pad, p, min(j0 + r16, p - 1))];
     double v[16];
 #pragma unroll
