@@ -248,8 +248,11 @@ def test_full_size_properties(p, N):
         F = np.linalg.cholesky(H).T
         q = np.linalg.solve(R.T, g)
         qt = np.linalg.solve(F.T, h)
-        for o, got in zip(perms[:2], fwd[:2]):
-            np.testing.assert_allclose(got, O.ordering_lift(R, F, q, qt, eng.y_norm_sq, o), **LIFT_TOL)
+        # every one of the 16 orderings, and the antithetical pairs, against the oracle's QR-based algorithm
+        want = np.array([O.ordering_lift(R, F, q, qt, eng.y_norm_sq, o) for o in perms])
+        np.testing.assert_allclose(fwd, want, **LIFT_TOL)
+        want_rev = np.array([O.ordering_lift(R, F, q, qt, eng.y_norm_sq, o[::-1]) for o in perms[:4]])
+        np.testing.assert_allclose(anti[:4], 0.5 * (want[:4] + want_rev), **LIFT_TOL)
     finally:
         eng.close()
 
