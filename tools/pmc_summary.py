@@ -24,6 +24,9 @@ CLASS_OF = {"gather_kernel": "gather", "chol_diag2_kernel": "chol_diag", "chol_p
             "gram_kernel": "gram"}
 
 
+ONE_TIME = ("gram_kernel", "gram_reduce_kernel", "gram_finalize_kernel", "to_f32_kernel")   # per problem, not per step
+
+
 def short(name):
     return re.sub(r"[<(].*", "", name).replace("void ", "").replace("lsspa::", "")
 
@@ -52,13 +55,13 @@ def main():
         n = len(fetch[k])
         f_raw, w = sum(fetch[k]), sum(write.get(k, [0.0]))
         total = 2.0 * f_raw + w
-        rows.append((k, n, f_raw, 2.0 * f_raw, w, total / n, total / args.steps))
+        rows.append((k, n, f_raw, 2.0 * f_raw, w, total / n, 0.0 if k in ONE_TIME else total / args.steps))
         if k in CLASS_OF:
             per_class[CLASS_OF[k]] = total / n
     out_csv = os.path.join(ROOT, "profiles", f"r02_pmc_summary_{args.label}.csv")
     with open(out_csv, "w") as fh:
         fh.write("kernel,launches,FETCH_SIZE_bytes_raw,fetch_bytes_corrected_x2,WRITE_SIZE_bytes,"
-                 "bytes_per_launch,bytes_per_step\n")
+                 "bytes_per_launch,bytes_per_step (0 for the once-per-problem reduction kernels)\n")
         for r in rows:
             fh.write(",".join(str(x) for x in r) + "\n")
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
