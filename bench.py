@@ -503,8 +503,12 @@ def main():
                         cov_at_stop = eng.stats(want_cov=True)[2]
             except Exception as exc:   # a failing leg must not cost the throughput line
                 legs[name] = {"error": repr(exc)}
-        # the whole public call on the host arrays: reduction over PCIe included
+        # the whole public call on the host arrays: reduction over PCIe included.  One GPU (or the one-rank rehearsal)
+        # only: with several ranks every call would make its own communicator, and a rank that fails to while the
+        # others succeed would leave them waiting in a collective -- the sharded sampling loop above is the N > 1 figure
         try:
+            if world > 1:
+                raise RuntimeError("skipped with several ranks (see time_to_tolerance* for the sharded loop)")
             kw = dict(reg=reg, method="argsort", batch_size=B, num_batches=128, tolerance=1e-2, seed=42,
                       device=local, precision="float32" if args.dtype == "f32" else "float64")
             e2e = {}
