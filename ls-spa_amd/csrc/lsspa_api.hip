@@ -290,6 +290,7 @@ int set_dims(lsspa_ctx* ctx, int p, int m, int tri) {
   ctx->src_f32_valid = false;
   // a workspace sized for another shape is released now: kept, it would count as unavailable memory when the
   // new one is sized from hipMemGetInfo (and its layout depends on p_pad / m_pad / tri anyway)
+  for (Lane& L : ctx->lanes) L.in_flight = false;   // a batch launched on the previous problem is void
   if (p != ctx->p || m != ctx->m || tri != ctx->tri) {
     free_workspace(ctx);
     dev_free(ctx->Gf);
@@ -1749,7 +1750,9 @@ int lsspa_set_precision(lsspa_ctx* ctx, int32_t dtype) {
   if (dtype != LSSPA_F64 && dtype != LSSPA_F32) return ctx->fail(LSSPA_ERR_ARG, "dtype");
   HIPCHK(hipSetDevice(ctx->device));
   if ((dtype == LSSPA_F32) != (ctx->f32 != 0)) {
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (const Lane& L : ctx->lanes)
+      if (L.in_flight) return ctx->fail(LSSPA_ERR_STATE, "a launched batch is still to be collected");
+    TRY(sync_all(ctx));     // kernels on the lanes' streams still use the workspace that is about to go
     ctx->f32 = dtype == LSSPA_F32;
     free_workspace(ctx);   // re-created for the new element size on demand
   }
