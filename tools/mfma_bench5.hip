@@ -75,6 +75,59 @@ __global__ __launch_bounds__(256, 2) void kloop(const double* __restrict__ src, 
   out[(size_t)blockIdx.x * 256 + tid] = sum;
   if (tid == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = w1 - w0; }
 }
+// the same loop with double-buffered LDS: one barrier per chunk (loads of chunk c + 1 issued before the MFMAs of chunk c,
+// parked in the other buffer after them)
+__global__ __launch_bounds__(256, 2) void kloop_db(const double* __restrict__ src, double* out, int nch, long long* cyc) {
+  __shared__ __attribute__((aligned(16))) double s_a[2][128 * RK_LD];
+  __shared__ __attribute__((aligned(16))) double s_b[2][128 * RK_LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const double* pa = src + (size_t)blockIdx.x * 2 * nch * 2048;
+  const double* pb = pa + (size_t)nch * 2048;
+  const int c8 = tid & 7, row = tid >> 3;
+  v2d ra[4], rb[4];
+  auto load = [&](int c) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ra[q] = *reinterpret_cast<const v2d*>(pa + (size_t)c * 2048 + (row + 32 * q) * 16 + 2 * c8);
+      rb[q] = *reinterpret_cast<const v2d*>(pb + (size_t)c * 2048 + (row + 32 * q) * 16 + 2 * c8);
+    }
+  };
+  auto park = [&](int b) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<v2d*>(s_a[b] + (row + 32 * q) * RK_LD + 2 * c8) = ra[q];
+      *reinterpret_cast<v2d*>(s_b[b] + (row + 32 * q) * RK_LD + 2 * c8) = rb[q];
+    }
+  };
+  d4 acc[8][2];
+  for (int x = 0; x < 8; ++x) for (int y = 0; y < 2; ++y) acc[x][y] = d4{0, 0, 0, 0};
+  load(0); park(0);
+  __syncthreads();
+  const long long t0 = clock64(), w0 = wall_clock64();
+  for (int c = 0; c < nch; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nch) load(c + 1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double av[8], bv[2];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) av[x] = s_a[cur][(16 * x + l15) * RK_LD + 4 * kk + l4];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) bv[y] = s_b[cur][(32 * w + 16 * y + l15) * RK_LD + 4 * kk + l4];
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
+    }
+    if (c + 1 < nch) park(cur ^ 1);
+    __syncthreads();
+  }
+  const long long t1 = clock64(), w1 = wall_clock64();
+  double sum = 0;
+  for (int x = 0; x < 8; ++x) for (int y = 0; y < 2; ++y) for (int s = 0; s < 4; ++s) sum += acc[x][y][s];
+  out[(size_t)blockIdx.x * 256 + tid] = sum;
+  if (tid == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = w1 - w0; }
+}
 template <typename F> float timeit(F f) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   f(); (void)hipDeviceSynchronize();
@@ -102,19 +155,20 @@ int main(int argc, char**) {
   (void)hipMalloc(&out, (size_t)grid * 256 * 8); (void)hipMalloc(&cyc, 64);
   const double flops = (double)grid * nch * 128.0 * 128 * 16 * 2;
   const double bytes = (double)grid * nch * 2 * 2048 * 8;
-  const char* names[4] = {"16x16x4 + HBM", "4x4x4   + HBM", "16x16x4 no loads", "4x4x4   no loads"};
+  const char* names[5] = {"16x16x4 + HBM", "4x4x4   + HBM", "16x16x4 no loads", "4x4x4   no loads", "16x16x4 + HBM, 2 LDS buffers"};
   for (int rep = 0; rep < 2; ++rep)
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < 5; ++m) {
       float ms = 0;
       if (m == 0) ms = timeit([&] { hipLaunchKernelGGL(kloop<0>, dim3(grid), dim3(256), 0, 0, src, out, nch, cyc); });
       if (m == 1) ms = timeit([&] { hipLaunchKernelGGL(kloop<1>, dim3(grid), dim3(256), 0, 0, src, out, nch, cyc); });
       if (m == 2) ms = timeit([&] { hipLaunchKernelGGL(kloop<2>, dim3(grid), dim3(256), 0, 0, src, out, nch, cyc); });
       if (m == 3) ms = timeit([&] { hipLaunchKernelGGL(kloop<3>, dim3(grid), dim3(256), 0, 0, src, out, nch, cyc); });
+      if (m == 4) ms = timeit([&] { hipLaunchKernelGGL(kloop_db, dim3(grid), dim3(256), 0, 0, src, out, nch, cyc); });
       long long h[2] = {0, 0}; (void)hipMemcpy(h, cyc, 16, hipMemcpyDeviceToHost);
       // shader clock held inside the loop = shader-cycle counter / 100 MHz wall counter (MI355X_MICROARCH.md, DVFS item 6)
       const double ghz = h[1] > 0 ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
       printf("%-18s %.3f ms  %.1f TFLOP/s  %.2f TB/s operand stream  (wg0 loop: %lld cycles, clock held %.2f GHz -> "
-             "peak at that clock %.1f TFLOP/s)\n", names[m], ms, flops / ms * 1e-9, (m < 2 ? bytes : 0.0) / ms * 1e-9,
+             "peak at that clock %.1f TFLOP/s)\n", names[m], ms, flops / ms * 1e-9, ((m < 2 || m == 4) ? bytes : 0.0) / ms * 1e-9,
              h[0], ghz, 78.6 * ghz / 2.4);
     }
   return 0;
