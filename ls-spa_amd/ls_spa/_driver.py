@@ -272,6 +272,11 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
     # rule fires, the chunks launched beyond it are dropped: nothing of them ever reaches the statistics.  The next
     # group is launched BEFORE the rule is evaluated on the last chunk of the current one, so the GPU works while
     # the collective, the host's estimate and the decision run.
+    if lookahead == "auto":
+        # automatic: a chunk of fewer than 64 samples per rank leaves most of an MI355X idle (§6 of DESIGN.md) --
+        # launch as many chunks together as make up 64, eight at most
+        per_rank = -(-int(batch_size) // comm.world)
+        lookahead = max(1, min(8, 64 // max(per_rank, 1)))
     group = max(1, int(lookahead)) if (hasattr(engine, "launch_batch") and source.independent and not chunk_cap) else 1
     queue = []
 
@@ -390,7 +395,8 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
     lookahead:  QMC samplers ('argsort', 'permutohedron') only.  k > 1 launches the orderings of k chunks as one GPU
         batch (a chunk of batch_size / n_gpus samples may fill a fraction of the GPU), accumulates and checks them
         chunk by chunk in the reference's order and drops the chunks beyond a stop.  Same results; at most k - 1
-        chunks of wasted work at the end of a run.
+        chunks of wasted work at the end of a run.  'auto': 1 when a rank's chunk has 64 samples or more, else as
+        many chunks as make up 64 samples, eight at most.  Default 1 (every chunk its own launch).
     comm:  several GPUs, one process each: the communicator every rank passes -- ``NativeComm.from_env()``
         (RCCL through the C ABI, no PyTorch) or ``TorchComm()`` (torch.distributed: RCCL, or gloo on CPU in
         the tests).  The orderings of every chunk are dealt round-robin over the ranks; the only data-path
@@ -426,8 +432,8 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
             comm.bind(engine)      # RCCL communicator on this engine's GPU and stream (collective)
         if precision != "float64" or getattr(engine, "precision", "float64") != "float64":
             engine.set_precision(precision)
-        if int(lookahead) < 1:
-            raise ValueError("lookahead must be >= 1")
+        if lookahead != "auto" and int(lookahead) < 1:
+            raise ValueError("lookahead must be >= 1 or 'auto'")
         prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
                                     antithetical=antithetical, method=method)
         if row_sharded:

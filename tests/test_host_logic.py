@@ -436,6 +436,13 @@ def test_lookahead_keeps_the_reference_order(golden):
         assert e4.launched == 0 and e4.discarded == 0
     with pytest.raises(ValueError):
         ls_spa(*d, lookahead=0, _engine=OracleEngine())
+    # 'auto': chunks of 16 samples are launched four at a time (64 samples), chunks of 64 and more one at a time
+    ea, eb = OracleEngine(), OracleEngine()
+    auto = ls_spa(*d, method="argsort", seed=5, max_samples=96, batch_size=16, tolerance=0.0, lookahead="auto", _engine=ea)
+    np.testing.assert_array_equal(auto.attribution, first.attribution)
+    assert ea.launched == 2                       # 7 chunks in groups of 4 and 3
+    ls_spa(*d, method="argsort", seed=5, max_samples=128, batch_size=64, tolerance=0.0, lookahead="auto", _engine=eb)
+    assert eb.launched == 0
 
 
 def test_lookahead_with_history_and_checkpoint(golden, tmp_path):
