@@ -998,9 +998,13 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
     if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_NOMEM, "streamed reduction buffers", e);
   }
   if (rc == LSSPA_OK) {
-    // pin the caller's arrays in place; harmless if refused (the copies then stage through the runtime)
-    reg_x = hipHostRegister(const_cast<void*>(X), (size_t)n * ld * es, hipHostRegisterDefault) == hipSuccess;
-    reg_y = hipHostRegister(const_cast<void*>(y), (size_t)n * es, hipHostRegisterDefault) == hipSuccess;
+    // pin the caller's arrays in place when that pays: from 8 MB on the copies then are true DMA at PCIe rate;
+    // below, the runtime's staged copy is as fast, and a small heap block shares its pages with unrelated
+    // allocations that have no business being locked.  Harmless if refused.
+    constexpr size_t PIN_FROM = (size_t)8 << 20;
+    const size_t bx = (size_t)n * ld * es, by = (size_t)n * es;
+    reg_x = bx >= PIN_FROM && hipHostRegister(const_cast<void*>(X), bx, hipHostRegisterDefault) == hipSuccess;
+    reg_y = by >= PIN_FROM && hipHostRegister(const_cast<void*>(y), by, hipHostRegisterDefault) == hipSuccess;
     (void)hipGetLastError();
     ProfScope ps(ctx, LSSPA_K_GRAM);
     int k = 0;
