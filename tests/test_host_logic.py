@@ -471,3 +471,30 @@ def test_lookahead_with_history_and_checkpoint(golden, tmp_path):
     resumed = ls_spa(*d, checkpoint=ck, lookahead=3, _engine=OracleEngine(), **kw)
     np.testing.assert_allclose(resumed.attribution, one.attribution, rtol=0, atol=1e-14)
     np.testing.assert_allclose(resumed.error_history, one.error_history, rtol=1e-9)
+
+
+def test_bench_helpers_follow_the_baseline_recipe():
+    """bench.py's data generator is BASELINE.md section 3's (the same stream as the oracle's / the product's Gaussian
+    workload, whatever the row blocking), its config labels are BASELINE.json's, and the algorithmic flop counts
+    are SURVEY.md 8d's."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    got = bench.baseline_data(7, 50, "f64")
+    import lsspa_oracle as O
+    want = O.gaussian_workload(7, 50, 50, seed=0)
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-13)      # y = X theta + noise: same draws, same order
+    np.testing.assert_array_equal(got[0], want[0])
+    f32 = bench.baseline_data(7, 50, "f32")
+    assert all(a.dtype == np.float32 for a in f32)
+    np.testing.assert_array_equal(f32[0], want[0].astype(np.float32))
+    assert bench.config_label(100, 10000, "f64") == "C2" and bench.config_label(1000, 100000, "f64") == "C3"
+    assert bench.config_label(5000, 200000, "f32") == "C5" and bench.config_label(1000, 100000, "f32") == "custom"
+    p, n_ord = 1000, 256
+    assert bench.algorithmic_flops("strip", p, n_ord, True, 1) == pytest.approx(p ** 3 / 3 * n_ord)
+    assert bench.algorithmic_flops("chol_panel", p, n_ord, True, 7) == pytest.approx(p ** 3 / 3 * 2 * n_ord / 7)
+    assert bench.algorithmic_flops("small_p", 100, n_ord, True, 1) == pytest.approx(100 ** 3 * n_ord)
