@@ -1128,7 +1128,12 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
   // zeros before, during and after every update, so the 16-row accumulator tiles that consist of them only are
   // left out of every product -- the same bits with fewer instructions (p = 1000 pads to 1024: 1 tile in 64;
   // p = 5000 to 5120: 7 in 320).
-  const int ylive = min(YT, max(0, (p_live - (I0 + RW * w) + 15) / 16));   // live 16-row tiles of this wave
+  // Both counts are wave-uniform, and the compiler has to know it (the wave index comes out of threadIdx): a
+  // condition it takes for divergent turns every product it guards into an exec-masked region of its own; as
+  // scalars they are plain branches (measured: 4.08 -> 4.04 ms of panel time per C3 step).  A condition-free copy
+  // of the k-loop for full tiles was measured too: no faster (it costs registers the epilogue then spills).
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+  const int ylive = min(YT, max(0, (p_live - (I0 + RW * ws) + 15) / 16));   // live 16-row tiles of this wave
   const int tlive = min(8, max(0, (p_live - I0 + 15) / 16));                // live 16-row tiles of the whole tile
 
   const T* srcJ = M + cm_off(p_pad, J0, 0);
@@ -1286,7 +1291,6 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
   __threadfence_block();
   acc_t upd[NU];
   int ti[NU], tj[NU];
-  const int ws = __builtin_amdgcn_readfirstlane(w);
 #pragma unroll
   for (int q = 0; q < NU; ++q) {
     const int t = ws + NW * q;
@@ -1329,6 +1333,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
       if (col <= row) M[cm_off(p_pad, I0 + row, I0 + col)] = -upd[q][r];
     }
   }
+
 
   // Tile 0 is the next panel's diagonal block and has just received its last update: factor it here,
   // the latency-bound sweep overlaps with the other workgroups' MFMA work.
@@ -1383,8 +1388,10 @@ hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double p
 // =====================================================================================
 // NT threads = NT / 64 waves, each owning 32 columns: the strip is CW = NT / 2 columns wide.  The wider
 // strip (NT = 512) reads L half as often; the accumulators per wave, and so the waves per SIMD, are the same.
-template <typename T, int NT>
-__global__ __launch_bounds__(NT, 2) void strip2_kernel(StripArgs a) {
+// fp32, 256 threads: capped at 168 registers (172 otherwise) for a third workgroup per CU -- 105.9 -> 101.6 ms at the
+// C5 shape; fp64 needs all 256 registers for its accumulators and stays at two.
+template <typename T, int NT, int OCC = (sizeof(T) == 4 && NT == 256) ? 3 : 2>
+__global__ __launch_bounds__(NT, OCC) void strip2_kernel(StripArgs a) {
   constexpr int CW = NT / 2;
   typedef KCWRegs<T, CW, NT> KR;
   typedef typename Tr<T>::acc_t acc_t;
@@ -1394,6 +1401,7 @@ __global__ __launch_bounds__(NT, 2) void strip2_kernel(StripArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
+  const int ws = __builtin_amdgcn_readfirstlane(w);   // the wave index as the scalar it is
   const int ord = blockIdx.x;
   const int c0 = blockIdx.y * CW;
   const int cols_valid = min(CW, a.m_pad - c0);   // the last strip of a wide layout may be half empty
@@ -1419,11 +1427,6 @@ __global__ __launch_bounds__(NT, 2) void strip2_kernel(StripArgs a) {
   for (int ib = ib0; ib < n_iblk; ib += 2) {
     const int I0 = ib * NB;
     const bool two = ib + 1 < n_iblk;          // the last step of an odd block count has one half
-    // Strides re-materialised per step: otherwise every row address of the epilogue (32 of them, 64 bit)
-    // is hoisted out of this loop and carried -- spilled -- through the k-loop.
-    int64_t ldv_e = ldv;
-    int pp_e = p_pad;
-    asm volatile("" : "+s"(ldv_e), "+s"(pp_e));
     acc_t acc[8][2];
 #pragma unroll
     for (int x = 0; x < 8; ++x)
@@ -1433,7 +1436,7 @@ __global__ __launch_bounds__(NT, 2) void strip2_kernel(StripArgs a) {
     // col_live (zero columns of the right-hand side, hence of V) only ever add exact zeros in the k-loop: the 16 x 16
     // tiles made of them are left out of it
     const int xlive = min(8, max(0, (a.row_live - I0 + 15) / 16));
-    const int ylive = min(2, max(0, (a.col_live - (c0 + 32 * w) + 15) / 16));
+    const int ylive = min(2, max(0, (a.col_live - (c0 + 32 * ws) + 15) / 16));   // wave-uniform, and known to be
 
     const T* srcL = L + cm_off(p_pad, I0, kstart);
     const T* srcV = V + kstart * ldv + c0;
@@ -1456,7 +1459,7 @@ __global__ __launch_bounds__(NT, 2) void strip2_kernel(StripArgs a) {
         kcw_load<T, CW, NT>(rv, srcV + (c + 1) * KCH * ldv, ldv, tid, cols_valid);
       }
       // tri: V[k][col] = 0 for col > k: wave w (columns c0 + 32 w ..) sees only zeros while k < c0 + 32 w
-      if (a.tri && c < 2 * w) continue;
+      if (a.tri && c < 2 * ws) continue;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         T av[8], bv[2];
@@ -1473,6 +1476,12 @@ __global__ __launch_bounds__(NT, 2) void strip2_kernel(StripArgs a) {
           }
       }
     }
+
+    // Strides re-materialised AFTER the k-loop: otherwise every row address of the epilogue (32 of them, 64 bit)
+    // is computed ahead of the k-loop and carried -- spilled -- through it.
+    int64_t ldv_e = ldv;
+    int pp_e = p_pad;
+    asm volatile("" : "+s"(ldv_e), "+s"(pp_e));
 
     __syncthreads();  // s_dinv is still being read by slower waves of the previous step
     load_block64<T, NT>(s_dinv, Dv + (int64_t)ib * 4096, tid);
