@@ -686,11 +686,17 @@ __device__ __forceinline__ void load_block64_cm(T* lds, const T* __restrict__ A,
 //        A22 -= L21 L21^T on the matrix pipe; L22, L22^-1 by the elimination again.
 // Half as many dependent launches as the one-level scheme, two thirds of its operand traffic.
 // =====================================================================================
-// lower tiles (ti >= tj) of the 8 x 8 grid of 16 x 16 tiles of a 128 x 128 block; wave w owns 9 of them
-__constant__ unsigned char kSyrkTi[36] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5,
-                                          5, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7, 7};
-__constant__ unsigned char kSyrkTj[36] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2,
-                                          3, 4, 5, 0, 1, 2, 3, 4, 5, 6, 0, 1, 2, 3, 4, 5, 6, 7};
+// lower tiles (ti >= tj) of the 8 x 8 grid of 16 x 16 tiles of a 128 x 128 block, row by row; wave w owns 9 of them.
+// The (ti, tj) of tile t come out of two packed constants (3 bits an entry) with scalar shifts: as a table in
+// constant memory every lookup was a memory load whose wait also drained the loads issued before it -- nine
+// dependent round trips in front of the diagonal update of every panel tile.
+__device__ __forceinline__ void syrk_tile(int t, int& ti, int& tj) {
+  constexpr unsigned long long TI_LO = 0x5b6db2491b6d2448ull, TI_HI = 0x1ffffffb6db6ull;   // entries 0..20, 21..35
+  constexpr unsigned long long TJ_LO = 0x58d111a21a211040ull, TJ_HI = 0x1f58d11ac688ull;
+  const int sh = 3 * (t < 21 ? t : t - 21);
+  ti = (int)(((t < 21 ? TI_LO : TI_HI) >> sh) & 7);
+  tj = (int)(((t < 21 ? TJ_LO : TJ_HI) >> sh) & 7);
+}
 
 // acc[4 h + xp][y] <- sign * sum_{x <= xp} D[xp][x] acc[4 h + x][y]  (D lower triangular, 64 x 64 in LDS),
 // one column tile y at a time so that only four extra tiles are live
@@ -895,7 +901,7 @@ template <typename T, int NT>
 __device__ __forceinline__ void factor_block64_core(T* __restrict__ M, int p_pad, int r0, T* __restrict__ Dg,
                                                     const double* __restrict__ diag0, double piv_tol,
                                                     int32_t* __restrict__ info, T* s_t, T* s_x, int tid) {
-  const int lane = tid & 63, w = tid >> 6;
+  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave index as the scalar it is
   T* const s_dd = s_x + 4 * 16 * XD_LD;
   int bad = 0;
 #pragma unroll 1
@@ -982,7 +988,7 @@ __device__ __forceinline__ void factor_diag128(T* __restrict__ M, int p_pad, int
                                                int32_t* __restrict__ info, T* s_a, T* s_x, int tid) {
   static_assert(NT == 256, "four waves");
   typedef typename Tr<T>::acc_t acc_t;
-  const int lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, l4 = lane >> 4;
   // A21 tile of wave w: rows i = 16 w + l15, loaded as (k = 16 x + acc_row, i) = the B operand of L11^-1 A21^T
   acc_t c[4], o[4];
 #pragma unroll
@@ -1034,7 +1040,8 @@ __device__ __forceinline__ void factor_diag128(T* __restrict__ M, int p_pad, int
     const int t = w + 4 * q;
     u[q] = Tr<T>::zero();
     if (t < 10) {
-      const int ti = kSyrkTi[t], tj = kSyrkTj[t];
+      int ti, tj;
+      syrk_tile(t, ti, tj);
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk)
         u[q] = Tr<T>::mfma(s_a[(16 * ti + l15) * DI_LD + 4 * kk + l4], s_a[(16 * tj + l15) * DI_LD + 4 * kk + l4],
@@ -1049,7 +1056,8 @@ __device__ __forceinline__ void factor_diag128(T* __restrict__ M, int p_pad, int
   for (int q = 0; q < 3; ++q) {
     const int t = w + 4 * q;
     if (t < 10) {
-      const int ti = kSyrkTi[t], tj = kSyrkTj[t];
+      int ti, tj;
+      syrk_tile(t, ti, tj);
 #pragma unroll
       for (int r = 0; r < 4; ++r) s_a[(16 * ti + Tr<T>::acc_row(l4, r)) * DI_LD + 16 * tj + l15] -= u[q][r];
     }
@@ -1294,8 +1302,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
 #pragma unroll
   for (int q = 0; q < NU; ++q) {
     const int t = ws + NW * q;
-    ti[q] = t < 36 ? kSyrkTi[t] : 0;
-    tj[q] = t < 36 ? kSyrkTj[t] : 0;
+    syrk_tile(t < 36 ? t : 0, ti[q], tj[q]);
     // start from -A[I,I] (unconditional loads: the block's upper triangle exists, its content is never stored):
     // the reads are in flight under the re-staging loop instead of being a dependent read-modify-write at the end
 #pragma unroll

@@ -28,20 +28,15 @@ struct ZRegs {
   vec_t v[NP];
 };
 
-// Column class of a thread's vector inside its tile (loop invariant): 0 = all VE columns are features (plain
-// vector load), 1 = the vector touches column p (= y) or the end of the features (element-wise), 2 = padding (zeros).
-template <typename T>
-__device__ __forceinline__ int zcol_mode(int col0, int p) {
-  constexpr int VE = ZRegs<T>::VE;
-  if (col0 + VE <= p) return 0;
-  return col0 <= p ? 1 : 2;
-}
-
-// FULL: the tile lies inside the features and the 16 rows exist -- no guards at all.  Otherwise rows at or beyond
-// r_hi and columns beyond y read as zero; addresses stay inside the arrays (clamped rows, per-element columns).
+// FULL: the tile lies inside the features and the 16 rows exist -- no guards at all, 16-byte loads.
+// Otherwise (ragged last tile, y column, last rows of a slice): element loads, every one of them unconditional --
+// the row is clamped into the slice, the column's source is chosen by an address select (a feature column of X, or
+// y for column p and, harmlessly, beyond) -- and the values that must read as zero are cleared by zmask() AFTER the
+// products the loads run under.  A guarded load or a select right behind the load would put a wait for the loads
+// in front of those products.
 template <typename T, bool FULL>
 __device__ __forceinline__ void zload(ZRegs<T>& r, const T* __restrict__ X, const T* __restrict__ y, int64_t ld,
-                                      int p, int col_tile0, int64_t row0, int64_t r_hi, int tid, int mode) {
+                                      int p, int col_tile0, int64_t row0, int64_t r_hi, int tid) {
   typedef ZRegs<T> R;
   const int vc = tid % R::VPR, k0 = tid / R::VPR;
   const int col0 = col_tile0 + R::VE * vc;
@@ -53,26 +48,29 @@ __device__ __forceinline__ void zload(ZRegs<T>& r, const T* __restrict__ X, cons
     } else {
       const int64_t rc = row < r_hi ? row : r_hi - 1;
       typename R::vec_t v;
-      if (mode == 0) {
-        v = *reinterpret_cast<const typename R::gvec_t*>(X + rc * ld + col0);
-      } else {
 #pragma unroll
-        for (int e = 0; e < R::VE; ++e) {
-          const int c = col0 + e;
-          T val = (T)0;
-          if (mode == 1) {
-            if (c < p) val = X[rc * ld + c];
-            else if (c == p) val = y[rc];
-          }
-          v[e] = val;
-        }
-      }
-      if (row >= r_hi) {
-#pragma unroll
-        for (int e = 0; e < R::VE; ++e) v[e] = (T)0;
+      for (int e = 0; e < R::VE; ++e) {
+        const int c = col0 + e;
+        const T* src = (c < p) ? X + rc * ld + c : y + rc;
+        v[e] = *src;
       }
       r.v[q] = v;
     }
+  }
+}
+
+// the zeros of a guarded chunk: columns beyond y, rows at or beyond r_hi
+template <typename T>
+__device__ __forceinline__ void zmask(ZRegs<T>& r, int p, int col_tile0, int64_t row0, int64_t r_hi, int tid) {
+  typedef ZRegs<T> R;
+  const int vc = tid % R::VPR, k0 = tid / R::VPR;
+  const int col0 = col_tile0 + R::VE * vc;
+#pragma unroll
+  for (int q = 0; q < R::NP; ++q) {
+    const bool row_ok = row0 + k0 + R::RPP * q < r_hi;
+#pragma unroll
+    for (int e = 0; e < R::VE; ++e)
+      if (!(row_ok && col0 + e <= p)) r.v[q][e] = (T)0;
   }
 }
 
@@ -115,9 +113,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const T* __restrict__ X, c
   const int64_t r_lo = (int64_t)blockIdx.y * rows_per_split;
   const int64_t r_hi = (r_lo + rows_per_split < n) ? r_lo + rows_per_split : n;
   const int wi = w >> 1, wj = w & 1;  // wave quadrant: rows 64 wi .., cols 64 wj ..
-  const bool full_i = ci0 + 128 <= p, full_j = cj0 + 128 <= p;     // tile j <= tile i: full_i implies full_j
-  const int mode_i = zcol_mode<T>(ci0 + ZRegs<T>::VE * (tid % ZRegs<T>::VPR), p);
-  const int mode_j = zcol_mode<T>(cj0 + ZRegs<T>::VE * (tid % ZRegs<T>::VPR), p);
+  const bool full_i = ci0 + 128 <= p;     // tile j <= tile i: full_i implies that tile j is full too
 
   d4 acc[4][4];
 #pragma unroll
@@ -129,28 +125,22 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const T* __restrict__ X, c
   const int n_chunks = (int)((n_rows + 15) / 16);
   const int n_full = (int)(n_rows / 16);                           // chunks whose 16 rows all exist
   ZRegs<T> ri, rj;
-  auto fetch = [&](int c) {
+  auto fetch_full = [&](int c) {      // a chunk whose 16 rows exist, of tiles inside the features: no guards
     const int64_t row0 = r_lo + (int64_t)c * 16;
-    if (c < n_full && full_i) {       // wave-uniform
-      zload<T, true>(ri, X, y, ld, p, ci0, row0, r_hi, tid, 0);
-      if (!diag) zload<T, true>(rj, X, y, ld, p, cj0, row0, r_hi, tid, 0);
-    } else {
-      zload<T, false>(ri, X, y, ld, p, ci0, row0, r_hi, tid, mode_i);
-      if (!diag) {
-        if (c < n_full && full_j) zload<T, true>(rj, X, y, ld, p, cj0, row0, r_hi, tid, 0);
-        else zload<T, false>(rj, X, y, ld, p, cj0, row0, r_hi, tid, mode_j);
-      }
-    }
+    zload<T, true>(ri, X, y, ld, p, ci0, row0, r_hi, tid);
+    if (!diag) zload<T, true>(rj, X, y, ld, p, cj0, row0, r_hi, tid);
   };
-  if (n_chunks > 0) {
-    fetch(0);
-    zstore<T>(ri, s_i[0], tid);
-    if (!diag) zstore<T>(rj, s_j[0], tid);
-  }
-  __syncthreads();
-  for (int c = 0; c < n_chunks; ++c) {
-    const int cur = c & 1;
-    if (c + 1 < n_chunks) fetch(c + 1);
+  auto fetch_guarded = [&](int c) {   // raw values; mask_guarded(c) clears what must read as zero
+    const int64_t row0 = r_lo + (int64_t)c * 16;
+    zload<T, false>(ri, X, y, ld, p, ci0, row0, r_hi, tid);
+    if (!diag) zload<T, false>(rj, X, y, ld, p, cj0, row0, r_hi, tid);
+  };
+  auto mask_guarded = [&](int c) {
+    const int64_t row0 = r_lo + (int64_t)c * 16;
+    zmask<T>(ri, p, ci0, row0, r_hi, tid);
+    if (!diag) zmask<T>(rj, p, cj0, row0, r_hi, tid);
+  };
+  auto products = [&](int cur) {
     const double* si = s_i[cur];
     const double* sj = diag ? s_i[cur] : s_j[cur];
     // diagonal pair: only the lower triangle of the tile is ever read (gram_finalize symmetrises from it), so the
@@ -158,21 +148,50 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const T* __restrict__ X, c
     // co-resident workgroup
     if (!(diag && wi < wj)) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      double av[4], bv[4];
+      for (int kk = 0; kk < 4; ++kk) {
+        double av[4], bv[4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) av[x] = si[(4 * kk + l4) * KC_LD + 64 * wi + 16 * x + l15];
+        for (int x = 0; x < 4; ++x) av[x] = si[(4 * kk + l4) * KC_LD + 64 * wi + 16 * x + l15];
 #pragma unroll
-      for (int yv = 0; yv < 4; ++yv) bv[yv] = sj[(4 * kk + l4) * KC_LD + 64 * wj + 16 * yv + l15];
+        for (int yv = 0; yv < 4; ++yv) bv[yv] = sj[(4 * kk + l4) * KC_LD + 64 * wj + 16 * yv + l15];
 #pragma unroll
-      for (int x = 0; x < 4; ++x)
+        for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int yv = 0; yv < 4; ++yv) acc[x][yv] = mfma(av[x], bv[yv], acc[x][yv]);
+          for (int yv = 0; yv < 4; ++yv) acc[x][yv] = mfma(av[x], bv[yv], acc[x][yv]);
+      }
     }
+  };
+  auto park = [&](int buf) {
+    zstore<T>(ri, s_i[buf], tid);
+    if (!diag) zstore<T>(rj, s_j[buf], tid);
+  };
+  // Chunks [0, c_split) prefetch a chunk of the guard-free kind, the rest one of the guarded kind: TWO loops, each
+  // with one kind of load.  (One loop choosing the kind per chunk made the compiler merge the loaded registers of
+  // the two kinds after the choice -- a full wait for the loads BEFORE the products they were meant to run under.)
+  const int c_split = (full_i && n_full > 1) ? n_full - 1 : 0;
+  if (n_chunks > 0) {
+    if (full_i && n_full > 0) {
+      fetch_full(0);
+    } else {
+      fetch_guarded(0);
+      mask_guarded(0);
     }
-    if (c + 1 < n_chunks) {
-      zstore<T>(ri, s_i[cur ^ 1], tid);
-      if (!diag) zstore<T>(rj, s_j[cur ^ 1], tid);
+    park(0);
+  }
+  __syncthreads();
+  for (int c = 0; c < c_split; ++c) {
+    fetch_full(c + 1);
+    products(c & 1);
+    park((c & 1) ^ 1);
+    __syncthreads();
+  }
+  for (int c = c_split; c < n_chunks; ++c) {
+    const bool more = c + 1 < n_chunks;
+    if (more) fetch_guarded(c + 1);
+    products(c & 1);
+    if (more) {
+      mask_guarded(c + 1);
+      park((c & 1) ^ 1);
     }
     __syncthreads();
   }
