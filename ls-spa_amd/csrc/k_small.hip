@@ -139,7 +139,9 @@ __global__ __launch_bounds__(512) void small_p_kernel(SmallArgs a) {
   int32_t* const s_perm = reinterpret_cast<int32_t*>(s_y + 128);   // [128]
   __shared__ int s_bad;
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave index as the scalar it is: the phase
+                                                             // structure below branches on it all the time
   const int half = wv >> 2, w = wv & 3, t2 = tid & 255;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int ord = blockIdx.x;
