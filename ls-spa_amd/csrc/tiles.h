@@ -205,9 +205,14 @@ __device__ __forceinline__ void kcw_load(KCWRegs<T, CW, NT>& r, const T* __restr
   typedef KCWRegs<T, CW, NT> KR;
   const int c = tid % KR::VPR, k = tid / KR::VPR;
   const int cc = (Tr<T>::VE * c < cols_valid) ? Tr<T>::VE * c : 0;
+  // one 32-bit per-thread offset for all passes; the pass's row step is uniform and goes into the scalar base --
+  // the 64-bit address of every pass kept per thread was four register pairs carried (spilled) through the kernel
+  const unsigned toff = (unsigned)(k * (int)ld + cc);
 #pragma unroll
-  for (int q = 0; q < KR::NP; ++q)
-    r.v[q] = *reinterpret_cast<const typename Tr<T>::vec_t*>(src + (int64_t)(k + KR::RPP * q) * ld + cc);
+  for (int q = 0; q < KR::NP; ++q) {
+    const T* row = src + (int64_t)(KR::RPP * q) * ld;
+    r.v[q] = *reinterpret_cast<const typename Tr<T>::vec_t*>(row + toff);
+  }
 }
 
 template <typename T, int CW, int NT>
