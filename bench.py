@@ -431,9 +431,10 @@ def main():
                     "unit": "TFLOP/s", "frac": ach / peak_tf, "traffic": traffic,
                     "algorithmic_flops_per_launch": flops, "avg_launch_ms": per_class[dom]["avg_launch_ms"],
                     "traffic_gbps": (traffic / (per_class[dom]["avg_launch_ms"] * 1e-3) / 1e9) if traffic else None,
-                    "note": "peak = vendor fp64 (fp32) matrix figure; the isolated k-loop of these kernels sustains "
-                            "48-55 TFLOP/s fp64 with random operands streaming from HBM on this chip "
-                            "(profiles/r02_mfma_bench5.log: the matrix pipe is power bound, the clock depends on the data)"}
+                    "note": "peak = vendor fp64 (fp32) matrix figure; on random operands at the steady-state clock the "
+                            "isolated k-loop of these kernels sustains ~60 TFLOP/s fp64 fed from HBM and ~67 fed from the "
+                            "caches, the vendor library's GEMM 69-71 at 8192^3 and 59-67 batched at 1024^3 "
+                            "(profiles/r02_kloop_ceiling.log)"}
         out = {
             "metric": "orderings_per_sec", "value": value, "unit": "orderings/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,

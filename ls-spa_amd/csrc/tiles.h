@@ -52,16 +52,16 @@ __host__ __device__ inline int64_t ldv_of(int m_pad) { return (int64_t)m_pad + L
 // rows of a V matrix: the ordering's row blocks rounded up to 128
 __host__ __device__ inline int64_t v_rows_of(int p) { return (int64_t)((p + 127) / 128) * 128; }
 
-// Note on v_mfma_f64_4x4x4_4b_f64: in a dependent-free register loop it issues every 16.5 cycles
-// (70-76 TFLOP/s, tools/mfma_bench3.hip) against 47 TFLOP/s for the 16x16x4 form, and a 16x16x4 step can
-// be built from four of them (lane maps probed in tools/mfma_probe4.hip: lane l = 16 q + 4 g + t holds
-// A_g[i=t][k=q], B_g[k=q][j=t], D_g[i=q][j=t]; CBSZ/ABID broadcast is ignored for f64).  It buys nothing
-// in the kernels: tools/mfma_bench5.hip runs the k-loop of the two-level kernels in isolation (global
-// prefetch -> LDS -> barrier -> fragments -> MFMA, 2 workgroups per CU) and both forms sustain the same
-// 48-54 TFLOP/s with random operands streaming from HBM (61 / 57 without the loads, 64-70 with all-zero
-// operands): the fp64 matrix pipe is bound by power -- the sustained clock depends on the data -- not by
-// issue rate.  Kernel variants written with the 4x4x4 form (git history: "Experimental 4x4x4-MFMA kernel
-// variants") were correct and slower.  ~50 TFLOP/s is the practical fp64 ceiling these kernels price against.
+// Note on v_mfma_f64_4x4x4_4b_f64: in a dependent-free register loop it issues every 16.5 cycles (tools/mfma_bench3.hip)
+// and a 16x16x4 step can be built from four of them (lane maps probed in tools/mfma_probe4.hip: lane l = 16 q + 4 g + t
+// holds A_g[i=t][k=q], B_g[k=q][j=t], D_g[i=q][j=t]; CBSZ/ABID broadcast is ignored for f64).  It buys nothing in the
+// kernels: in the isolated k-loop (tools/mfma_bench5.hip) both forms sustain the same rate, and kernel variants written
+// with the 4x4x4 form (git history: "Experimental 4x4x4-MFMA kernel variants") were correct and slower.
+// What this loop shape (128 x 128 tile, 16-wide k-chunks through LDS, 2 workgroups per CU) delivers on random operands
+// at the steady-state clock (tools/mfma_bench6.hip, profiles/r02_kloop_ceiling.log): ~60 TFLOP/s fed from HBM, ~67 from
+// the Infinity Cache or L2 -- the vendor library's own 128 x 128 x 16 GEMM kernel reaches 69-71 at 8192^3 and 59-67 batched
+// at 1024^3.  Variations of the loop (fragment prefetch, double-buffered LDS, one operand straight to registers, deeper
+// global prefetch) measured equal or slower: the loop is not what holds the factorisation kernels at 46-50.
 
 // ---- per-element-type traits ---------------------------------------------------------------------
 template <typename T>

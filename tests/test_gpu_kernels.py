@@ -40,6 +40,28 @@ def test_gram_reduction(engine, p, n, m):
     assert abs(engine.y_norm_sq - ye @ ye) <= 1e-12 * (ye @ ye)
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("p,n,m", [(1, 40, 33), (127, 300, 290), (131, 333, 301), (255, 700, 650), (257, 513, 511),
+                                   (300, 1000, 17), (383, 450, 449)])
+def test_gram_ragged_tiles_and_rows(engine, p, n, m, dt):
+    """The guarded loads of the Gram kernel: odd p (a 16-byte vector straddles the end of the features or the y
+    column), p + 1 a multiple of 128 (the y column is the last column of a full-width tile), tiles past the
+    features, row counts that are no multiple of the 16-row chunk or of the slice, both data types.  The guarded
+    chunks are loaded unconditionally (clamped rows, y for every column at or beyond p) and masked after the
+    products -- every value that must read as zero is checked through the sums it would otherwise corrupt."""
+    Xa, Xe, ya, ye = problem(23, p, n, m)
+    Xa, Xe, ya, ye = (np.ascontiguousarray(a, dtype=dt) for a in (Xa, Xe, ya, ye))
+    engine.load_data(Xa, Xe, ya, ye, 0.125)
+    G, g, H, h = engine.gram()
+    A64, E64, a64, e64 = (a.astype(np.float64) for a in (Xa, Xe, ya, ye))
+    np.testing.assert_allclose(G, A64.T @ A64 / n + 0.125 * np.eye(p), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(g, A64.T @ a64 / n, rtol=1e-12, atol=1e-12)
+    if m >= p:
+        np.testing.assert_allclose(H, E64.T @ E64, rtol=1e-12, atol=1e-11)
+        np.testing.assert_allclose(h, E64.T @ e64, rtol=1e-12, atol=1e-11)
+    assert abs(engine.y_norm_sq - e64 @ e64) <= 1e-12 * (e64 @ e64)
+
+
 @pytest.mark.parametrize("p,n,m", [(12, 60, 50), (100, 400, 300), (200, 500, 260)])
 def test_cholesky_factor(engine, p, n, m):
     Xa, Xe, ya, ye = problem(4, p, n, m)

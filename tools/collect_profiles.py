@@ -24,6 +24,18 @@ with open(os.path.join(DST, "r02_mfma_bench5.log"), "w") as out:
               "## all-zero operands\n" + open(os.path.join(SRC, "mfma_bench5_zero.log")).read() +
               "\n## random operands (./mfma_bench5 random)\n" + open(os.path.join(SRC, "mfma_bench5_random.log")).read())
 print("profiles/r02_mfma_bench5.log")
+with open(os.path.join(DST, "r02_kloop_ceiling.log"), "w") as out:
+    out.write("# What the fp64 / fp32 matrix pipe delivers on the MI355X of this run (tools/r02_final.sh)\n\n"
+              "## tools/mfma_bench6.hip: the fp64 k-loop of the two-level kernels in isolation, steady-state clock\n" +
+              open(os.path.join(SRC, "mfma_bench6.log")).read() +
+              "\n## tools/mfma_bench7.hip: the fp32 k-loop\n" + open(os.path.join(SRC, "mfma_bench7.log")).read() +
+              "\n## tools/dgemm_probe.py: the vendor library's GEMM / batched GEMM / batched Cholesky / triangular solve (torch -> rocBLAS / hipBLASLt / rocSOLVER)\n" +
+              "".join(l for l in open(os.path.join(SRC, "dgemm_probe.log")) if "amdgpu.ids" not in l) +
+              "\n## tools/dgemm_probe2.py: shapes like ours (X^T X at C3, batched 1024^3 NN / NT)\n" +
+              "".join(l for l in open(os.path.join(SRC, "dgemm_probe2.log")) if "amdgpu.ids" not in l) +
+              "\n## tools/gram_time.py: our Gram reduction, both sides per line (C3: 2 x 1.003e11 flop; C5 per side as printed)\n" +
+              "".join(l for l in open(os.path.join(SRC, "gram_time.log")) if "amdgpu.ids" not in l))
+print("profiles/r02_kloop_ceiling.log")
 # (config, p, batch, dtype, steps executed by the PMC runs = warm-up + timed + event pass)
 for cfg, p, b, dt, steps in (("c3", 1000, 128, "f64", 2 + 6 + 6), ("c5", 5000, 128, "f32", 1 + 3 + 3),
                              ("c2", 100, 128, "f64", 8 + 16 + 16)):

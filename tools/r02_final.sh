@@ -4,6 +4,12 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02_final; mkdir -p $O
 ./tools/bin/mfma_bench5 > $O/mfma_bench5_zero.log 2>&1
 ./tools/bin/mfma_bench5 random > $O/mfma_bench5_random.log 2>&1
+# steady-state k-loop harnesses (random operands, >= 0.4 s of back-to-back launches per line) and the vendor's GEMMs
+./tools/bin/mfma_bench6 > $O/mfma_bench6.log 2>&1
+./tools/bin/mfma_bench7 > $O/mfma_bench7.log 2>&1
+python3 tools/dgemm_probe.py > $O/dgemm_probe.log 2>&1
+python3 tools/dgemm_probe2.py > $O/dgemm_probe2.log 2>&1
+python3 tools/gram_time.py > $O/gram_time.log 2>&1
 echo ceiling done
 # the driver's command, in full (time to tolerance, CPU baseline)
 python3 bench.py --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err
