@@ -761,6 +761,20 @@ __device__ long long g_stamps[32];
 #else
 #define FSTAMP(i) do { } while (0)
 #endif
+// Phase stamps of the panel kernel (tools/panel_probe.hip; compiled out of the library): 100 MHz wall clock at the
+// phase boundaries of a few workgroups spread over the grid, [workgroup slot][phase].
+#ifdef LSSPA_PANEL_STAMPS
+constexpr int PST_SLOTS = 64, PST_PHASES = 16;
+__device__ long long g_pstamps[PST_SLOTS * PST_PHASES];
+#define PSTAMP(i)                                                                                   \
+  do {                                                                                              \
+    const unsigned pst_stride = gridDim.x / PST_SLOTS ? gridDim.x / PST_SLOTS : 1;                  \
+    if (threadIdx.x == 0 && blockIdx.x % pst_stride == 0 && blockIdx.x / pst_stride < PST_SLOTS)    \
+      g_pstamps[(blockIdx.x / pst_stride) * PST_PHASES + (i)] = wall_clock64();                     \
+  } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
 constexpr int XD_LD = 17;
 constexpr int FB_SX_ELEMS = 4 * 16 * XD_LD + 16;
 
@@ -1132,6 +1146,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
   T* M = A + (int64_t)mt * p_pad * p_pad;
   const int J0 = Jo * 128;
   const int I0 = J0 + 128 + tile * 128;
+  PSTAMP(0);
   // Rows at or beyond p_live (= p + 1 rounded up to 16) are identity padding: left of the diagonal they are exact
   // zeros before, during and after every update, so the 16-row accumulator tiles that consist of them only are
   // left out of every product -- the same bits with fewer instructions (p = 1000 pads to 1024: 1 tile in 64;
@@ -1189,6 +1204,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
     }
   }
 
+  PSTAMP(1);
   for (int c = 0; c < nch; ++c) {
     __syncthreads();
     rk_store<T, 128, NT>(rj, s_rkj, tid);
@@ -1214,6 +1230,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
     }
   }
 
+  PSTAMP(2);
   // two-level solve on the accumulators (they hold -C^T):
   //   X1^T = L11^-1 C1^T ;  -C2^T += L21 X1^T ;  X2^T = L22^-1 C2^T
   // acc[4 h + xp][y] <- -sum_{x <= xp} D[xp][x] acc[4 h + x][y], one column tile at a time (in place)
@@ -1247,8 +1264,10 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
   __syncthreads();  // every wave is done with the operand tiles that region A now loses
   block64_put<T, NT>(nb, s_dinv, tid);
   __syncthreads();
+  PSTAMP(12);
   block64_fetch_cm<T, NT>(nb, M, p_pad, J0 + NB, J0, tid);
   tri_mult(0);
+  PSTAMP(13);
   __syncthreads();
   block64_put<T, NT>(nb, s_dinv, tid);
   __syncthreads();
@@ -1266,11 +1285,13 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
       }
     __builtin_amdgcn_sched_barrier(0);
   }
+  PSTAMP(14);
   __syncthreads();
   block64_put<T, NT>(nb, s_dinv, tid);
   __syncthreads();
   tri_mult(1);
 
+  PSTAMP(3);
   // Store L[I, panel] through the output buffer, one 16-column chunk at a time (a contiguous 128 x 16
   // block in the chunk-major layout).
   typedef RKRegs<T, 128, NT> RR;
@@ -1292,6 +1313,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
     }
   }
 
+  PSTAMP(4);
   // A[I,I] -= L[I,panel] L[I,panel]^T on the tile's own diagonal block (this workgroup alone owns it):
   // 36 lower 16 x 16 tiles over the waves.  The accumulators of the solve are dead by now, so the eight
   // chunks just written are staged once more (they come back from L2) instead of keeping both sets of
@@ -1313,11 +1335,15 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
     const T* srcP = M + cm_off(p_pad, I0, J0);
     RKRegs<T, 128, NT> rp = {};
     __syncthreads();   // all stores above are issued and fenced
+    PSTAMP(8);
     rk_load_full<T, 128, NT>(rp, srcP, CM_LD, tid);
     for (int c = 0; c < 8; ++c) {
       __syncthreads();
       rk_store<T, 128, NT>(rp, s_out, tid);
       __syncthreads();
+      if (c == 0) PSTAMP(9);
+      if (c == 1) PSTAMP(10);
+      if (c == 2) PSTAMP(11);
       if (c + 1 < 8) rk_load_full<T, 128, NT>(rp, srcP + (c + 1) * chunk, CM_LD, tid);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -1331,6 +1357,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
       }
     }
   }
+  PSTAMP(5);
 #pragma unroll
   for (int q = 0; q < NU; ++q) {
     if (ws + NW * q >= 36) continue;
@@ -1340,6 +1367,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
       if (col <= row) M[cm_off(p_pad, I0 + row, I0 + col)] = -upd[q][r];
     }
   }
+  PSTAMP(6);
 
 
   // Tile 0 is the next panel's diagonal block and has just received its last update: factor it here,
@@ -1350,6 +1378,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
     factor_diag128<T, NT>(M, p_pad, I0, Dinv + ((int64_t)mt * nblk + 2 * (Jo + 1)) * 4096,
                           diag0 + (int64_t)mt * p_pad, piv_tol, info, s_a, s_b, tid);
   }
+  PSTAMP(7);
 }
 
 // whole factorisation of n_mats matrices: one diagonal launch + (p_pad / 128 - 1) panel launches
