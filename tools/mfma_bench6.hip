@@ -153,6 +153,57 @@ __global__ __launch_bounds__(256, 2) void kloop(const double* __restrict__ src, 
   if (tid == 0 && blockIdx.x == gridDim.x / 2) { cyc[0] = t1 - t0; cyc[1] = w1 - w0; }
 }
 
+// Row-tile PAIR per workgroup: 512 threads, 256 x 128 output (eight waves, each 128 x 32 as before), the shared operand
+// (128 rows x 16 k) staged once for both halves -- 21 instead of 16 flop per operand byte, one 8-wave barrier domain,
+// one workgroup per CU.  Operand layout: pa = shared rows, pb = the pair's 256 own rows ([chunk][256][16]).
+__global__ __launch_bounds__(512, 2) void kloop_pair(const double* __restrict__ src, double* out, int nch, int nsets,
+                                                     long long* cyc) {
+  __shared__ __attribute__((aligned(16))) double s_a[128 * LD];
+  __shared__ __attribute__((aligned(16))) double s_b[256 * LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int set = blockIdx.x % nsets;
+  const double* pa = src + (size_t)set * 3 * nch * 2048;   // [chunk][128][16] then [chunk][256][16]
+  const double* pb = pa + (size_t)nch * 2048;
+  const int c8 = tid & 7, row = tid >> 3;                  // 64 rows per pass
+  v2d ra[2], rb[4];
+  auto load = [&](int c) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ra[q] = *reinterpret_cast<const v2d*>(pa + (size_t)c * 2048 + (row + 64 * q) * 16 + 2 * c8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const v2d*>(pb + (size_t)c * 4096 + (row + 64 * q) * 16 + 2 * c8);
+  };
+  d4 acc[8][2];
+  for (int x = 0; x < 8; ++x) for (int y = 0; y < 2; ++y) acc[x][y] = d4{0, 0, 0, 0};
+  load(0);
+  const long long t0 = clock64(), w0 = wall_clock64();
+  for (int c = 0; c < nch; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *reinterpret_cast<v2d*>(s_a + (row + 64 * q) * LD + 2 * c8) = ra[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<v2d*>(s_b + (row + 64 * q) * LD + 2 * c8) = rb[q];
+    __syncthreads();
+    if (c + 1 < nch) load(c + 1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double av[8], bv[2];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) av[x] = s_a[(16 * x + l15) * LD + 4 * kk + l4];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) bv[y] = s_b[(32 * w + 16 * y + l15) * LD + 4 * kk + l4];
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = mfma(av[x], bv[y], acc[x][y]);
+    }
+  }
+  const long long t1 = clock64(), w1 = wall_clock64();
+  double sum = 0;
+  for (int x = 0; x < 8; ++x) for (int y = 0; y < 2; ++y) for (int s2 = 0; s2 < 4; ++s2) sum += acc[x][y][s2];
+  out[(size_t)blockIdx.x * 512 + tid] = sum;
+  if (tid == 0 && blockIdx.x == gridDim.x / 2) { cyc[0] = t1 - t0; cyc[1] = w1 - w0; }
+}
+
 __global__ void fill_random(double* p, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     unsigned long long z = i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
@@ -195,5 +246,20 @@ int main(int argc, char** argv) {
                ms, flops / ms * 1e-9, h[0], ghz);
         fflush(stdout);
       }
+  // the row-tile pair: half as many workgroups for the same flops; the source holds 3 x nch chunks per workgroup
+  for (int round = 0; round < 2; ++round)
+    for (int fp = 0; fp < 3; ++fp) {
+      const int g2 = grid / 2, sets = footprints[fp] == grid ? g2 : footprints[fp];
+      for (int r = 0; r < 150; ++r) hipLaunchKernelGGL(kloop_pair, dim3(g2), dim3(512), 0, 0, src, out, nch, sets, cyc);
+      (void)hipEventRecord(e0);
+      for (int r = 0; r < 60; ++r) hipLaunchKernelGGL(kloop_pair, dim3(g2), dim3(512), 0, 0, src, out, nch, sets, cyc);
+      (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+      float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 60;
+      long long h[2] = {0, 0}; (void)hipMemcpy(h, cyc, 16, hipMemcpyDeviceToHost);
+      const double ghz = h[1] > 0 ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+      printf("%-36s %-18s %.3f ms  %.1f TFLOP/s  (a mid-grid workgroup: %lld cycles, clock held %.2f GHz)\n", fnames[fp],
+             "pair 256x128 / 512", ms, flops / ms * 1e-9, h[0], ghz);
+      fflush(stdout);
+    }
   return 0;
 }
