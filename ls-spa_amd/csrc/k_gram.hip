@@ -205,24 +205,41 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const T* __restrict__ X, c
         slab[(64 * wi + 16 * x + acc_row(l4, r)) * 128 + 64 * wj + 16 * yv + l15] = acc[x][yv][r];
 }
 
-// C[i][j] = C[j][i] = sum over slices of the pair's slab, fixed order
+// C[i][j] = C[j][i] = sum over slices of the pair's slab, fixed order.  One workgroup per 32 x 32 sub-tile of a pair
+// (16 per pair: enough workgroups to cover the load latency of the n_split slabs), the mirror image written from an
+// LDS copy so that both stores are coalesced (written straight, the mirror was a 64-way scattered store per wave and
+// the whole reduction took a tenth of the Gram time for a fiftieth of its bytes).
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ slabs, int n_split,
                                                           int n_pairs, int P1pad, double* __restrict__ C,
                                                           int accumulate) {
+  __shared__ double s_t[32][33];
   int pair = blockIdx.x, ti = 0;
   while (pair >= ti + 1) {
     pair -= ti + 1;
     ++ti;
   }
   const int tj = pair;
-  for (int e = threadIdx.x + 256 * blockIdx.y; e < 128 * 128; e += 256 * gridDim.y) {
+  const int sy = blockIdx.y >> 2, sx = blockIdx.y & 3;          // sub-tile (rows, columns) of the 128 x 128 tile
+  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;        // column, first row; rows r0 + 8 q
+  const int i0 = ti * 128 + sy * 32, j0 = tj * 128 + sx * 32;
+  double v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = (sy * 32 + r0 + 8 * q) * 128 + sx * 32 + c;
     double s = 0.0;
     for (int k = 0; k < n_split; ++k) s += slabs[((int64_t)k * n_pairs + blockIdx.x) * (128 * 128) + e];
-    const int i = ti * 128 + (e >> 7), j = tj * 128 + (e & 127);
-    if (accumulate) s += C[(int64_t)i * P1pad + j];   // fixed chunk order: still reproducible
-    C[(int64_t)i * P1pad + j] = s;
-    if (ti != tj) C[(int64_t)j * P1pad + i] = s;
+    const int64_t o = (int64_t)(i0 + r0 + 8 * q) * P1pad + j0 + c;
+    if (accumulate) s += C[o];   // fixed chunk order: still reproducible
+    C[o] = s;
+    v[q] = s;
   }
+  if (ti == tj) return;            // workgroup-uniform
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s_t[r0 + 8 * q][c] = v[q];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q)      // row j0 + (r0 + 8 q) of the mirror image, columns i0 + c
+    C[(int64_t)(j0 + r0 + 8 * q) * P1pad + i0 + c] = s_t[c][r0 + 8 * q];
 }
 
 __global__ __launch_bounds__(256) void gram_finalize_kernel(const double* __restrict__ C, int P1pad, int p,
@@ -286,7 +303,7 @@ hipError_t launch_gram(const GramArgs& a, hipStream_t st) {
                        (const double*)a.y, a.n, a.ld, a.p, (int)rps, np, a.slabs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(np, 8), dim3(256), 0, st, a.slabs, a.n_split, np, P1pad, a.C,
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(np, 16), dim3(256), 0, st, a.slabs, a.n_split, np, P1pad, a.C,
                      a.accumulate);
   return hipGetLastError();
 }
