@@ -273,21 +273,25 @@ __global__ __launch_bounds__(64) void stats_small_kernel(const double* __restric
   const int ac = a < p ? a : p - 1, bc = b < p ? b : p - 1;     // clamped addresses, value selected afterwards
   const double mua = mean[ac], mub = mean[bc];
   d4 acc = d4_zero(), colsum = d4_zero();
-  // 32 samples per trip: 16 independent loads per lane in flight, then 8 (+8) MFMAs
-  for (int s0 = 0; s0 < n_samples; s0 += 32) {
-    double av[8], bv[8];
+  // 128 samples per trip: 64 independent loads per lane in flight (the wave has the register file to itself), then
+  // 32 (+32) MFMAs -- the kernel is a chain of load round trips, two of them for a batch of 256 instead of eight
+  constexpr int KT = 32;
+  for (int s0 = 0; s0 < n_samples; s0 += 4 * KT) {
+    double ra[KT], rb[KT];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
+    for (int kk = 0; kk < KT; ++kk) {
       const int s = s0 + 4 * kk + l4;
       const int sc = s < n_samples ? s : n_samples - 1;
-      const double xa = lifts[(int64_t)sc * p + ac] - mua, xb = lifts[(int64_t)sc * p + bc] - mub;
-      av[kk] = (s < n_samples && a < p) ? xa : 0.0;
-      bv[kk] = (s < n_samples && b < p) ? xb : 0.0;
+      ra[kk] = lifts[(int64_t)sc * p + ac];
+      rb[kk] = lifts[(int64_t)sc * p + bc];
     }
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      acc = mfma(av[kk], bv[kk], acc);
-      if (diag) colsum = mfma(av[kk], 1.0, colsum);     // every column of the result = sum over the samples of D[., a]
+    for (int kk = 0; kk < KT; ++kk) {
+      const int s = s0 + 4 * kk + l4;
+      const double av = (s < n_samples && a < p) ? ra[kk] - mua : 0.0;
+      const double bv = (s < n_samples && b < p) ? rb[kk] - mub : 0.0;
+      acc = mfma(av, bv, acc);
+      if (diag) colsum = mfma(av, 1.0, colsum);     // every column of the result = sum over the samples of D[., a]
     }
   }
 #pragma unroll
