@@ -6,7 +6,8 @@ all-reduce (SUM, fp64) per chunk of the packed pending statistics
 [n_b, sum(l - mu), sum (l - mu)(l - mu)^T] -- the multi-device form of the reference's
 merge_sample_mean / merge_sample_cov (cvxgrp/ls-spa ls_spa/ls_spa.py:103-119, :212-216).
 With backend "nccl" (= RCCL on ROCm) the buffer is reduced in place in HBM over xGMI;
-with "gloo" (CPU tests) it is a host tensor.  After the collective every rank holds the
+with "gloo" it is a host tensor (CPU tests) or a device buffer staged through the host (the two-ranks-on-one-GPU
+test).  After the collective every rank holds the
 same moments, merges them identically and therefore takes the same stop decision.
 
 Stream discipline on the GPU: if the engine was created on a torch stream
@@ -82,6 +83,15 @@ class TorchComm:
             return
         t = self._as_tensor(get_buffer(), engine)
         if not self._on_gpu:
+            if t.is_cuda:
+                # a HIP engine under a CPU transport (gloo: several ranks sharing one GPU in the tests -- RCCL refuses
+                # two ranks on one device): the buffer is staged through the host around the collective
+                engine.synchronize()
+                h = t.cpu()
+                self._dist.all_reduce(h, op=self._dist.ReduceOp.SUM, group=self._group)
+                t.copy_(h)
+                self._torch.cuda.synchronize(t.device)
+                return
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
             return
         if self._torch.cuda.current_device() != engine.device:
