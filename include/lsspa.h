@@ -51,7 +51,16 @@ int lsspa_synchronize(lsspa_ctx* ctx);
  * Forms G = X_tr^T X_tr / N + reg I, g = X_tr^T y_tr / N and, when M >= p, H = X_te^T X_te,
  * h = X_te^T y_te by one MFMA Gram pass each; when M < p the test rows themselves are
  * kept (transposed) as the test factor.  X pointers: row-major [rows][ld]; dtype applies to
- * X and y alike; location says whether the four pointers are host or device memory. */
+ * X and y alike; location says whether the four pointers are host or device memory.
+ * p is limited by the LDS of a CU (the gather stages one source row and the ordering: 12 B a feature of the padded
+ * count, 160 KB): p <= 13567; a larger p is refused here with LSSPA_ERR_ARG and a message naming it (the reference
+ * has no limit, ls_spa/ls_spa.py:163).
+ * Host arrays are never written and stay the caller's: they are read during the call only.  A dense X (ld == p) of
+ * 8 MB or more is page-locked in place for the duration of the call (hipHostRegister) -- only the whole pages that
+ * lie strictly inside the array, so no page shared with a neighbouring allocation (y, another thread's block) is
+ * ever locked; the unaligned ends, y, strided X (ld > p) and memory the HIP runtime already knows (hipHostMalloc'ed
+ * or registered by the caller) go through ordinary copies and are left exactly as they were.
+ * No C++ exception leaves any entry point of this header: host allocation failure is LSSPA_ERR_NOMEM. */
 int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const void* y_train, int64_t N,
                  const void* X_test, int64_t ld_test, const void* y_test, int64_t M, int32_t p, double reg,
                  int32_t dtype, int32_t location);
@@ -177,6 +186,7 @@ int lsspa_error_quantiles(lsspa_ctx* ctx, double* feature_errors, double* overal
 int lsspa_comm_unique_id(uint8_t* id128);
 int lsspa_comm_init(lsspa_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world);
 int lsspa_comm_destroy(lsspa_ctx* ctx);
+/* rank and size as RCCL reports them for this context's communicator (ncclCommUserRank / ncclCommCount) */
 int lsspa_comm_info(const lsspa_ctx* ctx, int32_t* rank, int32_t* world);
 int lsspa_stats_allreduce(lsspa_ctx* ctx);
 int lsspa_reduce_allreduce(lsspa_ctx* ctx);
@@ -207,6 +217,7 @@ int lsspa_profile_reset(lsspa_ctx* ctx);
  *   256  unpaired gather                              512  256-column strips (512-thread workgroups)
  *  2048  no skipping of the all-padding 16 x 16 tiles in the panel / strip products
  *  1024  general path also for small problems (p + 1 <= 128 normally takes the fused one-workgroup kernel)
+ *  4096  streamed reduction never page-locks the caller's X (A/B of the PCIe path)
  * Every combination computes the same lifts (tests/test_gpu_kernels.py). */
 int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);
 

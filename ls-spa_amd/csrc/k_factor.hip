@@ -117,32 +117,40 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
   }
 }
 
+// Largest feature count the per-ordering kernels take: the gather keeps one source row (8 B an entry in the fp64
+// path) and the ordering (4 B an entry) of p_pad entries in LDS, and a CU has 160 KB of it.
+int max_features() {
+  const int p_pad_max = (int)(LDS_BYTES_PER_CU / (sizeof(double) + sizeof(int32_t))) / 128 * 128;
+  return p_pad_max - 1;
+}
+
+template <typename T, bool PAIRED, typename ST>
+static hipError_t launch_gather_as(const GatherArgs& a, dim3 grid, size_t shmem, hipStream_t st) {
+  static DynLdsGrant grant;   // one per instantiation
+  hipError_t e = grant.ensure(reinterpret_cast<const void*>(gather_kernel<T, PAIRED, ST>), shmem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((gather_kernel<T, PAIRED, ST>), grid, dim3(256), shmem, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_gather(const GatherArgs& a, hipStream_t st) {
   if (a.p < 1 || a.p_pad % NB != 0 || a.p_pad <= a.p || a.n_ord < 1 || a.n_src < 1 || a.n_src > 2 ||
       (a.ld_src & 1) || (a.paired && (a.n_ord & 1)))
     return hipErrorInvalidValue;
   const bool srcf = a.f32 && a.Sf[0] != nullptr && (a.n_src == 1 || a.Sf[1] != nullptr);
   const size_t shmem = (srcf ? sizeof(float) : sizeof(double)) * a.p_pad + sizeof(int32_t) * a.p_pad;
-  if (shmem > 64 * 1024) return hipErrorInvalidValue;
+  if (shmem > LDS_BYTES_PER_CU) return hipErrorInvalidValue;   // set_dims refuses such p (max_features)
   dim3 grid((a.p_pad + GROWS - 1) / GROWS, (a.paired ? a.n_ord / 2 : a.n_ord) * a.n_src);
   // aug row reads sperm[j] for all j < p: the workgroup holding row p must have them all
   // (jmax = min(i0 + GROWS, p) = p there), so nothing else to arrange.
   if (a.paired) {
-    if (srcf)
-      hipLaunchKernelGGL((gather_kernel<float, true, float>), grid, dim3(256), shmem, st, a);
-    else if (a.f32)
-      hipLaunchKernelGGL((gather_kernel<float, true, double>), grid, dim3(256), shmem, st, a);
-    else
-      hipLaunchKernelGGL((gather_kernel<double, true, double>), grid, dim3(256), shmem, st, a);
-  } else {
-    if (srcf)
-      hipLaunchKernelGGL((gather_kernel<float, false, float>), grid, dim3(256), shmem, st, a);
-    else if (a.f32)
-      hipLaunchKernelGGL((gather_kernel<float, false, double>), grid, dim3(256), shmem, st, a);
-    else
-      hipLaunchKernelGGL((gather_kernel<double, false, double>), grid, dim3(256), shmem, st, a);
+    if (srcf) return launch_gather_as<float, true, float>(a, grid, shmem, st);
+    if (a.f32) return launch_gather_as<float, true, double>(a, grid, shmem, st);
+    return launch_gather_as<double, true, double>(a, grid, shmem, st);
   }
-  return hipGetLastError();
+  if (srcf) return launch_gather_as<float, false, float>(a, grid, shmem, st);
+  if (a.f32) return launch_gather_as<float, false, double>(a, grid, shmem, st);
+  return launch_gather_as<double, false, double>(a, grid, shmem, st);
 }
 
 __global__ __launch_bounds__(256) void to_f32_kernel(const double* __restrict__ src, float* __restrict__ dst,

@@ -515,7 +515,11 @@ __global__ __launch_bounds__(1024) void backsolve_kernel(const T* __restrict__ L
 hipError_t launch_backsolve(const void* A, double* theta, int p, int p_pad, int f32, hipStream_t st) {
   if (p < 1 || p_pad <= p) return hipErrorInvalidValue;
   const size_t shmem = sizeof(double) * p;
-  if (shmem > 60 * 1024) return hipErrorInvalidValue;
+  if (shmem + 64 > LDS_BYTES_PER_CU) return hipErrorInvalidValue;   // set_dims refuses such p (max_features)
+  static DynLdsGrant grant_f, grant_d;
+  hipError_t e = f32 ? grant_f.ensure(reinterpret_cast<const void*>(backsolve_kernel<float>), shmem)
+                     : grant_d.ensure(reinterpret_cast<const void*>(backsolve_kernel<double>), shmem);
+  if (e != hipSuccess) return e;
   if (f32)
     hipLaunchKernelGGL(backsolve_kernel<float>, dim3(1), dim3(1024), shmem, st, (const float*)A, theta, p, p_pad);
   else

@@ -363,13 +363,9 @@ hipError_t launch_small_p(const SmallArgs& a, hipStream_t st) {
       (a.n_ord % a.per_sample) != 0 || !a.S[0] || !a.S[1] || !a.perms || !a.lifts)
     return hipErrorInvalidValue;
   const size_t bytes = small_p_lds_bytes(a.nb);
-  static size_t configured = 0;
-  if (bytes > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(small_p_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    configured = bytes;
-  }
+  static DynLdsGrant grant;   // per device (a second engine on another GPU sets the attribute there too)
+  hipError_t e = grant.ensure(reinterpret_cast<const void*>(small_p_kernel), bytes);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(small_p_kernel, dim3(a.n_ord), dim3(512), bytes, st, a);
   return hipGetLastError();
 }

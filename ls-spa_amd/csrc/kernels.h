@@ -9,7 +9,30 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 namespace lsspa {
+
+// Dynamic LDS beyond the 64 KB default needs hipFuncAttributeMaxDynamicSharedMemorySize, which is set on the CURRENT
+// device's copy of the function: remember the size granted per device (a second engine on another GPU of the same
+// process must set it again), under a lock (two engines may launch from two host threads).
+struct DynLdsGrant {
+  static constexpr int MAX_DEVICES = 64;
+  std::mutex mu;
+  size_t granted[MAX_DEVICES] = {0};
+  hipError_t ensure(const void* fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < MAX_DEVICES && granted[dev] >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev >= 0 && dev < MAX_DEVICES) granted[dev] = bytes;
+    return e;
+  }
+};
+constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;   // gfx950
 
 struct GatherArgs {
   const double* S[2];      // source Gram matrices (train, test), fp64, row-major, stride ld_src
@@ -27,6 +50,7 @@ struct GatherArgs {
                            // the source rows writes both matrices
 };
 hipError_t launch_gather(const GatherArgs& a, hipStream_t st);
+int max_features();   // largest p the per-ordering kernels take (LDS of the gather)
 // dst[i] = (float)src[i]
 hipError_t launch_to_f32(const double* src, float* dst, int64_t count, hipStream_t st);
 

@@ -4,6 +4,7 @@
 #include "../../include/lsspa.h"
 
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -201,7 +202,12 @@ struct ProfScope {
   ~ProfScope() {
     if (!live) return;
     (void)hipEventRecord(rec.end, st);
-    ctx->prof_recs.push_back(rec);
+    try {
+      ctx->prof_recs.push_back(rec);
+    } catch (...) {   // out of host memory: lose the sample, not the process (a throwing destructor terminates)
+      (void)hipEventDestroy(rec.beg);
+      (void)hipEventDestroy(rec.end);
+    }
   }
 };
 
@@ -285,6 +291,14 @@ int sync_all(lsspa_ctx* ctx) {
 int set_dims(lsspa_ctx* ctx, int p, int m, int tri) {
   if (p < 1 || m < 1) return ctx->fail(LSSPA_ERR_ARG, "p and m must be positive");
   if (tri && m != p) return ctx->fail(LSSPA_ERR_ARG, "tri mode needs m == p");
+  if (p > max_features()) {
+    // the reference has no limit (ls_spa/ls_spa.py:163); here the gather keeps a source row and the ordering in the
+    // 160 KB of LDS of a CU.  Refused now, by name, rather than at the first batch's launch.
+    char msg[160];
+    snprintf(msg, sizeof msg, "p = %d features exceeds the %d this engine supports (one source row and the ordering "
+             "must fit the 160 KB of LDS of a CU)", p, max_features());
+    return ctx->fail(LSSPA_ERR_ARG, msg);
+  }
   TRY(sync_all(ctx));  // buffers below may be re-allocated
   ctx->have_problem = false;
   ctx->src_f32_valid = false;
@@ -801,6 +815,28 @@ bool all_permutations(const int32_t* perms, int B, int p, std::vector<int32_t>& 
   return true;
 }
 
+// No exception crosses the C ABI: std::vector / std::string / new inside an entry point turn into a status code
+// (an escaping std::bad_alloc would be std::terminate, i.e. an abort of the host process).
+int abi_caught(lsspa_ctx* ctx) noexcept {
+  const char* what = "C++ exception inside the library";
+  int code = LSSPA_ERR_HIP;
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    what = "out of host memory";
+    code = LSSPA_ERR_NOMEM;
+  } catch (const std::exception& e) {
+    what = e.what();
+  } catch (...) {
+  }
+  try {
+    if (ctx) ctx->err = what;
+    else g_create_error = what;
+  } catch (...) {
+  }
+  return code;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -852,7 +888,7 @@ int lsspa_create(int32_t device, lsspa_ctx** out) {
   return LSSPA_OK;
 }
 
-int lsspa_destroy(lsspa_ctx* ctx) {
+int lsspa_destroy(lsspa_ctx* ctx) try {
   if (!ctx) return LSSPA_OK;
   (void)hipSetDevice(ctx->device);
   (void)sync_all(ctx);
@@ -896,9 +932,11 @@ int lsspa_destroy(lsspa_ctx* ctx) {
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_set_stream(lsspa_ctx* ctx, void* hip_stream) {
+int lsspa_set_stream(lsspa_ctx* ctx, void* hip_stream) try {
   if (!ctx) return LSSPA_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   TRY(sync_all(ctx));
@@ -911,15 +949,19 @@ int lsspa_set_stream(lsspa_ctx* ctx, void* hip_stream) {
     ctx->own_stream = true;
   }
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_synchronize(lsspa_ctx* ctx) {
+int lsspa_synchronize(lsspa_ctx* ctx) try {
   if (!ctx) return LSSPA_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   return sync_all(ctx);
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_set_lanes(lsspa_ctx* ctx, int32_t n) {
+int lsspa_set_lanes(lsspa_ctx* ctx, int32_t n) try {
   if (!ctx || (n != 1 && n != 2)) return LSSPA_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   for (const Lane& L : ctx->lanes)
@@ -934,6 +976,8 @@ int lsspa_set_lanes(lsspa_ctx* ctx, int32_t n) {
   }
   if (n == 2 && !ctx->ev_problem) TRY(mark_problem(ctx));
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -968,10 +1012,67 @@ static int gram_side(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, in
   return rc;
 }
 
+// Pin, in place, the part of a caller's host array that is the array's ALONE: the whole pages strictly inside
+// [base, base + bytes).  The first and the last page of an unaligned block are shared with whatever the
+// allocator put next to it (NumPy hands out malloc blocks: X and y of one call may share a page; so may a block
+// of another thread), and a page lock is not ours to take on their behalf -- those few KB go through the runtime's
+// ordinary staged copy.  Not pinned at all: blocks under 8 MB (the staged copy is as fast), memory the runtime
+// already knows (hipHostMalloc'ed or registered by the caller: it is DMA-able as it stands, and unregistering it
+// here would pull it from under its owner).  Returns an empty span when nothing was pinned.
+struct PinnedSpan {
+  const char* lo = nullptr;
+  const char* hi = nullptr;
+};
+
+static PinnedSpan pin_interior(const void* base, size_t bytes) {
+  PinnedSpan sp;
+  constexpr size_t PIN_FROM = (size_t)8 << 20;
+  if (!base || bytes < PIN_FROM) return sp;
+  long pg = sysconf(_SC_PAGESIZE);
+  if (pg <= 0) pg = 4096;
+  const uintptr_t b = reinterpret_cast<uintptr_t>(base);
+  const uintptr_t lo = (b + (uintptr_t)pg - 1) / (uintptr_t)pg * (uintptr_t)pg;
+  const uintptr_t hi = (b + bytes) / (uintptr_t)pg * (uintptr_t)pg;
+  if (hi <= lo) return sp;
+  hipPointerAttribute_t at;
+  std::memset(&at, 0, sizeof at);
+  const hipError_t qa = hipPointerGetAttributes(&at, reinterpret_cast<const void*>(lo));
+  (void)hipGetLastError();
+  if (qa == hipSuccess && at.type != hipMemoryTypeUnregistered) return sp;   // the runtime knows it: leave it alone
+  const hipError_t e = hipHostRegister(reinterpret_cast<void*>(lo), hi - lo, hipHostRegisterDefault);
+  (void)hipGetLastError();
+  if (e != hipSuccess) return sp;   // refused (e.g. hipErrorHostMemoryAlreadyRegistered for a part of it): staged copies
+  sp.lo = reinterpret_cast<const char*>(lo);
+  sp.hi = reinterpret_cast<const char*>(hi);
+  return sp;
+}
+
+static void unpin(PinnedSpan& sp) {
+  if (sp.lo) (void)hipHostUnregister(const_cast<char*>(sp.lo));
+  (void)hipGetLastError();
+  sp.lo = sp.hi = nullptr;
+}
+
+// host -> device copy of [src, src + n) that crosses at most the two ends of a pinned span: the part inside the
+// span is one true DMA, the parts outside (under a page each) are the runtime's staged copies.  A single call
+// over the whole range would be refused: the range is not inside one registration.
+static hipError_t copy_h2d_split(char* dst, const char* src, size_t n, const PinnedSpan& sp, hipStream_t st) {
+  if (!sp.lo) return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st);
+  const char* const end = src + n;
+  const char* const a = std::min(end, std::max(src, sp.lo));   // first pinned byte of the range
+  const char* const b = std::max(a, std::min(end, sp.hi));     // one past its last pinned byte
+  hipError_t e = hipSuccess;
+  if (a > src) e = hipMemcpyAsync(dst, src, (size_t)(a - src), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && b > a) e = hipMemcpyAsync(dst + (a - src), a, (size_t)(b - a), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && end > b) e = hipMemcpyAsync(dst + (b - src), b, (size_t)(end - b), hipMemcpyHostToDevice, st);
+  return e;
+}
+
 // Gram of a HOST-resident [n][ld] matrix, streamed: the rows cross PCIe in chunks through two device
 // buffers on a copy stream while the previous chunk's Gram runs on the compute stream; the chunk
-// Grams accumulate in C in chunk order.  The caller's array is pinned in place for the duration
-// (hipHostRegister) when the runtime allows it, so the copies are true DMA.
+// Grams accumulate in C in chunk order.  A dense X (ld == p) of 8 MB or more is pinned in place for the
+// duration -- its interior pages only, see pin_interior -- so that its copies are true DMA.  y (1 / p of the
+// bytes) and strided X (ld > p: the extent (n - 1) ld + p ends inside somebody else's row) are never pinned.
 static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, int64_t ld, int p,
                               int is_f32, double* C_out) {
   const size_t es = is_f32 ? 4 : 8;
@@ -983,7 +1084,7 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
   void* dy[2] = {nullptr, nullptr};
   hipStream_t cs = nullptr;
   hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
-  bool reg_x = false, reg_y = false;
+  PinnedSpan pin;
   C.ptr = C_out;
   int rc = dev_alloc(ctx, slabs, gram_workspace_bytes(p, n_split) / sizeof(double));
   hipError_t e = hipSuccess;
@@ -998,14 +1099,7 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
     if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_NOMEM, "streamed reduction buffers", e);
   }
   if (rc == LSSPA_OK) {
-    // pin the caller's arrays in place when that pays: from 8 MB on the copies then are true DMA at PCIe rate;
-    // below, the runtime's staged copy is as fast, and a small heap block shares its pages with unrelated
-    // allocations that have no business being locked.  Harmless if refused.
-    constexpr size_t PIN_FROM = (size_t)8 << 20;
-    const size_t bx = (size_t)n * ld * es, by = (size_t)n * es;
-    reg_x = bx >= PIN_FROM && hipHostRegister(const_cast<void*>(X), bx, hipHostRegisterDefault) == hipSuccess;
-    reg_y = by >= PIN_FROM && hipHostRegister(const_cast<void*>(y), by, hipHostRegisterDefault) == hipSuccess;
-    (void)hipGetLastError();
+    if (ld == p && !(ctx->flags & 4096)) pin = pin_interior(X, (size_t)n * p * es);   // flag 4096: never pin (A/B)
     ProfScope ps(ctx, LSSPA_K_GRAM);
     int k = 0;
     for (int64_t r0 = 0; r0 < n && e == hipSuccess; r0 += rows, ++k) {
@@ -1015,7 +1109,7 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
       const char* src = static_cast<const char*>(X) + (size_t)r0 * ld * es;
       if (e == hipSuccess) {
         if (ld == p)
-          e = hipMemcpyAsync(dX[b], src, (size_t)nr * p * es, hipMemcpyHostToDevice, cs);
+          e = copy_h2d_split(static_cast<char*>(dX[b]), src, (size_t)nr * p * es, pin, cs);
         else
           e = hipMemcpy2DAsync(dX[b], (size_t)p * es, src, (size_t)ld * es, (size_t)p * es, (size_t)nr,
                                hipMemcpyHostToDevice, cs);
@@ -1043,14 +1137,17 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
     }
     if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "streamed gram", e);
   }
+  // Both streams are idle before the span is unpinned and the buffers go -- on the error paths too: every copy
+  // that reads the caller's pages was enqueued on cs, every kernel that reads dX / dy on the context's stream.
   hipError_t es1 = hipStreamSynchronize(ctx->stream);
+  hipError_t es2 = hipSuccess;
   if (cs) {
-    (void)hipStreamSynchronize(cs);
+    es2 = hipStreamSynchronize(cs);
     (void)hipStreamDestroy(cs);
   }
   if (rc == LSSPA_OK && es1 != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "streamed gram sync", es1);
-  if (reg_x) (void)hipHostUnregister(const_cast<void*>(X));
-  if (reg_y) (void)hipHostUnregister(const_cast<void*>(y));
+  if (rc == LSSPA_OK && es2 != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "streamed gram copy sync", es2);
+  unpin(pin);
   for (int b = 0; b < 2; ++b) {
     if (dX[b]) (void)hipFree(dX[b]);
     if (dy[b]) (void)hipFree(dy[b]);
@@ -1147,7 +1244,7 @@ static int reduce_finalize(lsspa_ctx* ctx, int64_t N_total, double reg) {
 
 int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const void* y_train, int64_t N,
                  const void* X_test, int64_t ld_test, const void* y_test, int64_t M, int32_t p, double reg,
-                 int32_t dtype, int32_t location) {
+                 int32_t dtype, int32_t location) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!X_train || !y_train || !X_test || !y_test) return ctx->fail(LSSPA_ERR_ARG, "NULL data pointer");
   if (p < 1 || N < p || M < 1 || ld_train < p || ld_test < p)
@@ -1161,11 +1258,13 @@ int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const vo
   TRY(set_dims(ctx, p, tri ? p : (int)M, tri));
   TRY(reduce_rows(ctx, X_train, ld_train, y_train, N, X_test, ld_test, y_test, M, p, dtype, location, tri));
   return reduce_finalize(ctx, N, reg);
+} catch (...) {
+  return abi_caught(ctx);
 }
 
 int lsspa_reduce_partial(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const void* y_train,
                          int64_t n_local, const void* X_test, int64_t ld_test, const void* y_test,
-                         int64_t m_local, int64_t M_total, int32_t p, int32_t dtype, int32_t location) {
+                         int64_t m_local, int64_t M_total, int32_t p, int32_t dtype, int32_t location) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (n_local < 0 || m_local < 0 || M_total < 1 || m_local > M_total || p < 1)
     return ctx->fail(LSSPA_ERR_ARG, "need n_local >= 0, 0 <= m_local <= M_total, p >= 1");
@@ -1183,29 +1282,35 @@ int lsspa_reduce_partial(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, 
                   tri));
   ctx->reduce_open = true;
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_reduce_buffer(lsspa_ctx* ctx, void** device_ptr, int64_t* count) {
+int lsspa_reduce_buffer(lsspa_ctx* ctx, void** device_ptr, int64_t* count) try {
   if (!ctx || !device_ptr || !count) return LSSPA_ERR_ARG;
   if (!ctx->reduce_open) return ctx->fail(LSSPA_ERR_STATE, "no partial reduction in progress");
   *device_ptr = ctx->Cred.ptr;
   const int64_t P1pad = round_up(ctx->p + 1, 128);
   *count = 2 * P1pad * P1pad;
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_reduce_finish(lsspa_ctx* ctx, int64_t N_total, double reg) {
+int lsspa_reduce_finish(lsspa_ctx* ctx, int64_t N_total, double reg) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->reduce_open) return ctx->fail(LSSPA_ERR_STATE, "no partial reduction in progress");
   if (N_total < ctx->p) return ctx->fail(LSSPA_ERR_ARG, "need N_total >= p");
   if (!(reg >= 0.0)) return ctx->fail(LSSPA_ERR_ARG, "reg must be >= 0");
   HIPCHK(hipSetDevice(ctx->device));
   return reduce_finalize(ctx, N_total, reg);
+} catch (...) {
+  return abi_caught(ctx);
 }
 
 int lsspa_set_reduced(lsspa_ctx* ctx, int32_t p, const double* G, const double* g, double aug_train,
                       int32_t tri, const double* H, const double* h, int32_t m, const double* Ft,
-                      const double* ytil, double y_norm_sq) {
+                      const double* ytil, double y_norm_sq) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!G || !g) return ctx->fail(LSSPA_ERR_ARG, "G and g are required");
   if (tri ? (!H || !h) : (!Ft || !ytil)) return ctx->fail(LSSPA_ERR_ARG, "test side pointers missing");
@@ -1233,18 +1338,22 @@ int lsspa_set_reduced(lsspa_ctx* ctx, int32_t p, const double* G, const double* 
   ctx->have_problem = true;
   TRY(mark_problem(ctx));
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_get_problem(const lsspa_ctx* ctx, int32_t* p, int32_t* m, int32_t* tri, double* y_norm_sq) {
+int lsspa_get_problem(const lsspa_ctx* ctx, int32_t* p, int32_t* m, int32_t* tri, double* y_norm_sq) try {
   if (!ctx || !ctx->have_problem) return LSSPA_ERR_STATE;
   if (p) *p = ctx->p;
   if (m) *m = ctx->m;
   if (tri) *tri = ctx->tri;
   if (y_norm_sq) *y_norm_sq = ctx->y_norm_sq;
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(const_cast<lsspa_ctx*>(ctx));
 }
 
-int lsspa_get_gram(lsspa_ctx* ctx, double* G, double* g, double* H, double* h) {
+int lsspa_get_gram(lsspa_ctx* ctx, double* G, double* g, double* H, double* h) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
@@ -1256,6 +1365,8 @@ int lsspa_get_gram(lsspa_ctx* ctx, double* G, double* g, double* H, double* h) {
   if (H) HIPCHK(hipMemcpy2D(H, p * 8, ctx->H.ptr, pp * 8, p * 8, p, hipMemcpyDeviceToHost));
   if (h) HIPCHK(hipMemcpy(h, ctx->h.ptr, p * 8, hipMemcpyDeviceToHost));
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
 // device -> host copy of `count` work-matrix elements starting at element offset `off`, as doubles
@@ -1292,7 +1403,7 @@ static int factor_identity(lsspa_ctx* ctx, const int32_t* perm_or_null) {
   return LSSPA_OK;
 }
 
-int lsspa_full_fit(lsspa_ctx* ctx, double* theta, double* r_squared, int32_t* info) {
+int lsspa_full_fit(lsspa_ctx* ctx, double* theta, double* r_squared, int32_t* info) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
@@ -1323,9 +1434,11 @@ int lsspa_full_fit(lsspa_ctx* ctx, double* theta, double* r_squared, int32_t* in
     *r_squared = s;
   }
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_get_factors(lsspa_ctx* ctx, double* R_tr, double* q_tr, double* F_te, double* q_te) {
+int lsspa_get_factors(lsspa_ctx* ctx, double* R_tr, double* q_tr, double* F_te, double* q_te) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
@@ -1359,11 +1472,13 @@ int lsspa_get_factors(lsspa_ctx* ctx, double* R_tr, double* q_tr, double* F_te, 
     if (q_te) HIPCHK(hipMemcpy(q_te, ctx->ytil.ptr, sizeof(double) * m, hipMemcpyDeviceToHost));
   }
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
 // ---------------------------------------------------------------------------------------------
 int lsspa_lift_batch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t antithetical,
-                     double* lifts_out, int32_t accumulate) {
+                     double* lifts_out, int32_t accumulate) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   if (!perms || B < 1) return ctx->fail(LSSPA_ERR_ARG, "perms / B");
@@ -1376,11 +1491,13 @@ int lsspa_lift_batch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t an
   Lane* L = nullptr;
   TRY(lift_launch(ctx, perms, B, per, &L));
   return lift_collect(ctx, *L, 0, B, lifts_out, accumulate);
+} catch (...) {
+  return abi_caught(ctx);
 }
 
 // The two halves of lsspa_lift_batch, for callers that want a batch in flight while they decide what to do with
 // the previous one (the driver launches batch k+1 before it evaluates the stop rule on batch k).
-int lsspa_lift_launch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t antithetical, int32_t* ticket) {
+int lsspa_lift_launch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t antithetical, int32_t* ticket) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   if (!perms || B < 1 || !ticket) return ctx->fail(LSSPA_ERR_ARG, "perms / B / ticket");
@@ -1391,25 +1508,38 @@ int lsspa_lift_launch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t a
   TRY(lift_launch(ctx, perms, B, antithetical ? 2 : 1, &L));
   *ticket = (int32_t)(L - ctx->lanes);
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
 int lsspa_lift_collect(lsspa_ctx* ctx, int32_t ticket, int32_t first, int32_t count, double* lifts_out,
-                       int32_t accumulate) {
+                       int32_t accumulate) try {
   if (!ctx || ticket < 0 || ticket > 1 || first < 0) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
   return lift_collect(ctx, ctx->lanes[ticket], first, count, lifts_out, accumulate);
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_lift_discard(lsspa_ctx* ctx, int32_t ticket) {
+int lsspa_lift_discard(lsspa_ctx* ctx, int32_t ticket) try {
   if (!ctx || ticket < 0 || ticket > 1) return LSSPA_ERR_ARG;
   Lane& L = ctx->lanes[ticket];
   if (!L.in_flight) return ctx->fail(LSSPA_ERR_STATE, "no launched batch on this lane");
+  if (ctx->n_lanes == 2 && L.taken > 0) {
+    // part of the batch was collected: those statistics kernels, on the context's stream, still read this lane's
+    // lift vectors -- the lane's next launch (on its own stream) has to wait for them as after a full collect
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipEventRecord(L.ev_consumed, ctx->stream));
+    L.consumed_valid = true;
+  }
   L.in_flight = false;    // its kernels run to completion in stream order; nothing reads their output
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_get_info(lsspa_ctx* ctx, int32_t* info) {
+int lsspa_get_info(lsspa_ctx* ctx, int32_t* info) try {
   if (!ctx || !info) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
@@ -1417,24 +1547,30 @@ int lsspa_get_info(lsspa_ctx* ctx, int32_t* info) {
   HIPCHK(hipMemcpyAsync(info, ctx->info_d.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_stats_reset(lsspa_ctx* ctx) {
+int lsspa_stats_reset(lsspa_ctx* ctx) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
   return stats_reset(ctx);
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_stats_pending(lsspa_ctx* ctx, void** device_ptr, int64_t* count) {
+int lsspa_stats_pending(lsspa_ctx* ctx, void** device_ptr, int64_t* count) try {
   if (!ctx || !device_ptr || !count) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   *device_ptr = ctx->pend.ptr;
   *count = (int64_t)1 + ctx->p + (int64_t)ctx->p * ctx->p;
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_stats_merge(lsspa_ctx* ctx) {
+int lsspa_stats_merge(lsspa_ctx* ctx) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
@@ -1450,9 +1586,11 @@ int lsspa_stats_merge(lsspa_ctx* ctx) {
                           ctx->stream));
   ctx->pend_dirty = false;
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_stats_get(lsspa_ctx* ctx, int64_t* n, double* mean, double* cov_biased) {
+int lsspa_stats_get(lsspa_ctx* ctx, int64_t* n, double* mean, double* cov_biased) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
@@ -1468,9 +1606,11 @@ int lsspa_stats_get(lsspa_ctx* ctx, int64_t* n, double* mean, double* cov_biased
     for (size_t i = 0; i < p * p; ++i) cov_biased[i] *= inv;
   }
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_stats_set(lsspa_ctx* ctx, int64_t n, const double* mean, const double* cov_biased) {
+int lsspa_stats_set(lsspa_ctx* ctx, int64_t n, const double* mean, const double* cov_biased) try {
   if (!ctx || !mean || !cov_biased || n < 0) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
@@ -1485,10 +1625,12 @@ int lsspa_stats_set(lsspa_ctx* ctx, int64_t n, const double* mean, const double*
   HIPCHK(hipStreamSynchronize(ctx->stream));   // m2 / st are stack and heap temporaries
   ctx->pend_dirty = false;
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
 // ---------------------------------------------------------------------------------------------
-int lsspa_history_enable(lsspa_ctx* ctx, int64_t capacity) {
+int lsspa_history_enable(lsspa_ctx* ctx, int64_t capacity) try {
   if (!ctx || capacity < 0) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
@@ -1508,9 +1650,11 @@ int lsspa_history_enable(lsspa_ctx* ctx, int64_t capacity) {
   HIPCHK(hipMemsetAsync(ctx->draws.ptr, 0, ctx->draws.count * 8, ctx->stream));
   ctx->hist_cap = capacity;
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_history_get(lsspa_ctx* ctx, int64_t* count, double* lifts) {
+int lsspa_history_get(lsspa_ctx* ctx, int64_t* count, double* lifts) try {
   if (!ctx || !count) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   *count = ctx->hist_n;
@@ -1521,9 +1665,11 @@ int lsspa_history_get(lsspa_ctx* ctx, int64_t* count, double* lifts) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_history_append(lsspa_ctx* ctx, const double* lifts, int64_t rows) {
+int lsspa_history_append(lsspa_ctx* ctx, const double* lifts, int64_t rows) try {
   if (!ctx || rows < 0 || (rows > 0 && !lifts)) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   if (ctx->hist_cap == 0) return ctx->fail(LSSPA_ERR_STATE, "history is not enabled");
@@ -1532,9 +1678,11 @@ int lsspa_history_append(lsspa_ctx* ctx, const double* lifts, int64_t rows) {
   TRY(hist_append(ctx, lifts, rows, hipMemcpyHostToDevice));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_error_draws(lsspa_ctx* ctx, const double* xi, int64_t ld_xi, int64_t n_local, int64_t n_total) {
+int lsspa_error_draws(lsspa_ctx* ctx, const double* xi, int64_t ld_xi, int64_t n_local, int64_t n_total) try {
   if (!ctx || n_local < 0 || n_total < n_local || (n_local > 0 && (!xi || ld_xi < n_local)))
     return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
@@ -1561,17 +1709,21 @@ int lsspa_error_draws(lsspa_ctx* ctx, const double* xi, int64_t ld_xi, int64_t n
   HIPCHK(launch_error_draws(ctx->xi_d.ptr, (int)n_pad, ctx->hist.ptr, ldh, (int)n_pad, ctx->mean.ptr, scale,
                             ctx->p, ctx->draws.ptr, ldh, ctx->stream));
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_error_buffer(lsspa_ctx* ctx, void** device_ptr, int64_t* count) {
+int lsspa_error_buffer(lsspa_ctx* ctx, void** device_ptr, int64_t* count) try {
   if (!ctx || !device_ptr || !count) return LSSPA_ERR_ARG;
   if (ctx->hist_cap == 0) return ctx->fail(LSSPA_ERR_STATE, "history is not enabled");
   *device_ptr = ctx->draws.ptr;
   *count = (int64_t)ERR_DRAWS * ctx->ldh();
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_error_quantiles(lsspa_ctx* ctx, double* feature_errors, double* overall_error) {
+int lsspa_error_quantiles(lsspa_ctx* ctx, double* feature_errors, double* overall_error) try {
   if (!ctx || !feature_errors || !overall_error) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   if (ctx->hist_cap == 0) return ctx->fail(LSSPA_ERR_STATE, "history is not enabled");
@@ -1588,20 +1740,24 @@ int lsspa_error_quantiles(lsspa_ctx* ctx, double* feature_errors, double* overal
   std::copy(out.begin(), out.begin() + p, feature_errors);
   *overall_error = out[p];
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Collectives: RCCL on the context's stream, so kernels -> all-reduce -> merge need no host synchronisation.
-int lsspa_comm_unique_id(uint8_t* id128) {
+int lsspa_comm_unique_id(uint8_t* id128) try {
   std::string err;
   if (comm_unique_id(id128, err) != 0) {
     g_create_error = err;
     return LSSPA_ERR_HIP;
   }
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(nullptr);
 }
 
-int lsspa_comm_init(lsspa_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world) {
+int lsspa_comm_init(lsspa_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!id128 || world < 1 || rank < 0 || rank >= world) return ctx->fail(LSSPA_ERR_ARG, "need an id and 0 <= rank < world");
   if (ctx->comm) return ctx->fail(LSSPA_ERR_STATE, "this context already has a communicator");
@@ -1609,9 +1765,11 @@ int lsspa_comm_init(lsspa_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t 
   std::string err;
   if (comm_create(id128, rank, world, ctx->device, &ctx->comm, err) != 0) return ctx->fail(LSSPA_ERR_HIP, err.c_str());
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_comm_destroy(lsspa_ctx* ctx) {
+int lsspa_comm_destroy(lsspa_ctx* ctx) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->comm) return LSSPA_OK;
   HIPCHK(hipSetDevice(ctx->device));
@@ -1619,13 +1777,17 @@ int lsspa_comm_destroy(lsspa_ctx* ctx) {
   comm_destroy(ctx->comm);
   ctx->comm = nullptr;
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_comm_info(const lsspa_ctx* ctx, int32_t* rank, int32_t* world) {
+int lsspa_comm_info(const lsspa_ctx* ctx, int32_t* rank, int32_t* world) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (rank) *rank = comm_rank(ctx->comm);
   if (world) *world = comm_world(ctx->comm);
   return ctx->comm ? LSSPA_OK : LSSPA_ERR_STATE;
+} catch (...) {
+  return abi_caught(const_cast<lsspa_ctx*>(ctx));
 }
 
 static int allreduce_buffer(lsspa_ctx* ctx, double* buf, size_t count) {
@@ -1634,7 +1796,7 @@ static int allreduce_buffer(lsspa_ctx* ctx, double* buf, size_t count) {
   return LSSPA_OK;
 }
 
-int lsspa_stats_allreduce(lsspa_ctx* ctx) {
+int lsspa_stats_allreduce(lsspa_ctx* ctx) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   if (!ctx->comm) return ctx->fail(LSSPA_ERR_STATE, "no communicator: call lsspa_comm_init first");
@@ -1648,9 +1810,11 @@ int lsspa_stats_allreduce(lsspa_ctx* ctx) {
   TRY(allreduce_buffer(ctx, ctx->pack.ptr, cnt));
   HIPCHK(launch_stats_unpack(ctx->pack.ptr, ctx->pend.ptr, p, ctx->stream));
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_reduce_allreduce(lsspa_ctx* ctx) {
+int lsspa_reduce_allreduce(lsspa_ctx* ctx) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->reduce_open) return ctx->fail(LSSPA_ERR_STATE, "no partial reduction in progress");
   if (!ctx->comm) return ctx->fail(LSSPA_ERR_STATE, "no communicator: call lsspa_comm_init first");
@@ -1658,18 +1822,22 @@ int lsspa_reduce_allreduce(lsspa_ctx* ctx) {
   const size_t P1pad = (size_t)round_up(ctx->p + 1, 128);
   ProfScope ps(ctx, LSSPA_K_COMM);
   return allreduce_buffer(ctx, ctx->Cred.ptr, 2 * P1pad * P1pad);
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_error_allreduce(lsspa_ctx* ctx) {
+int lsspa_error_allreduce(lsspa_ctx* ctx) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (ctx->hist_cap == 0) return ctx->fail(LSSPA_ERR_STATE, "history is not enabled");
   if (!ctx->comm) return ctx->fail(LSSPA_ERR_STATE, "no communicator: call lsspa_comm_init first");
   HIPCHK(hipSetDevice(ctx->device));
   ProfScope ps(ctx, LSSPA_K_COMM);
   return allreduce_buffer(ctx, ctx->draws.ptr, (size_t)ERR_DRAWS * ctx->ldh());
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_comm_sum_i64(lsspa_ctx* ctx, int64_t* values, int32_t count) {
+int lsspa_comm_sum_i64(lsspa_ctx* ctx, int64_t* values, int32_t count) try {
   if (!ctx || !values || count < 1) return LSSPA_ERR_ARG;
   if (!ctx->comm) return ctx->fail(LSSPA_ERR_STATE, "no communicator: call lsspa_comm_init first");
   HIPCHK(hipSetDevice(ctx->device));
@@ -1681,9 +1849,11 @@ int lsspa_comm_sum_i64(lsspa_ctx* ctx, int64_t* values, int32_t count) {
   HIPCHK(hipMemcpyAsync(values, ctx->ibuf.ptr, (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_comm_allgather(lsspa_ctx* ctx, const double* send, int64_t count, double* recv) {
+int lsspa_comm_allgather(lsspa_ctx* ctx, const double* send, int64_t count, double* recv) try {
   if (!ctx || count < 0 || (count > 0 && (!send || !recv))) return LSSPA_ERR_ARG;
   if (!ctx->comm) return ctx->fail(LSSPA_ERR_STATE, "no communicator: call lsspa_comm_init first");
   if (count == 0) return LSSPA_OK;
@@ -1699,27 +1869,33 @@ int lsspa_comm_allgather(lsspa_ctx* ctx, const double* send, int64_t count, doub
   HIPCHK(hipMemcpyAsync(recv, d_recv, world * cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
 // ---------------------------------------------------------------------------------------------
-int lsspa_profile_enable(lsspa_ctx* ctx, int32_t on) {
+int lsspa_profile_enable(lsspa_ctx* ctx, int32_t on) try {
   if (!ctx) return LSSPA_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   TRY(prof_collect(ctx));
   ctx->prof_on = on != 0;
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_profile_get(lsspa_ctx* ctx, int32_t k, double* total_ms, int64_t* launches) {
+int lsspa_profile_get(lsspa_ctx* ctx, int32_t k, double* total_ms, int64_t* launches) try {
   if (!ctx || k < 0 || k >= LSSPA_K_COUNT) return LSSPA_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   TRY(prof_collect(ctx));
   if (total_ms) *total_ms = ctx->prof_ms[k];
   if (launches) *launches = ctx->prof_n[k];
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_profile_reset(lsspa_ctx* ctx) {
+int lsspa_profile_reset(lsspa_ctx* ctx) try {
   if (!ctx) return LSSPA_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   TRY(prof_collect(ctx));
@@ -1728,28 +1904,36 @@ int lsspa_profile_reset(lsspa_ctx* ctx) {
     ctx->prof_n[k] = 0;
   }
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
 // ---------------------------------------------------------------------------------------------
-int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags) {
+int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags) try {
   if (!ctx) return LSSPA_ERR_ARG;
   ctx->flags = flags;
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_debug_pack_from(lsspa_ctx* ctx, int32_t p_min) {
+int lsspa_debug_pack_from(lsspa_ctx* ctx, int32_t p_min) try {
   if (!ctx || p_min < 1) return LSSPA_ERR_ARG;
   ctx->pack_from_p = p_min;
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_debug_fail_alloc(lsspa_ctx* ctx, int32_t nth) {
+int lsspa_debug_fail_alloc(lsspa_ctx* ctx, int32_t nth) try {
   if (!ctx || nth < 0) return LSSPA_ERR_ARG;
   ctx->fail_alloc_in = nth;
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_set_precision(lsspa_ctx* ctx, int32_t dtype) {
+int lsspa_set_precision(lsspa_ctx* ctx, int32_t dtype) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (dtype != LSSPA_F64 && dtype != LSSPA_F32) return ctx->fail(LSSPA_ERR_ARG, "dtype");
   HIPCHK(hipSetDevice(ctx->device));
@@ -1761,9 +1945,11 @@ int lsspa_set_precision(lsspa_ctx* ctx, int32_t dtype) {
     free_workspace(ctx);   // re-created for the new element size on demand
   }
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
-int lsspa_mfma_probe(lsspa_ctx* ctx, const double* A16x4, const double* B4x16, double* D16x16, int32_t dtype) {
+int lsspa_mfma_probe(lsspa_ctx* ctx, const double* A16x4, const double* B4x16, double* D16x16, int32_t dtype) try {
   if (!ctx || !A16x4 || !B4x16 || !D16x16) return LSSPA_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   DevBuf<double> buf;
@@ -1776,10 +1962,12 @@ int lsspa_mfma_probe(lsspa_ctx* ctx, const double* A16x4, const double* B4x16, d
   dev_free(buf);
   if (e != hipSuccess) return ctx->fail(LSSPA_ERR_HIP, "mfma probe", e);
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
 int lsspa_debug_factor(lsspa_ctx* ctx, const int32_t* perm, double* L, double* Lt, double* V, int32_t* p_pad,
-                       int32_t* m_pad, int32_t* v_rows) {
+                       int32_t* m_pad, int32_t* v_rows) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
@@ -1813,6 +2001,8 @@ int lsspa_debug_factor(lsspa_ctx* ctx, const int32_t* perm, double* L, double* L
         V[r * mp + c] = (ctx->tri && !(ctx->flags & 4) && r < (c / 128) * 128) ? 0.0 : tmp[r * ldv + c];
   }
   return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
 }
 
 }  // extern "C"

@@ -22,6 +22,8 @@ struct Rccl {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;        // optional: what RCCL itself reports
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   std::string load_error;
 };
 
@@ -52,6 +54,8 @@ void load_rccl() {
   g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(sym("ncclAllReduce"));
   g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(sym("ncclAllGather"));
   g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
+  g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(g_rccl.handle, "ncclCommCount"));
+  g_rccl.CommUserRank = reinterpret_cast<decltype(g_rccl.CommUserRank)>(dlsym(g_rccl.handle, "ncclCommUserRank"));
 }
 
 bool rccl_ready(std::string& err) {
@@ -120,8 +124,20 @@ void comm_destroy(Comm* c) {
   delete c;
 }
 
-int comm_rank(const Comm* c) { return c ? c->rank : 0; }
-int comm_world(const Comm* c) { return c ? c->world : 1; }
+// rank / size as the RCCL communicator reports them (the numbers it was made with are the fallback for a
+// librccl without the two queries): "did RCCL see N ranks" is answered by RCCL, not by our own bookkeeping
+int comm_rank(const Comm* c) {
+  if (!c) return 0;
+  int r = c->rank;
+  if (c->comm && g_rccl.CommUserRank && g_rccl.CommUserRank(c->comm, &r) != ncclSuccess) r = c->rank;
+  return r;
+}
+int comm_world(const Comm* c) {
+  if (!c) return 1;
+  int n = c->world;
+  if (c->comm && g_rccl.CommCount && g_rccl.CommCount(c->comm, &n) != ncclSuccess) n = c->world;
+  return n;
+}
 
 int comm_allreduce_f64(Comm* c, double* buf, size_t count, hipStream_t st, std::string& err) {
   if (!c || !buf) {

@@ -124,15 +124,35 @@ def _load_checkpoint(path, comm, expect):
     """The state to resume from, or None.  With several ranks the ranks first agree on it: each reports the sample
     counts of the (at most two) generations it holds and all resume from the largest count EVERY rank holds;
     if there is none -- a rank without a file next to ranks with files, files of different runs -- every rank
-    raises the same error instead of running chunks that no longer pair up in the collectives."""
+    raises the same error instead of running chunks that no longer pair up in the collectives.
+
+    Nothing raises before that exchange: a rank whose own file is unreadable or belongs to another run (other
+    seed, data, sampler ...) reports it through the collective, and then ALL ranks raise -- a rank raising alone
+    would leave the others waiting in the all-reduce.  A stale or foreign ``.prev`` next to a valid file is
+    ignored (it is only ever the fallback generation)."""
     target = _ckpt_path(path, comm)
-    gens = [st for st in (_read_checkpoint(target, expect), _read_checkpoint(target + ".prev", expect))
-            if st is not None]
+    gens, target_problem = [], None
+    for k, f in enumerate((target, target + ".prev")):
+        try:
+            st = _read_checkpoint(f, expect)
+        except Exception as exc:     # unreadable archive, missing key, version or ident mismatch
+            st = None
+            if k == 0:
+                target_problem = f"{exc}"
+        if st is not None:
+            gens.append(st)
     if comm.world == 1:
+        if target_problem is not None:
+            raise ValueError(target_problem)
         return gens[0] if gens else None
-    mine = ([int(st["n"]) for st in gens] + [-1, -1])[:2]
+    mine = ([int(st["n"]) for st in gens] + [-1, -1])[:2] + [0 if target_problem is None else 1]
     table = comm.gather_ints(mine)
-    held = [set(v for v in row if v >= 0) for row in table]
+    bad = [r for r, row in enumerate(table) if row[2]]
+    if bad:
+        raise ValueError(f"checkpoint {path}: the file of rank(s) {bad} is unreadable or was written by another run"
+                         + (f" ({target_problem})" if target_problem is not None else "")
+                         + "; remove the files to start over")
+    held = [set(v for v in row[:2] if v >= 0) for row in table]
     if not any(held):
         return None
     common = set.intersection(*held)
@@ -182,14 +202,20 @@ def prepare_sampling(p, *, max_samples, batch_size, seed, perms, antithetical, m
 
 def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms, antithetical,
                   return_attribution_history, method, error_estimator, comm=None, chunk_cap=None,
-                  checkpoint=None, prepared=None, lookahead=1):
+                  checkpoint=None, prepared=None, lookahead=1, timings=None):
     """The sampling loop on an engine whose problem is already loaded.  Returns
     (attribution, attribution_errors, overall_error, error_history, attribution_history, n).
 
     checkpoint: path of a state file.  Written after every error check (sample count, running mean and
     covariance, generator state, error history, the lift history the thin-form estimators need); if it
     exists when the call starts, the run continues from it -- the orderings, the estimator's draws and
-    therefore every later number are those of the uninterrupted run."""
+    therefore every later number are those of the uninterrupted run.
+
+    timings: optional dict; receives the host seconds spent drawing orderings ('sampler'), in the estimator calls
+    ('estimator', reads of the statistics included) and in everything else of the loop ('sampling')."""
+    import time as _time
+    t_loop0 = _time.perf_counter()
+    t_sampler = t_estimator = 0.0
     comm = comm or _Comm()
     if prepared is None:
         prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
@@ -216,8 +242,7 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
     ident = {"p": p, "seed": seed, "method": str(method), "batch_size": batch_size,
              "antithetical": bool(antithetical), "error_estimator": error_estimator, "world": comm.world}
     if checkpoint is not None:
-        if return_attribution_history:
-            raise ValueError("checkpoint= cannot be combined with return_attribution_history")
+        ident["history"] = bool(return_attribution_history)
         ident["precision"] = str(getattr(engine, "precision", "float64"))
         ident["data"] = _data_fingerprint(engine)
         st = _load_checkpoint(checkpoint, comm, ident)
@@ -229,6 +254,9 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
             source.skip(i)
             err_hist = [float(v) for v in st["error_history"]]
             feat_err, total_err = st["feature_errors"], float(st["overall_error"])
+            if return_attribution_history:
+                hist_parts.append(st["attribution_history"])
+                hist_sum = st["history_sum"]
             if error_estimator == "lowrank":
                 lift_parts.append(st["lifts"])
             elif on_device:
@@ -241,6 +269,9 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
         state = dict(ident, version=_CKPT_VERSION, n=n, rng_state=json.dumps(rng.bit_generator.state),
                      error_history=np.array(err_hist), feature_errors=feat_err, overall_error=total_err)
         _, state["mean"], state["cov_biased"] = engine.stats(want_cov=True)
+        if return_attribution_history:
+            state["attribution_history"] = np.concatenate(hist_parts) if hist_parts else np.zeros((0, p))
+            state["history_sum"] = hist_sum
         if error_estimator == "lowrank":
             state["lifts"] = np.concatenate(lift_parts) if lift_parts else np.zeros((0, p))
         elif on_device:
@@ -248,8 +279,9 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
             state["local_idx"] = np.concatenate(local_idx) if local_idx else np.zeros(0, dtype=np.int64)
         _save_checkpoint(checkpoint, comm, state)
 
-    def estimate_now(n):
-        nonlocal feat_err, total_err
+    def estimate_now(n, cov_b=None):
+        nonlocal feat_err, total_err, t_estimator
+        t_e0 = _time.perf_counter()
         with np.errstate(divide="ignore", invalid="ignore"):
             if error_estimator == "lowrank":
                 centred = np.concatenate(lift_parts) - mean
@@ -262,16 +294,21 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
                 comm.allreduce_draws(engine)
                 feat_err, total_err = engine.error_quantiles()
             else:
-                _, _, cov_b = engine.stats(want_cov=True)
+                if cov_b is None:
+                    _, _, cov_b = engine.stats(want_cov=True)
                 feat_err, total_err = error_estimates(rng, cov_b * n / (n - 1) / n)
         err_hist.append(total_err)
+        t_estimator += _time.perf_counter() - t_e0
 
     # lookahead > 1 (QMC samplers only: their stream is nobody else's): the orderings of several chunks are launched
     # as ONE batch -- a chunk of batch_size / world samples may fill a fraction of the GPU -- and then accumulated,
     # all-reduced and checked chunk by chunk in the reference's order (ls_spa/ls_spa.py:212-230).  When the stop
-    # rule fires, the chunks launched beyond it are dropped: nothing of them ever reaches the statistics.  The next
-    # group is launched BEFORE the rule is evaluated on the last chunk of the current one, so the GPU works while
-    # the collective, the host's estimate and the decision run.
+    # rule fires, the chunks launched beyond it are dropped: nothing of them ever reaches the statistics.  With a
+    # host-side estimator the next group is launched AFTER the statistics of the group's last chunk have been read
+    # back and BEFORE the host's estimate and decision, so the GPU works while the host computes (a stop then
+    # wastes up to k chunks of GPU work, which only the final read-back waits for); the engine has one stream, so
+    # with the device-side estimator, whose kernels would queue behind a new group, the next group is launched
+    # after the decision instead (nothing wasted, nothing overlapped).
     if lookahead == "auto":
         # automatic: a chunk of fewer than 64 samples per rank leaves most of an MI355X idle (§6 of DESIGN.md) --
         # launch as many chunks together as make up 64, eight at most
@@ -281,6 +318,7 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
     queue = []
 
     def refill(i_now):
+        nonlocal t_sampler
         entries, cursor = [], i_now
         for _ in range(group):
             if cursor >= max_samples:
@@ -289,7 +327,9 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
             want = min(target, max_samples) - cursor
             if chunk_cap:
                 want = min(want, chunk_cap)
+            t_s0 = _time.perf_counter()
             chunk = source.take(want)
+            t_sampler += _time.perf_counter() - t_s0
             if len(chunk) == 0:
                 break
             entries.append([chunk, chunk[comm.rank::comm.world], want])   # dealt round-robin over the ranks
@@ -345,11 +385,13 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
         if n_new < want and not chunk_cap:
             stop = True  # the source ran dry inside a chunk
         check = estimate and (i % batch_size == 0 or i == max_samples - 1)
-        if group > 1 and check and not queue and not stop and i < max_samples:
-            refill(i)      # in flight while the stop rule below is evaluated
         if check:
-            _, mean, _ = engine.stats(want_cov=False)
-            estimate_now(i)
+            t_e0 = _time.perf_counter()
+            _, mean, cov_now = engine.stats(want_cov=error_estimator == "reference")
+            t_estimator += _time.perf_counter() - t_e0
+            if group > 1 and not on_device and not queue and not stop and i < max_samples:
+                refill(i)      # in flight while the host evaluates the stop rule below
+            estimate_now(i, cov_now)
             pending = False
             if checkpoint is not None:
                 save_now(i)
@@ -366,6 +408,10 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
     history = None
     if return_attribution_history:
         history = np.concatenate(hist_parts) if hist_parts else np.zeros((0, p))
+    if timings is not None:
+        timings["sampler"] = timings.get("sampler", 0.0) + t_sampler
+        timings["estimator"] = timings.get("estimator", 0.0) + t_estimator
+        timings["sampling"] = timings.get("sampling", 0.0) + (_time.perf_counter() - t_loop0) - t_sampler - t_estimator
     return mean, feat_err, total_err, np.array(err_hist), history, n
 
 
@@ -373,7 +419,7 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
            tolerance=1e-2, seed=42, perms=None, antithetical=True, return_attribution_history=False, *,
            method=None, num_batches=None, return_history=None, device=0, error_estimator="reference",
            precision="float64", row_sharded=False, checkpoint=None, comm=None, lookahead=1, _engine=None,
-           _comm=None):
+           _comm=None, _timings=None):
     """Estimates the Shapley attribution of the out-of-sample R^2 of a least-squares fit.
 
     Positional parameters, defaults and behaviour follow cvxgrp/ls-spa
@@ -394,8 +440,8 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         (same data, seed and sampler required); with several ranks every rank keeps ``<path>.rank<r>``.
     lookahead:  QMC samplers ('argsort', 'permutohedron') only.  k > 1 launches the orderings of k chunks as one GPU
         batch (a chunk of batch_size / n_gpus samples may fill a fraction of the GPU), accumulates and checks them
-        chunk by chunk in the reference's order and drops the chunks beyond a stop.  Same results; at most k - 1
-        chunks of wasted work at the end of a run.  'auto': 1 when a rank's chunk has 64 samples or more, else as
+        chunk by chunk in the reference's order and drops the chunks beyond a stop.  Same results; at most k
+        chunks of wasted GPU work at the end of a run (none with error_estimator='device').  'auto': 1 when a rank's chunk has 64 samples or more, else as
         many chunks as make up 64 samples, eight at most.  Default 1 (every chunk its own launch).
     comm:  several GPUs, one process each: the communicator every rank passes -- ``NativeComm.from_env()``
         (RCCL through the C ABI, no PyTorch) or ``TorchComm()`` (torch.distributed: RCCL, or gloo on CPU in
@@ -421,12 +467,21 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
     if error_estimator not in ("reference", "lowrank", "device"):
         raise ValueError("error_estimator must be 'reference', 'lowrank' or 'device'")
 
+    import time as _time
+    tm = _timings if _timings is not None else {}   # bench.py's e2e_breakdown: host seconds per phase of this call
+
+    def lap(key, t0):
+        tm[key] = tm.get(key, 0.0) + (_time.perf_counter() - t0)
+        return _time.perf_counter()
+
     comm = comm if comm is not None else _comm
     engine = _engine
     owns = engine is None
+    t0 = _time.perf_counter()
     if owns:
         from ._engine import HipEngine
         engine = HipEngine(device)
+    t0 = lap("engine_create", t0)
     try:
         if comm is not None and hasattr(comm, "bind"):
             comm.bind(engine)      # RCCL communicator on this engine's GPU and stream (collective)
@@ -434,18 +489,22 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
             engine.set_precision(precision)
         if lookahead != "auto" and int(lookahead) < 1:
             raise ValueError("lookahead must be >= 1 or 'auto'")
+        t0 = lap("setup", t0)
         prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
                                     antithetical=antithetical, method=method)
+        t0 = lap("sampler_start", t0)
         if row_sharded:
             engine.load_data_sharded(X_train, X_test, y_train, y_test, reg, comm or _Comm(),
                                      shard_test=row_sharded != "train")
         else:
             engine.load_data(X_train, X_test, y_train, y_test, reg)
+        t0 = lap("reduction_h2d_gram", t0)
         attribution, feat_err, total_err, err_hist, history, _ = run_estimator(
             engine, p, max_samples=max_samples, batch_size=batch_size, tolerance=tolerance, seed=seed,
             perms=perms, antithetical=antithetical, return_attribution_history=return_attribution_history,
             method=method, error_estimator=error_estimator, comm=comm, checkpoint=checkpoint, prepared=prepared,
-            lookahead=lookahead)
+            lookahead=lookahead, timings=tm)
+        t0 = _time.perf_counter()
         theta, r_squared, info = engine.full_fit()
         if info or engine.info():
             warnings.warn("a permuted Gram matrix was not numerically positive definite; the attribution "
@@ -461,11 +520,14 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
             else:
                 pred = X_test.astype(np.float64) @ theta
                 r_squared = float((2.0 * (pred @ y_test) - pred @ pred) / yy)
+        t0 = lap("final_fit", t0)
     finally:
+        t0 = _time.perf_counter()
         if owns:
             if comm is not None and hasattr(comm, "close"):
                 comm.close()       # the communicator lives on the engine's context
             engine.close()
+        lap("teardown", t0)
     return ShapleyResults(attribution=attribution, theta=theta, overall_error=total_err,
                           attribution_errors=feat_err, r_squared=r_squared, error_history=err_hist,
                           attribution_history=history)

@@ -31,6 +31,33 @@ def golden():
     return load
 
 
+def large_problem(seed, p, n, m):
+    """The seeded data of the large-p fixtures (tests/golden/make_golden_large.py: same stream, regenerated here
+    instead of stored)."""
+    rng = np.random.default_rng(seed)
+    X_tr = rng.standard_normal((n, p))
+    X_te = rng.standard_normal((m, p))
+    w = rng.standard_normal(p) / np.sqrt(p)
+    return X_tr, X_te, X_tr @ w + rng.standard_normal(n), X_te @ w + rng.standard_normal(m)
+
+
+@pytest.fixture(scope="session")
+def large_case(golden):
+    """name -> (fixture, data); the regenerated data are checked against the head values the fixture keeps."""
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            g = golden(name)
+            d = large_problem(int(g["seed"]), int(g["p"]), int(g["N"]), int(g["M"]))
+            np.testing.assert_array_equal(d[3][:8], g["y_test_head"])
+            np.testing.assert_array_equal(d[0][0, :8], g["X_train_head"])
+            cache.clear()        # one data set at a time: p = 5000 is 2 x 240 MB
+            cache[name] = (g, d)
+        return cache[name]
+    return get
+
+
 def _gpu_available():
     try:
         import torch

@@ -521,3 +521,152 @@ def test_c5_full_size_from_host_arrays():
     # relevant features carry the attribution: largest |theta| get the largest shares
     top = np.argsort(-np.abs(th))[:50]
     assert res.attribution[top].mean() > 5 * res.attribution.mean()
+
+
+# ------------------------------------------------------------------ large p pinned to the REFERENCE itself
+@pytest.mark.parametrize("name", ["large_p1000", "large_p5000"])
+def test_large_p_against_reference_fixture(large_case, name):
+    """The HIP path at the benchmark feature counts against lift vectors produced by the reference's own
+    reduce_data + square_shapley (ls_spa/ls_spa.py:256-318; tests/golden/make_golden_large.py) -- not against the
+    oracle: p = 1000 (C3 / C4; eight orderings + the reference driver's attribution on them) and p = 5000 (C5; one
+    ordering and its reverse).  fp64 <= 1e-10, fp32 per-ordering work <= 1e-4, theta 1e-9 relative."""
+    from ls_spa._engine import HipEngine
+    g, d = large_case(name)
+    p, reg = int(g["p"]), float(g["reg"])
+    orders = g["orders"].astype(np.int32)
+    eng = HipEngine(0)
+    try:
+        eng.load_data(*d, reg)
+        assert eng.y_norm_sq == pytest.approx(float(g["y_norm_sq"]), rel=1e-13)
+        got = eng.run_batch(orders, False, want_lifts=True, accumulate=False)
+        np.testing.assert_allclose(got, g["lifts"], rtol=0, atol=1e-10)
+        theta, r2, info = eng.full_fit()
+        assert info == 0
+        np.testing.assert_allclose(theta, g["theta"], rtol=1e-9, atol=1e-12)
+        assert abs(r2 - float(g["r_squared"])) < 1e-11
+        eng.set_precision("float32")
+        got32 = eng.run_batch(orders, False, want_lifts=True, accumulate=False)
+        np.testing.assert_allclose(got32, g["lifts"], rtol=0, atol=1e-4)
+    finally:
+        eng.close()
+    if name == "large_p1000":
+        res = ls_spa(*d, reg=reg, perms=g["orders"].astype(np.int64), batch_size=4, tolerance=0.0)
+        np.testing.assert_allclose(res.attribution, g["attribution"], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(res.theta, g["drv_theta"], rtol=1e-9, atol=1e-12)
+        assert abs(res.r_squared - float(g["drv_r_squared"])) < 1e-11
+
+
+def test_feature_count_beyond_64kb_of_gather_lds():
+    """p = 6000: the gather's row + ordering staging is 72 KB, past the 64 KB a kernel gets by default (the limit
+    that used to surface as hipErrorInvalidValue at the first batch; C5 sat 7 % under it).  One ordering against
+    the oracle; a p beyond what 160 KB of LDS hold is refused by lsspa_reduce, by name."""
+    from ls_spa._engine import HipEngine
+    p, n = 6000, 6400
+    d = O.gaussian_workload(p, n, n, seed=6)
+    R, F, q, qt = O.reduce(*d, 1e-3)
+    yy = float(np.linalg.norm(d[3]) ** 2)
+    perm = np.random.default_rng(60).permutation(p)
+    want = O.ordering_lift(R, F, q, qt, yy, perm)
+    eng = HipEngine(0)
+    try:
+        eng.load_data(*d, 1e-3)
+        got = eng.run_batch(perm[None, :].astype(np.int32), True, want_lifts=True, accumulate=False)[0]
+        want_pair = 0.5 * (want + O.ordering_lift(R, F, q, qt, yy, perm[::-1]))
+        np.testing.assert_allclose(got, want_pair, rtol=0, atol=1e-10)
+        theta, _, info = eng.full_fit()            # the back-substitution keeps p doubles in LDS too
+        assert info == 0
+        np.testing.assert_allclose(theta, np.linalg.lstsq(R, q, rcond=None)[0], rtol=1e-8, atol=1e-11)
+        # beyond the supported count: refused at the reduction, with a message that names p
+        big = 13568
+        z = np.zeros((big, big), dtype=np.float32)
+        y = np.ones(big, dtype=np.float32)
+        with pytest.raises(ValueError, match=f"p = {big} features exceeds"):
+            eng.load_data(z, z, y, y, 0.0)
+    finally:
+        eng.close()
+
+
+# ------------------------------------------------------------------ streamed reduction: page-locking of caller memory
+def test_streamed_reduction_pinning_corner_cases():
+    """lsspa_reduce from host arrays, through the C ABI, in the three situations the round-2 review listed for the
+    abort once seen in this path: (i) X and y carved out of ONE buffer so that they share pages, each >= 8 MB;
+    (ii) arrays the caller has already page-locked; (iii) a strided X (ld > p) whose last row ends exactly at the end
+    of a memory mapping, so that n * ld elements would reach past it.  Each must give the Gram matrices of the plain
+    call, and leave the caller's memory usable (still registered in (ii))."""
+    import ctypes as C
+    import mmap
+    from ls_spa import _native as N
+    from ls_spa._engine import HipEngine
+    import torch
+    p, n = 640, 4200                      # X: 4200 x 640 x 8 B = 21.5 MB per side
+    rng = np.random.default_rng(33)
+    eng = HipEngine(0)
+    lib = eng._lib
+
+    def reduce_host(Xa, ya, Xe, ye, ld):
+        eng._check(lib.lsspa_reduce(eng._h, Xa.ctypes.data, ld, ya.ctypes.data, n, Xe.ctypes.data, ld,
+                                    ye.ctypes.data, n, p, 0.0, N.F64, N.HOST))
+        eng._refresh_dims()
+        return eng.gram()
+
+    try:
+        # reference result: well-separated, aligned arrays
+        Xa, Xe = rng.standard_normal((n, p)), rng.standard_normal((n, p))
+        ya, ye = rng.standard_normal(n), rng.standard_normal(n)
+        base = reduce_host(Xa, ya, Xe, ye, p)
+        np.testing.assert_allclose(base[0], Xa.T @ Xa / n, rtol=0, atol=1e-12)
+
+        # (i) one buffer: [pad | X_train | y_train (>= 8 MB: padded with unused tail) | X_test | y_test], no alignment
+        ny = (8 << 20) // 8 + 3            # y blocks of >= 8 MB of which the first n entries are used
+        total = 5 + 2 * n * p + 2 * ny
+        buf = np.empty(total + 1)[1:]      # odd offset: base not even 16-byte aligned
+        o = 5
+        Xa1 = buf[o:o + n * p].reshape(n, p); o += n * p
+        ya1 = buf[o:o + ny]; o += ny
+        Xe1 = buf[o:o + n * p].reshape(n, p); o += n * p
+        ye1 = buf[o:o + ny]
+        Xa1[:], Xe1[:], ya1[:n], ye1[:n] = Xa, Xe, ya, ye
+        ya1[n:], ye1[n:] = 7.0, 7.0
+        assert Xa1.ctypes.data % 4096 and (Xa1.ctypes.data + Xa1.nbytes) // 4096 == ya1.ctypes.data // 4096
+        got = reduce_host(Xa1, ya1, Xe1, ye1, p)
+        for a, b in zip(got, base):
+            np.testing.assert_array_equal(a, b)
+        assert ya1[n] == 7.0 and np.array_equal(Xa1, Xa)        # untouched
+
+        # (ii) caller-pinned arrays (hipHostMalloc'ed by torch): left alone, still pinned afterwards
+        tXa, tXe = torch.from_numpy(Xa).pin_memory(), torch.from_numpy(Xe).pin_memory()
+        got = reduce_host(tXa.numpy(), ya, tXe.numpy(), ye, p)
+        for a, b in zip(got, base):
+            np.testing.assert_array_equal(a, b)
+        assert tXa.is_pinned() and tXe.is_pinned()
+        dev = tXa.to("cuda:0", non_blocking=True)               # the pinned block still serves its owner
+        torch.cuda.synchronize()
+        assert torch.equal(dev.cpu(), tXa)
+        del dev, tXa, tXe
+
+        # (iii) ld > p with the array's last element on the last bytes of a mapping
+        ld = p + 24
+        need = ((n - 1) * ld + p) * 8
+        size = -(-need // mmap.PAGESIZE) * mmap.PAGESIZE
+        maps = [mmap.mmap(-1, size + mmap.PAGESIZE) for _ in range(2)]
+        views = []
+        for m in maps:
+            whole = np.frombuffer(m, dtype=np.uint8)
+            # fence the page behind the array's end: those bytes are not ours to read, let alone to page-lock
+            addr = whole.ctypes.data
+            libc = C.CDLL(None, use_errno=True)
+            assert libc.mprotect(C.c_void_p(addr + size), C.c_size_t(mmap.PAGESIZE), 0) == 0     # PROT_NONE
+            flat = np.frombuffer(m, dtype=np.float64, count=size // 8)[(size - need) // 8:]
+            views.append(np.lib.stride_tricks.as_strided(flat, shape=(n, p), strides=(ld * 8, 8)))
+        views[0][:], views[1][:] = Xa, Xe
+        got = reduce_host(views[0], ya, views[1], ye, ld)
+        for a, b in zip(got, base):
+            np.testing.assert_array_equal(a, b)
+        # flag 4096 (never page-lock) gives the same bits: the pinning is transport only
+        eng.set_flags(4096)
+        got = reduce_host(Xa1, ya1, Xe1, ye1, p)
+        eng.set_flags(0)
+        for a, b in zip(got, base):
+            np.testing.assert_array_equal(a, b)
+    finally:
+        eng.close()

@@ -498,3 +498,114 @@ def test_bench_helpers_follow_the_baseline_recipe():
     assert bench.algorithmic_flops("strip", p, n_ord, True, 1) == pytest.approx(p ** 3 / 3 * n_ord)
     assert bench.algorithmic_flops("chol_panel", p, n_ord, True, 7) == pytest.approx(p ** 3 / 3 * 2 * n_ord / 7)
     assert bench.algorithmic_flops("small_p", 100, n_ord, True, 1) == pytest.approx(100 ** 3 * n_ord)
+
+
+def _bench_path():
+    import os
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the parent starts two ranks of itself with a
+    consistent rendezvous environment (before it imports torch or touches HIP: the ranks stop at a stub that reports
+    what they were given), relays rank 0's single line and exits 0; if a rank fails it exits non-zero."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(LSSPA_BENCH_STUB="1", LSSPA_BENCH_STUB_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, _bench_path(), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"stub": True, "world": 2}
+    recs = [json.load(open(tmp_path / f"bench_stub_rank{k}.json")) for k in range(2)]
+    assert [rec["RANK"] for rec in recs] == ["0", "1"] and [rec["LOCAL_RANK"] for rec in recs] == ["0", "1"]
+    assert all(rec["WORLD_SIZE"] == "2" and rec["MASTER_ADDR"] == "127.0.0.1" and rec["gpus"] == 2 for rec in recs)
+    assert recs[0]["MASTER_PORT"] == recs[1]["MASTER_PORT"] and 1024 < int(recs[0]["MASTER_PORT"]) < 65536 - 64
+    assert not any(rec["torch_imported"] for rec in recs)
+    # a failing rank ends the job with a non-zero status (and no JSON line is invented)
+    env["LSSPA_BENCH_STUB_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, _bench_path(), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode != 0 and "rank 1 exited" in r.stderr
+    # one GPU: no launcher (WORLD_SIZE unset, --gpus 1 runs in place: the stub sees no RANK)
+    env.pop("LSSPA_BENCH_STUB_FAIL_RANK")
+    r = subprocess.run([sys.executable, _bench_path(), "--gpus", "1"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0 and json.load(open(tmp_path / "bench_stub_rankNone.json"))["WORLD_SIZE"] is None
+
+
+def test_checkpoint_ranks_agree_before_anyone_raises(golden, tmp_path):
+    """A rank whose own file is foreign or unreadable reports it THROUGH the collective and then every rank raises;
+    nothing raises before the exchange (the other ranks would hang in it).  A foreign .prev next to a valid file
+    is ignored."""
+    from ls_spa import _driver as D
+
+    class TwoRanks:
+        world = 2
+
+        def __init__(self, rank, other_row):
+            self.rank, self.other_row, self.calls = rank, other_row, 0
+
+        def gather_ints(self, values):
+            self.calls += 1
+            rows = [None, None]
+            rows[self.rank] = [int(v) for v in values]
+            rows[1 - self.rank] = list(self.other_row)
+            return rows
+
+    ident = {"p": 3, "seed": 1}
+    path = str(tmp_path / "ck.npz")
+
+    def write(file, n, seed=1):
+        np.savez(file, version=D._CKPT_VERSION, n=n, p=3, seed=seed)
+        os.replace(file + ".npz", file) if os.path.exists(file + ".npz") else None
+
+    mine = D._ckpt_path(path, TwoRanks(0, []))
+    write(mine, 32)
+    write(mine + ".prev", 16, seed=99)          # a leftover of another run: ignored, the target is valid
+    c = TwoRanks(0, [32, 16, 0])
+    st = D._load_checkpoint(path, c, ident)
+    assert int(st["n"]) == 32 and c.calls == 1
+    # this rank's target belongs to another run: the error surfaces only after the exchange, and names the rank
+    write(mine, 32, seed=7)
+    c = TwoRanks(0, [32, -1, 0])
+    with pytest.raises(ValueError, match=r"rank\(s\) \[0\]"):
+        D._load_checkpoint(path, c, ident)
+    assert c.calls == 1
+    # the OTHER rank's file is bad: this rank raises the same error although its own file is fine
+    write(mine, 32)
+    c = TwoRanks(0, [-1, -1, 1])
+    with pytest.raises(ValueError, match=r"rank\(s\) \[1\]"):
+        D._load_checkpoint(path, c, ident)
+    # a corrupt archive is a problem like any other, not an exception before the collective
+    with open(mine, "wb") as fh:
+        fh.write(b"not a zip archive")
+    c = TwoRanks(0, [32, -1, 0])
+    with pytest.raises(ValueError, match=r"rank\(s\) \[0\]"):
+        D._load_checkpoint(path, c, ident)
+    assert c.calls == 1
+
+
+def test_checkpoint_keeps_the_attribution_history(golden, tmp_path):
+    """checkpoint= composes with return_attribution_history: the resumed run's history is the uninterrupted one's."""
+    class Dies(OracleEngine):
+        def run_batch(self, *a, **k):
+            if len(self.calls) == 2:
+                raise KeyboardInterrupt
+            return super().run_batch(*a, **k)
+
+    g = golden("p12")
+    d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+    kw = dict(batch_size=16, tolerance=0.0, seed=4, method="argsort", max_samples=64, return_attribution_history=True)
+    full = ls_spa(*d, _engine=OracleEngine(), **kw)
+    ck = str(tmp_path / "h.npz")
+    with pytest.raises(KeyboardInterrupt):
+        ls_spa(*d, checkpoint=ck, _engine=Dies(), **kw)
+    resumed = ls_spa(*d, checkpoint=ck, _engine=OracleEngine(), **kw)
+    assert resumed.attribution_history.shape == (64, 12)
+    np.testing.assert_array_equal(resumed.attribution_history, full.attribution_history)
+    np.testing.assert_allclose(resumed.attribution, full.attribution, rtol=0, atol=1e-14)
+    with pytest.raises(ValueError, match="history"):      # a state file written without the history cannot supply it
+        ls_spa(*d, checkpoint=ck, _engine=OracleEngine(), **dict(kw, return_attribution_history=False))

@@ -181,3 +181,24 @@ def test_edge_cases(golden):
         np.testing.assert_allclose(total, float(g[f"ee_{tag}_total"]), rtol=tol)
         if tag == "full":   # same stream position after a successful Cholesky draw
             np.testing.assert_array_equal(rng.standard_normal(4), g[f"ee_{tag}_next"])
+
+
+@pytest.mark.parametrize("name,n_check", [("large_p1000", 8), ("large_p5000", 1)])
+def test_large_p_against_the_reference(large_case, name, n_check):
+    """The oracle at the BENCHMARK feature counts, against lift vectors the reference itself produced there
+    (tests/golden/make_golden_large.py: reduce_data + square_shapley, ls_spa/ls_spa.py:256-318): p = 1000 (C3 / C4),
+    eight orderings, and p = 5000 (C5), one ordering.  Until round 3 the oracle was pinned at p <= 100 only."""
+    g, d = large_case(name)
+    reg = float(g["reg"])
+    R, F, q, qt = O.reduce(*d, reg)
+    yy = float(np.linalg.norm(d[3]) ** 2)
+    assert yy == pytest.approx(float(g["y_norm_sq"]), rel=1e-14)
+    for o, want in list(zip(g["orders"].astype(np.int64), g["lifts"]))[:n_check]:
+        got = O.ordering_lift(R, F, q, qt, yy, o)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    theta = np.linalg.lstsq(R, q, rcond=None)[0]
+    np.testing.assert_allclose(theta, g["theta"], rtol=1e-9, atol=1e-12)
+    if name == "large_p1000":
+        res = O.estimate(*d, reg=reg, perms=g["orders"].astype(np.int64), batch_size=4, tolerance=0.0)
+        np.testing.assert_allclose(res.attribution, g["attribution"], rtol=0, atol=1e-12)
+        assert abs(res.r_squared - float(g["drv_r_squared"])) < 1e-12
