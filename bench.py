@@ -61,6 +61,7 @@ def parse():
                          "has <= 32 samples, else 1")
     ap.add_argument("--lanes", type=int, choices=(1, 2), default=1,
                     help="batches in flight on the engine (lsspa_set_lanes): 2 = the next step's kernels run beside this one's")
+    ap.add_argument("--flags", type=int, default=0, help="developer switches of the engine (include/lsspa.h, lsspa_set_flags)")
     ap.add_argument("--no-probe", action="store_true", help="skip the strong-scaling probe (clean rocprof averages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ttt", action="store_true", help="skip the time-to-tolerance runs")
@@ -371,6 +372,8 @@ def main():
 
     if args.dtype == "f32":
         eng.set_precision("float32")
+    if args.flags:
+        eng.set_flags(args.flags)
     peak_tf = FP32_PEAK_TFLOPS if args.dtype == "f32" else FP64_PEAK_TFLOPS
     esz = 4 if args.dtype == "f32" else 8
     eng.profile(True)
@@ -585,6 +588,7 @@ def main():
                        "p": p, "N": rows, "M": rows, "reg": reg, "batch_size": B, "global_batch": B * world if
                        args.scaling == "weak" else B, "orderings_per_step_per_gpu": n_ord,
                        "path": "tri" if eng.tri else "rect", "collective": collective, "lanes": args.lanes, "lookahead": D,
+                       "flags": args.flags,
                        "data_generator": ("BASELINE.md section 3: default_rng(0) on the host, moved to HBM before timing"
                                           if args.data == "gaussian" else
                                           "the reference's gen_data (experiments/ground_truth_medium.py:74-106), seed 42, "

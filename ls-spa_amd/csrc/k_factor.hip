@@ -1103,14 +1103,15 @@ __global__ __launch_bounds__(256, 2) void chol_diag2_kernel(T* __restrict__ A, T
                     diag0 + (int64_t)mt * p_pad, piv_tol, info, s_a, s_x, threadIdx.x);
 }
 
-// Workgroup of NT threads (NT / 64 waves): wave w owns tile rows RW w .. RW w + RW - 1 (RW = 128 / waves)
-// for all 128 panel columns, i.e. 8 x YT accumulator tiles.
+// One 128 x 128 tile of panel step Jo of ONE matrix M (256 or 512 threads): the body shared by the one-launch-per-
+// panel-step kernel (chol_panel2_kernel: a workgroup per tile) and the whole-factorisation kernel
+// (chol_whole_kernel: a workgroup per matrix walks all its tiles).  Dm / diag0 are the matrix's own slices.
+// s_a: >= 2 * 128 * RK_LD elements, s_b: >= 128 * RK_LD elements of LDS.
 template <typename T, int NT>
-__global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict__ A, T* __restrict__ Dinv,
-                                                                 const double* __restrict__ diag0,
-                                                                 double piv_tol, int32_t* __restrict__ info,
-                                                                 int p_pad, int Jo, int nblk, int n_mats,
-                                                                 int grouped, int p_live) {
+__device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ Dm, const double* __restrict__ diag0,
+                                            double piv_tol, int32_t* __restrict__ info, const int p_pad, const int Jo,
+                                            const int tile, const int p_live, T* const s_a, T* const s_b,
+                                            const int tid) {
   typedef typename Tr<T>::acc_t acc_t;
   typedef typename Tr<T>::vec_t vec_t;
   constexpr int VE = Tr<T>::VE;
@@ -1120,8 +1121,6 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
   constexpr int NU = (36 + NW - 1) / NW;   // diagonal-update tiles per wave: 9 / 5
   // Region A: the two 128 x 16 operand tiles of the main loop; afterwards the 64 x 64 blocks of the
   // two-level solve and the elimination scratch.  Region B: output staging tile.
-  __shared__ __attribute__((aligned(16))) T s_a[2 * 128 * RK_LD];
-  __shared__ __attribute__((aligned(16))) T s_b[128 * RK_LD];
   static_assert(2 * 128 * RK_LD >= 64 * DI_LD, "a 64 x 64 block must fit region A");
   static_assert(128 * RK_LD >= FB_SX_ELEMS, "the diagonal factorisation's side buffer must fit region B");
   static_assert(sizeof(ElimScratch<T>) <= sizeof(T) * 64 * DI_LD, "elimination scratch must fit region A");
@@ -1130,28 +1129,8 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
   T* const s_dinv = s_a;
   T* const s_out = s_b;
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  // Dispatch order (1-D grid).  The tile-0 workgroups, which also factor the next diagonal block, come
-  // first, one per matrix.  The other tiles follow in groups of eight matrices: consecutive ids walk the
-  // eight matrices (id % 8 = matrix % 8 = XCD, workgroups go round-robin over the XCDs), then the tiles,
-  // so the tiles of one matrix run at about the same time on ONE XCD and share the panel-row operand
-  // L[J, 0:J0] through its L2 (worth ~1 %: the loop is not bound by that traffic).
-  int mt, tile;
-  {
-    const int id = blockIdx.x;
-    if (id < n_mats || !grouped) {
-      mt = id % n_mats;
-      tile = id / n_mats;
-    } else {
-      const int n_tiles = gridDim.x / n_mats;
-      const int rem = id - n_mats, per = 8 * (n_tiles - 1);
-      const int g = rem / per, within = rem - g * per;
-      tile = 1 + within / 8;
-      mt = 8 * g + (within & 7);
-    }
-  }
-  T* M = A + (int64_t)mt * p_pad * p_pad;
   const int J0 = Jo * 128;
   const int I0 = J0 + 128 + tile * 128;
   PSTAMP(0);
@@ -1266,7 +1245,7 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
   };
   // Each 64 x 64 operand block of the solve is fetched into registers one stage ahead and put into LDS when
   // the previous stage is done with the region.
-  const T* Dg = Dinv + ((int64_t)mt * nblk + 2 * Jo) * 4096;
+  const T* Dg = Dm + (int64_t)(2 * Jo) * 4096;
   DenseBlock64Regs<T, NT> nb;
   block64_fetch<T, NT>(nb, Dg, tid);
   __syncthreads();  // every wave is done with the operand tiles that region A now loses
@@ -1383,10 +1362,83 @@ __global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict
   if (tile == 0) {
     __threadfence_block();
     __syncthreads();
-    factor_diag128<T, NT>(M, p_pad, I0, Dinv + ((int64_t)mt * nblk + 2 * (Jo + 1)) * 4096,
-                          diag0 + (int64_t)mt * p_pad, piv_tol, info, s_a, s_b, tid);
+    factor_diag128<T, NT>(M, p_pad, I0, Dm + (int64_t)(2 * (Jo + 1)) * 4096, diag0, piv_tol, info, s_a, s_b, tid);
   }
   PSTAMP(7);
+}
+
+// Workgroup of NT threads (NT / 64 waves): wave w owns tile rows RW w .. RW w + RW - 1 (RW = 128 / waves)
+// for all 128 panel columns, i.e. 8 x YT accumulator tiles.
+template <typename T, int NT>
+__global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict__ A, T* __restrict__ Dinv,
+                                                                 const double* __restrict__ diag0,
+                                                                 double piv_tol, int32_t* __restrict__ info,
+                                                                 int p_pad, int Jo, int nblk, int n_mats,
+                                                                 int grouped, int p_live) {
+  __shared__ __attribute__((aligned(16))) T s_a[2 * 128 * RK_LD];
+  __shared__ __attribute__((aligned(16))) T s_b[128 * RK_LD];
+  // Dispatch order (1-D grid).  The tile-0 workgroups, which also factor the next diagonal block, come
+  // first, one per matrix.  The other tiles follow in groups of eight matrices: consecutive ids walk the
+  // eight matrices (id % 8 = matrix % 8 = XCD, workgroups go round-robin over the XCDs), then the tiles,
+  // so the tiles of one matrix run at about the same time on ONE XCD and share the panel-row operand
+  // L[J, 0:J0] through its L2 (worth ~1 %: the loop is not bound by that traffic).
+  int mt, tile;
+  {
+    const int id = blockIdx.x;
+    if (id < n_mats || !grouped) {
+      mt = id % n_mats;
+      tile = id / n_mats;
+    } else {
+      const int n_tiles = gridDim.x / n_mats;
+      const int rem = id - n_mats, per = 8 * (n_tiles - 1);
+      const int g = rem / per, within = rem - g * per;
+      tile = 1 + within / 8;
+      mt = 8 * g + (within & 7);
+    }
+  }
+  panel2_tile<T, NT>(A + (int64_t)mt * p_pad * p_pad, Dinv + (int64_t)mt * nblk * 4096, diag0 + (int64_t)mt * p_pad,
+                     piv_tol, info, p_pad, Jo, tile, p_live, s_a, s_b, threadIdx.x);
+}
+
+// The whole factorisation of one matrix by ONE workgroup (grid = matrices): the leading diagonal block, then panel
+// step by panel step every tile below it, in the order the one-launch-per-step scheme runs them -- the same
+// arithmetic on the same operands, hence the same bits (tested).  An experiment of round 3, kept behind developer
+// flag 8192: the idea was that without a launch boundary per panel step the two workgroups of a CU drift apart, so
+// that one's epilogue and diagonal factorisation run under the other's k-loop, with one tail instead of seven.
+// Measured at the C3 shape (512 matrices of 1024^2, fp64): 4.38 ms against 4.03 ms for diagonal launch + seven panel
+// launches.  The launches with several rounds of workgroups are out of step after their first round anyway; what
+// this form loses is the sharing of the panel-row operand L[J, 0:J0] among the tiles of a matrix that run side by side
+// on one XCD (here a workgroup re-reads it for every tile, from beyond the L2), and the tile body inlined into the
+// loop nest spills (67 registers; called out of line it loses the address-space and uniformity knowledge instead).
+// Memory order: everything a tile reads of L was written by this same workgroup, on this CU, through its L1.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void chol_whole_kernel(T* __restrict__ A, T* __restrict__ Dinv,
+                                                            const double* __restrict__ diag0, double piv_tol,
+                                                            int32_t* __restrict__ info, int p_pad, int nblk,
+                                                            int p_live) {
+  __shared__ __attribute__((aligned(16))) T s_a[2 * 128 * RK_LD];
+  __shared__ __attribute__((aligned(16))) T s_b[128 * RK_LD];
+  const int mt = blockIdx.x;
+  T* const M = A + (int64_t)mt * p_pad * p_pad;
+  T* const Dm = Dinv + (int64_t)mt * nblk * 4096;
+  const double* const d0 = diag0 + (int64_t)mt * p_pad;
+  factor_diag128<T, 256>(M, p_pad, 0, Dm, d0, piv_tol, info, s_a, s_b, threadIdx.x);
+  const int n_panel = p_pad / 128 - 1;
+#pragma unroll 1
+  for (int Jo = 0; Jo < n_panel; ++Jo) {
+#pragma unroll 1
+    for (int tile = 0; tile < n_panel - Jo; ++tile) {
+      __threadfence_block();   // the previous tile's (and the factorisation's) stores, before this tile's loads
+      __syncthreads();         // ... and its LDS reads, before this tile's LDS writes
+      // nothing the tile body derives from these may be hoisted out of the loops (it would spill far more)
+      T* Mi = M;
+      T* Di = Dm;
+      const double* di = d0;
+      int pp = p_pad, pl = p_live, t = threadIdx.x;
+      asm volatile("" : "+s"(Mi), "+s"(Di), "+s"(di), "+s"(pp), "+s"(pl), "+v"(t));
+      panel2_tile<T, 256>(Mi, Di, di, piv_tol, info, pp, Jo, tile, pl, s_a, s_b, t);
+    }
+  }
 }
 
 // whole factorisation of n_mats matrices: one diagonal launch + (p_pad / 128 - 1) panel launches
@@ -1419,6 +1471,20 @@ hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double p
   else
     hipLaunchKernelGGL((chol_panel2_kernel<double, 256>), grid, dim3(256), 0, st, (double*)A, (double*)Dinv,
                        diag0, piv_tol, info, p_pad, Jo, nblk, n_mats, grouped, p_live);
+  return hipGetLastError();
+}
+
+hipError_t launch_chol2_whole(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
+                              int n_mats, int f32, hipStream_t st, int p_live) {
+  if (p_live <= 0 || p_live > p_pad) p_live = p_pad;
+  if (p_pad % 128 != 0 || p_pad < 128 || n_mats < 1) return hipErrorInvalidValue;
+  const int nblk = p_pad / NB;
+  if (f32)
+    hipLaunchKernelGGL(chol_whole_kernel<float>, dim3(n_mats), dim3(256), 0, st, (float*)A, (float*)Dinv, diag0,
+                       piv_tol, info, p_pad, nblk, p_live);
+  else
+    hipLaunchKernelGGL(chol_whole_kernel<double>, dim3(n_mats), dim3(256), 0, st, (double*)A, (double*)Dinv, diag0,
+                       piv_tol, info, p_pad, nblk, p_live);
   return hipGetLastError();
 }
 

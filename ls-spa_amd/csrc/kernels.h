@@ -86,6 +86,10 @@ hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double pi
 // accumulator tiles are left out of the products
 hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
                               int Jo, int n_mats, int f32, hipStream_t st, int flags = 0, int p_live = 0);
+// the same factorisation in ONE launch: a workgroup per matrix runs the diagonal block and every panel tile of its
+// matrix (same results bit for bit); for batches with at least about two matrices per CU
+hipError_t launch_chol2_whole(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
+                              int n_mats, int f32, hipStream_t st, int p_live = 0);
 hipError_t launch_chol_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
                              int J, int n_mats, int flags, int f32, hipStream_t st);
 

@@ -78,6 +78,7 @@ struct Lane {
 
 struct lsspa_ctx {
   int device = 0;
+  int n_cu = 256;                // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
@@ -528,7 +529,20 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
   const bool fused = !(ctx->flags & 2);  // panel step J also factors diagonal block J + 1
   // a pivot below ~p ulps of its feature's own variance is numerically zero (collinear feature)
   const double piv_tol = 16.0 * (double)p * (ctx->f32 ? 1.1920929e-07 : 2.220446049250313e-16);
-  if (!(ctx->flags & 8)) {
+  // Developer flag 8192: the whole factorisation in ONE launch, a workgroup per matrix (chol_whole_kernel).  Same bits;
+  // measured slower at the C3 shape (4.38 against 4.03 ms for 512 matrices, round 3) and therefore not the default.
+  const bool whole = !(ctx->flags & (8 | 2)) && (ctx->flags & 8192);
+  if (whole) {
+    ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_PANEL, st);
+    HIPCHK(launch_chol2_whole(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, n_mats, ctx->f32, st,
+                              round_up(p + 1, 16)));
+    if (L.mid_armed && timed) {
+      HIPCHK(hipEventRecord(L.ev_mid, st));
+      L.mid_valid = true;
+      L.mid_armed = false;
+    }
+  }
+  if (!whole && !(ctx->flags & 8)) {
     {
       ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_DIAG, st);
       HIPCHK(launch_chol2_diag(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, n_mats,
@@ -549,7 +563,7 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
       }
     }
   }
-  for (int J = 0; J < nblk && (ctx->flags & 8); ++J) {   // A/B switch: the one-level scheme
+  for (int J = 0; J < nblk && !whole && (ctx->flags & 8); ++J) {   // A/B switch: the one-level scheme
     if (J == 0 || !fused) {
       ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_DIAG, st);
       HIPCHK(launch_chol_diag(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, J,
@@ -877,6 +891,7 @@ int lsspa_create(int32_t device, lsspa_ctx** out) {
     return LSSPA_ERR_NOMEM;
   }
   ctx->device = device;
+  if (prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
   if ((e = hipSetDevice(device)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
     g_create_error = std::string("stream creation: ") + hipGetErrorString(e);

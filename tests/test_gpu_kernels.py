@@ -324,6 +324,36 @@ def test_padding_tiles_are_skipped_without_a_trace(p, n, m, prec):
         eng.close()
 
 
+@pytest.mark.parametrize("p,n,m,prec", [(257, 900, 700, "float64"), (257, 900, 700, "float32"), (130, 500, 40, "float64"),
+                                        (1000, 3000, 2500, "float64"), (640, 2000, 1800, "float32")])
+def test_whole_factorisation_kernel_equals_the_launch_per_step_form(p, n, m, prec):
+    """The blocked Cholesky runs as one launch per 128-wide panel step (a workgroup per tile; the shipped form) or,
+    behind developer flag 8192, as ONE launch in which a workgroup walks all tiles of its matrix.  Same tile body,
+    same operands, same order: the lift vectors agree bit for bit, and the collinearity flag is raised by both."""
+    from ls_spa._engine import HipEngine
+    Xa, Xe, ya, ye = problem(23, p, n, m)
+    rng = np.random.default_rng(12)
+    perms = np.array([rng.permutation(p) for _ in range(5)])
+    eng = HipEngine(0)
+    try:
+        eng.set_precision(prec)
+        eng.load_data(Xa, Xe, ya, ye, 1e-3)
+        eng.set_flags(1024)
+        per_step = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        eng.set_flags(1024 | 8192)
+        whole = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        np.testing.assert_array_equal(whole, per_step)
+        assert eng.info() == 0
+        Xc = Xa.copy()
+        Xc[:, 3] = Xc[:, 1] + Xc[:, 2]                  # a collinear feature: both forms must flag it
+        eng.load_data(Xc, Xe, ya, ye, 0.0)
+        eng.set_flags(1024 | 8192)
+        eng.run_batch(perms[:1], False, want_lifts=True, accumulate=False)
+        assert eng.info() == 1
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("anti", [False, True])
 def test_batch_larger_than_the_workspace_is_split(engine, anti):
     """More orderings in one call than a launch sequence holds (4096): the batch is cut into sub-batches
