@@ -218,6 +218,7 @@ int lsspa_profile_reset(lsspa_ctx* ctx);
  *  2048  no skipping of the all-padding 16 x 16 tiles in the panel / strip products
  *  1024  general path also for small problems (p + 1 <= 128 normally takes the fused one-workgroup kernel)
  *  4096  streamed reduction never page-locks the caller's X (A/B of the PCIe path)
+ * 65536  Gram kernel: workgroup id = unit (the units of a row slice spread over the XCDs instead of sharing one L2)
  *  8192  whole factorisation in one launch, a workgroup per matrix (measured slower than a launch per panel step)
  * Every combination computes the same lifts (tests/test_gpu_kernels.py). */
 int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);

@@ -153,6 +153,7 @@ struct GramArgs {
   int n_split;
   double* C;               // out: [P1pad][P1pad] full symmetric, P1pad = round_up(p + 1, 128)
   int accumulate;          // C += (row chunks of a streamed matrix) instead of C =
+  int variant = 0;         // developer A/B switches (bit 0: workgroup id = unit, no XCD-contiguous map)
 };
 size_t gram_workspace_bytes(int p, int n_split);
 int gram_default_split(int64_t n, int p);

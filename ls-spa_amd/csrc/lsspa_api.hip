@@ -1016,6 +1016,7 @@ static int gram_side(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, in
     ga.n_split = n_split;
     ga.C = C.ptr;
     ga.accumulate = 0;
+    ga.variant = (ctx->flags >> 16) & 0xff;
     hipError_t e = launch_gram(ga, ctx->stream);
     if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "gram launch", e);
   }
@@ -1146,6 +1147,7 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
         ga.n_split = n_split;
         ga.C = C.ptr;
         ga.accumulate = k > 0;
+        ga.variant = (ctx->flags >> 16) & 0xff;
         e = launch_gram(ga, ctx->stream);
       }
       if (e == hipSuccess) e = hipEventRecord(consumed[b], ctx->stream);
