@@ -787,68 +787,40 @@ constexpr int XD_LD = 17;
 constexpr int FB_SX_ELEMS = 4 * 16 * XD_LD + 16;
 
 // one wave: factor the 16 x 16 block at s_blk (stride DI_LD, lower part valid) in place (L, zeros above the
-// diagonal) and write its inverse to s_inv (16 x XD_LD).  d0: the 16 original diagonal entries (pivot scale).
-// Lane (i = lane & 15, q = lane >> 4) keeps T[i][4q..4q+3] of the FULL symmetric block and Y[i][4q..4q+3].
-// Elimination without masks: step k subtracts f_i * (row k) from every row i > k of [T | Y], all columns;
-// the finished columns of T are overwritten by that, so each lane copies its entry of column k aside first.
-// Per pivot: one scalar broadcast, nine lane permutes (two addresses), a Newton reciprocal, eight FMAs --
-// no division, square root or memory access inside the sweep.
+// diagonal) and write its inverse to s_inv (16 x XD_LD).  tol_lane: lane l holds the pivot threshold of row l & 15
+// (piv_tol x the row's original diagonal entry).
+// The elimination runs on the matrix pipe with the block in accumulator layout (tiles.h: factor16_acc); here the
+// block is brought into that layout (the full symmetric block from its lower part), and L = (unscaled columns) /
+// sqrt(pivots) and L^-1 = (unscaled rows of Y) / sqrt(pivots) are written back.
 template <typename T>
-__device__ __forceinline__ void wave_factor16(T* s_blk, T* s_inv, T* s_dd, const double* __restrict__ d0,
-                                              double piv_tol, int lane, int& bad) {
-  const int i = lane & 15, q = lane >> 4;
-  T t[4], y[4], lcol[4];
+__device__ __forceinline__ void wave_factor16(T* s_blk, T* s_inv, T* s_dd, const double tol_lane, int lane,
+                                              int& bad) {
+  typedef typename Tr<T>::acc_t acc_t;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  acc_t t, y;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int j = 4 * q + e;
-    t[e] = (j <= i) ? s_blk[i * DI_LD + j] : s_blk[j * DI_LD + i];
-    y[e] = (j == i) ? (T)1 : (T)0;
-    lcol[e] = (T)0;
+  for (int r = 0; r < 4; ++r) {
+    const int row = Tr<T>::acc_row(l4, r);
+    t[r] = (l15 <= row) ? s_blk[row * DI_LD + l15] : s_blk[l15 * DI_LD + row];
+    y[r] = (row == l15) ? (T)1 : (T)0;
   }
-  const double tol_i = piv_tol * d0[i];   // lane i (any q) holds the threshold of pivot i
-  T dmine = (T)1;                         // lane i keeps pivot i for the final scaling
-  const int a_row = 64 * q;               // + 4 k : byte address of lane (k, q) = 4 (k + 16 q)
-  const int a_col = 4 * i;                // + 64 kq : lane (i, kq)
-  // pivots in groups of four: the register index ke is static, the group index a (uniform) run-time value --
-  // sixteen fully unrolled steps cost 256 VGPRs and an instruction-cache footprint for nothing
-#pragma unroll 1
-  for (int kq = 0; kq < 4; ++kq)
-#pragma unroll
-  for (int ke = 0; ke < 4; ++ke) {
-    const int k = 4 * kq + ke;
-    T d = bcast_lane<T>(t[ke], k + 16 * kq);
-    const double tol = bcast_lane<double>(tol_i, k);
-    if (!((double)d > tol)) {   // numerically not positive definite (or NaN): flag it, go on
-      d = (T)1;
-      bad = 1;
-    }
-    if (i == k) dmine = d;
-    if (q == kq) lcol[ke] = t[ke];                         // column k of T is final: L[i][k] * L[k][k]
-    const T cik = bperm<T>(a_col + 64 * kq, t[ke]);        // T[i][k]
-    T tk[4], yk[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      tk[e] = bperm<T>(a_row + 4 * k, t[e]);               // T[k][4q + e]
-      yk[e] = bperm<T>(a_row + 4 * k, y[e]);               // Y[k][4q + e]
-    }
-    const T f = (i > k) ? cik * fast_recip<T>(d) : (T)0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      t[e] -= f * tk[e];
-      y[e] -= f * yk[e];
-    }
-  }
-  if (q == 0) s_dd[i] = (T)1 / sqrt(dmine);   // 1 / L[i][i]
+  factor16_acc<T>(t, y, tol_lane, lane, bad);
+  // 1 / L[j][j] = 1 / sqrt(pivot j): the pivot sits on the diagonal of t.  One reciprocal square root per lane (the
+  // square-root-then-divide form, evaluated for every register under a predicate, cost as much as the sweep itself)
+  T dj;
+  const bool holds = acc_diag<T>(t, l15, l4, dj);
+  const T rs_mine = fast_rsqrt<T>(dj);
+  if (holds) s_dd[l15] = rs_mine;
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int j = 4 * q + e;
-    T lv = (T)0, xv = (T)0;
-    if (j < i) lv = lcol[e] * s_dd[j];
-    if (j == i) lv = (T)1 / s_dd[j];
-    if (j <= i) xv = y[e] * s_dd[i];
-    s_blk[i * DI_LD + j] = lv;
-    s_inv[i * XD_LD + j] = xv;
+  for (int r = 0; r < 4; ++r) {
+    const int row = Tr<T>::acc_row(l4, r);
+    const T rs_row = s_dd[row];
+    // t holds (row, col = l15): for col >= row the unscaled L[col][row]; y holds (L^-1)[row][col] L[row][row], col <= row
+    if (l15 > row) s_blk[l15 * DI_LD + row] = t[r] * rs_row;          // L[col][row], strictly lower
+    if (l15 == row) s_blk[row * DI_LD + row] = t[r] * rs_row;          // L[row][row] = sqrt(pivot)
+    if (l15 > row) s_blk[row * DI_LD + l15] = (T)0;                    // zeros above the diagonal
+    s_inv[row * XD_LD + l15] = (l15 <= row) ? y[r] * rs_row : (T)0;
   }
 }
 
@@ -921,8 +893,10 @@ __device__ __forceinline__ void factor_block64_load(const T* __restrict__ M, int
 // (lower blocks) and the off-diagonal blocks of the inverse (block (jb, ib) = X[ib][jb]), s_x its diagonal blocks.
 template <typename T, int NT>
 __device__ __forceinline__ void factor_block64_core(T* __restrict__ M, int p_pad, int r0, T* __restrict__ Dg,
-                                                    const double* __restrict__ diag0, double piv_tol,
-                                                    int32_t* __restrict__ info, T* s_t, T* s_x, int tid) {
+                                                    const double tol64, int32_t* __restrict__ info, T* s_t, T* s_x,
+                                                    int tid) {
+  // tol64: lane l holds the pivot threshold of row r0 + l (fetched from memory by the caller BEFORE the block was
+  // staged: read where it is needed, the global load sat in front of every one of the four 16 x 16 eliminations)
   const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave index as the scalar it is
   T* const s_dd = s_x + 4 * 16 * XD_LD;
   int bad = 0;
@@ -930,7 +904,7 @@ __device__ __forceinline__ void factor_block64_core(T* __restrict__ M, int p_pad
   for (int kb = 0; kb < 4; ++kb) {
     T* const blk = s_t + (16 * kb) * DI_LD + 16 * kb;
     T* const inv = s_x + kb * 16 * XD_LD;
-    if (w == 0) wave_factor16<T>(blk, inv, s_dd, diag0 + r0 + 16 * kb, piv_tol, lane, bad);
+    if (w == 0) wave_factor16<T>(blk, inv, s_dd, __shfl(tol64, 16 * kb + (lane & 15)), lane, bad);
     __syncthreads();
     FSTAMP(2 + 3 * kb);
     // (2): 3 - kb panel tiles and kb inverse tiles: three tiles in all, one per wave
@@ -995,8 +969,9 @@ template <typename T, int NT>
 __device__ __forceinline__ void factor_block64(T* __restrict__ M, int p_pad, int r0, T* __restrict__ Dg,
                                                const double* __restrict__ diag0, double piv_tol,
                                                int32_t* __restrict__ info, T* s_t, T* s_x, int tid) {
+  const double tol64 = piv_tol * diag0[r0 + (tid & 63)];
   factor_block64_load<T, NT>(M, p_pad, r0, s_t, tid);
-  factor_block64_core<T, NT>(M, p_pad, r0, Dg, diag0, piv_tol, info, s_t, s_x, tid);
+  factor_block64_core<T, NT>(M, p_pad, r0, Dg, tol64, info, s_t, s_x, tid);
 }
 
 // Factor the 128 x 128 diagonal block at (r0, r0) in place; inverses of its two 64 x 64 diagonal
@@ -1020,6 +995,7 @@ __device__ __forceinline__ void factor_diag128(T* __restrict__ M, int p_pad, int
       c[x][r] = M[cm_off(p_pad, r0 + NB + 16 * w + l15, r0 + 16 * x + Tr<T>::acc_row(l4, r))];
   Block64Regs<T, NT> a22;   // fetched now, needed after the first factorisation: its latency is off the critical path
   factor_block64_fetch<T, NT>(a22, M, p_pad, r0 + NB, tid);
+  const double tol64_b = piv_tol * diag0[r0 + NB + (tid & 63)];   // the second block's pivot thresholds, likewise
   FSTAMP(16);
   factor_block64<T, NT>(M, p_pad, r0, Dg, diag0, piv_tol, info, s_a, s_x, tid);
   FSTAMP(17);
@@ -1086,7 +1062,7 @@ __device__ __forceinline__ void factor_diag128(T* __restrict__ M, int p_pad, int
   }
   __syncthreads();
   FSTAMP(22);
-  factor_block64_core<T, NT>(M, p_pad, r0 + NB, Dg + 4096, diag0, piv_tol, info, s_a, s_x, tid);
+  factor_block64_core<T, NT>(M, p_pad, r0 + NB, Dg + 4096, tol64_b, info, s_a, s_x, tid);
   FSTAMP(23);
 }
 

@@ -22,9 +22,13 @@ namespace lsspa {
 // phase time stamps of workgroup 0 (tools/small_probe.hip builds this file with LSSPA_SMALL_STAMPS)
 #ifdef LSSPA_SMALL_STAMPS
 __device__ long long g_small_stamps[16];
-#define SSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_small_stamps[i] = wall_clock64(); } while (0)
+__device__ long long g_small_cycles[16];
+#define SSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_small_stamps[i] = wall_clock64(); g_small_cycles[i] = __builtin_amdgcn_s_memtime(); } } while (0)
+__device__ long long g_small_helper[16];
+#define HSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 64) g_small_helper[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SSTAMP(i) do { } while (0)
+#define HSTAMP(i) do { } while (0)
 #endif
 
 namespace {
@@ -35,62 +39,36 @@ __device__ __forceinline__ int tri_blk(int i, int j) { return i * (i + 1) / 2 + 
 constexpr int SINV_LD = 17;
 
 // One wave: factor the 16 x 16 diagonal block blk (swizzled, lower part valid) in place -- L below and on the
-// diagonal, zeros above -- and write its inverse to s_inv (16 x SINV_LD) and 1 / L[i][i] to s_rd[0..15].
-// Same elimination as wave_factor16 of k_factor.hip (carried identity, lane permutes, Newton reciprocal).
+// diagonal, the strictly lower part of L^-1 mirrored above it -- and write its inverse to s_inv (16 x SINV_LD) and
+// 1 / L[i][i] to s_rd[0..15].  The elimination itself runs on the matrix pipe in accumulator layout (tiles.h:
+// factor16_acc, round 3; the lane-permute sweep it replaces was ~4 us of every block step).
 __device__ __forceinline__ void wave_factor16_sw(double* blk, double* s_inv, double* s_rd, const double* d0,
                                                  double piv_tol, int lane, int& bad) {
-  const int i = lane & 15, q = lane >> 4;
-  double t[4], y[4], lcol[4];
+  const int l15 = lane & 15, l4 = lane >> 4;
+  d4 t, y;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int j = 4 * q + e;
-    t[e] = (j <= i) ? blk[sw(i, j)] : blk[sw(j, i)];   // upper part: mirrored (whatever is stored there is ignored)
-    y[e] = (j == i) ? 1.0 : 0.0;
-    lcol[e] = 0.0;
+  for (int r = 0; r < 4; ++r) {
+    const int row = acc_row(l4, r);
+    t[r] = (l15 <= row) ? blk[sw(row, l15)] : blk[sw(l15, row)];   // upper part: mirrored (what is stored there is ignored)
+    y[r] = (row == l15) ? 1.0 : 0.0;
   }
-  const double tol_i = piv_tol * d0[i];
-  double dmine = 1.0;
-  const int a_row = 64 * q;
-  const int a_col = 4 * i;
-#pragma unroll 1
-  for (int kq = 0; kq < 4; ++kq)
-#pragma unroll
-    for (int ke = 0; ke < 4; ++ke) {
-      const int k = 4 * kq + ke;
-      double d = bcast_lane<double>(t[ke], k + 16 * kq);
-      const double tol = bcast_lane<double>(tol_i, k);
-      if (!(d > tol)) {   // numerically not positive definite (or NaN): flag it, go on
-        d = 1.0;
-        bad = 1;
-      }
-      if (i == k) dmine = d;
-      if (q == kq) lcol[ke] = t[ke];
-      const double cik = bperm<double>(a_col + 64 * kq, t[ke]);
-      double tk[4], yk[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        tk[e] = bperm<double>(a_row + 4 * k, t[e]);
-        yk[e] = bperm<double>(a_row + 4 * k, y[e]);
-      }
-      const double f = (i > k) ? cik * fast_recip<double>(d) : 0.0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        t[e] -= f * tk[e];
-        y[e] -= f * yk[e];
-      }
-    }
-  if (q == 0) s_rd[i] = 1.0 / sqrt(dmine);   // 1 / L[i][i]
+  factor16_acc<double>(t, y, piv_tol * d0[l15], lane, bad);
+  double dj;
+  const bool holds = acc_diag<double>(t, l15, l4, dj);
+  const double rs_mine = fast_rsqrt<double>(dj);                  // 1 / L[j][j]: one reciprocal square root per lane
+  if (holds) s_rd[l15] = rs_mine;
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int j = 4 * q + e;
-    double lv = 0.0, xv = 0.0;
-    if (j < i) lv = lcol[e] * s_rd[j];
-    if (j == i) lv = 1.0 / s_rd[j];
-    if (j <= i) xv = y[e] * s_rd[i];
-    if (j <= i) blk[sw(i, j)] = lv;
-    if (j < i) blk[sw(j, i)] = xv;      // (L_d^-1)[i][j] lives at the mirrored position; its diagonal is s_rd
-    s_inv[i * SINV_LD + j] = xv;
+  for (int r = 0; r < 4; ++r) {
+    const int row = acc_row(l4, r);
+    const double rs_row = s_rd[row];
+    const double xv = (l15 <= row) ? y[r] * rs_row : 0.0;         // (L^-1)[row][l15]
+    // t holds (row, col = l15): for col >= row the unscaled L[col][row]; L[row][row] = pivot / sqrt(pivot)
+    if (l15 >= row) blk[sw(l15, row)] = t[r] * rs_row;
+    s_inv[row * SINV_LD + l15] = xv;
+    // the strictly lower part of L^-1 lives at the mirrored positions of the block (its diagonal is s_rd);
+    // position (col, row), col < row, is nobody's L entry
+    if (l15 < row) blk[sw(l15, row)] = xv;
   }
 }
 
@@ -101,25 +79,39 @@ __device__ __forceinline__ double inv_elem(const double* blk, const double* rd, 
 }
 
 // 16 x 16 x 16 products of one wave on up to NT tiles at once (independent accumulators: the MFMA chains overlap):
-//   T[q] -= A[q] B[q]^T  with A[q], B[q] row blocks of the current panel
+//   T[q] -= A[q] B[q]^T  with A[q], B[q] row blocks of the current panel.  The tiles are given as element OFFSETS into
+// the matrix M, not as pointers: an array of pointers loses the LDS address space, and every access through it
+// becomes a flat_load / flat_store (found in round 3: the helpers' share of a block step took twice the factoring
+// wave's).
 template <int NT>
-__device__ __forceinline__ void trailing_tiles(double* const (&Tb)[NT], const double* const (&Ab)[NT],
-                                               const double* const (&Bb)[NT], int n, int l15, int l4) {
+__device__ __forceinline__ void trailing_tiles(double* M, const int (&To)[NT], const int (&Ao)[NT], const int (&Bo)[NT],
+                                               int n, int l15, int l4) {
+  // every operand fragment and every element of the tiles to be updated is fetched before the first product: one
+  // LDS round trip for the batch instead of one in front of each of its 4 NT matrix instructions
+  double av[NT][4], bv[NT][4], tv[NT][4];
+#pragma unroll
+  for (int q = 0; q < NT; ++q) {
+    const int qq = (q < n) ? q : 0;        // a short batch re-reads tile 0 (uniform; nothing of it is stored)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      av[q][kk] = M[Ao[qq] + sw(l15, 4 * kk + l4)];
+      bv[q][kk] = M[Bo[qq] + sw(l15, 4 * kk + l4)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tv[q][r] = M[To[qq] + sw(acc_row(l4, r), l15)];
+  }
   d4 o[NT];
 #pragma unroll
   for (int q = 0; q < NT; ++q) o[q] = d4_zero();
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const int kx = 4 * kk + l4;
+  for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-    for (int q = 0; q < NT; ++q)
-      if (q < n) o[q] = mfma(Ab[q][sw(l15, kx)], Bb[q][sw(l15, kx)], o[q]);
-  }
+    for (int q = 0; q < NT; ++q) o[q] = mfma(av[q][kk], bv[q][kk], o[q]);
 #pragma unroll
   for (int q = 0; q < NT; ++q)
     if (q < n) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Tb[q][sw(acc_row(l4, r), l15)] -= o[q][r];
+      for (int r = 0; r < 4; ++r) M[To[q] + sw(acc_row(l4, r), l15)] = tv[q][r] - o[q][r];
     }
 }
 
@@ -196,6 +188,7 @@ __global__ __launch_bounds__(512) void small_p_kernel(SmallArgs a) {
     // would sit on the same SIMD and take turns on its issue slots
     const int fw = half;
     if (w == fw) wave_factor16_sw(M, inv, rd, d0, a.piv_tol, lane, bad);
+    SSTAMP(8);
     __syncthreads();
     for (int kb = 0; kb < nb; ++kb) {
       // panel: L[ib][kb] = T[ib][kb] Ld^-T, in place
@@ -211,38 +204,40 @@ __global__ __launch_bounds__(512) void small_p_kernel(SmallArgs a) {
         for (int r = 0; r < 4; ++r) Tb[sw(acc_row(l4, r), l15)] = o[r];
       }
       __syncthreads();
+      if (kb == 0) SSTAMP(9);
       if (kb + 1 == nb) break;
       // trailing update T[ib][jb] -= L[ib][kb] L[jb][kb]^T (kb < jb <= ib) with look-ahead: the factoring wave takes
       // the next diagonal tile alone and factors it at once, the other three share the rest four tiles at a time
       if (w == fw) {
-        double* const Tb[1] = {M + tri_blk(kb + 1, kb + 1) * 256};
-        const double* const Ab[1] = {M + tri_blk(kb + 1, kb) * 256};
-        trailing_tiles<1>(Tb, Ab, Ab, 1, l15, l4);
+        const int To[1] = {tri_blk(kb + 1, kb + 1) * 256}, Ao[1] = {tri_blk(kb + 1, kb) * 256};
+        trailing_tiles<1>(M, To, Ao, Ao, 1, l15, l4);
         __builtin_amdgcn_wave_barrier();
-        wave_factor16_sw(Tb[0], inv, rd + 16 * (kb + 1), d0 + 16 * (kb + 1), a.piv_tol, lane, bad);
+        if (kb == 0) SSTAMP(10);
+        wave_factor16_sw(M + To[0], inv, rd + 16 * (kb + 1), d0 + 16 * (kb + 1), a.piv_tol, lane, bad);
+        if (kb == 0) SSTAMP(11);
       } else {
         const int me = (w + 3 - fw) % 4 - 0;      // 0, 1, 2 among the three helpers
-        double* Tb[4];
-        const double *Ab[4], *Bb[4];
+        if (kb == 0) HSTAMP(0);
+        int hs = 1;
+        int To[4], Ao[4], Bo[4];
         int have = 0, tcount = 0;
-        for (int ib = kb + 1; ib < nb; ++ib)
+        for (int ib = kb + 2; ib < nb; ++ib)       // row kb + 1 holds (kb+1, kb+1) only: the factoring wave's
           for (int jb = kb + 1; jb <= ib; ++jb) {
-            if (ib == kb + 1) continue;            // (kb+1, kb+1): the factoring wave's
             if ((tcount++ % 3) != me) continue;
-            Tb[have] = M + tri_blk(ib, jb) * 256;
-            Ab[have] = M + tri_blk(ib, kb) * 256;
-            Bb[have] = M + tri_blk(jb, kb) * 256;
+            To[have] = tri_blk(ib, jb) * 256;
+            Ao[have] = tri_blk(ib, kb) * 256;
+            Bo[have] = tri_blk(jb, kb) * 256;
             if (++have == 4) {
-              trailing_tiles<4>(reinterpret_cast<double* const(&)[4]>(Tb), reinterpret_cast<const double* const(&)[4]>(Ab),
-                                reinterpret_cast<const double* const(&)[4]>(Bb), 4, l15, l4);
+              trailing_tiles<4>(M, To, Ao, Bo, 4, l15, l4);
+              if (kb == 0) { HSTAMP(hs); ++hs; }
               have = 0;
             }
           }
-        if (have)
-          trailing_tiles<4>(reinterpret_cast<double* const(&)[4]>(Tb), reinterpret_cast<const double* const(&)[4]>(Ab),
-                            reinterpret_cast<const double* const(&)[4]>(Bb), have, l15, l4);
+        if (have) trailing_tiles<4>(M, To, Ao, Bo, have, l15, l4);
+        if (kb == 0) HSTAMP(hs);
       }
       __syncthreads();
+      if (kb == 0) SSTAMP(12);
     }
     if (bad && lane == 0) s_bad = 1;
   }

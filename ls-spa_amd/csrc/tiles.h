@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace lsspa {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -305,6 +307,37 @@ __device__ __forceinline__ T fast_recip(T d) {
   }
 }
 
+// 1 / sqrt(d) to working precision without the square-root and division sequences (each a dozen dependent
+// instructions): hardware reciprocal square root + two Newton steps  r <- r + r (1 - d r^2) / 2
+template <typename T>
+__device__ __forceinline__ T fast_rsqrt(T d) {
+  if constexpr (sizeof(T) == 8) {
+    double r = __builtin_amdgcn_rsq(d);
+    r = fma(0.5 * r, fma(-d * r, r, 1.0), r);
+    r = fma(0.5 * r, fma(-d * r, r, 1.0), r);
+    return r;
+  } else {
+    float r = __builtin_amdgcn_rsqf(d);
+    r = fmaf(0.5f * r, fmaf(-d * r, r, 1.0f), r);
+    return r;
+  }
+}
+
+// the diagonal element of a 16 x 16 block in accumulator layout that this lane holds, if it holds one (lanes whose
+// rows include row l15); one select chain instead of a predicated computation per register
+template <typename T>
+__device__ __forceinline__ bool acc_diag(const typename Tr<T>::acc_t& t, int l15, int l4, T& d) {
+  d = t[0];
+  bool mine = false;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (Tr<T>::acc_row(l4, r) == l15) {
+      d = t[r];
+      mine = true;
+    }
+  return mine;
+}
+
 // value of v in the lane whose byte address (4 * lane) is addr
 template <typename T>
 __device__ __forceinline__ T bperm(int addr, T v) {
@@ -314,6 +347,65 @@ __device__ __forceinline__ T bperm(int addr, T v) {
     return (T)__hiloint2double(hi, lo);
   } else {
     return (T)__int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int((float)v)));
+  }
+}
+
+// ---- in-register factorisation of a 16 x 16 block on the matrix pipe (round 3) --------------------------------------
+// The block T (symmetric, positive definite) and the carried identity Y sit in MFMA ACCUMULATOR layout: element
+// (row, col) in lane (l15 = col, l4), register r with row = acc_row(l4, r).  Gaussian elimination step k,
+//     T[i][:] -= (T[i][k] / d) T[k][:],   Y[i][:] -= (T[i][k] / d) Y[k][:]      for the rows i > k,
+// is a rank-1 update, i.e. ONE matrix instruction per matrix whose only non-zero k-slot is the one the lanes of row
+// k feed: those lanes (l4 = lk4) hold T[k][j] in register rk -- as it stands the B operand (row k) and, the trailing
+// block being symmetric, also T[j][k], the column the multipliers come from.  No lane permutes, no LDS traffic, two
+// matrix instructions and a dozen vector ones per pivot (the permute-based sweep it replaces: 18 ds_bpermute and ~60
+// instructions).  Rows <= k are left alone (their multiplier is zero), so after the sweep
+//     T[k][j], j >= k  =  L[j][k] L[k][k]   (row k never changes after step k: the unscaled column k of L),
+//     Y[i][j], j <= i  =  (L^-1)[i][j] L[i][i].
+// tol_lane: lane l holds the pivot threshold of row l & 15.  A pivot at or below it (or NaN) is replaced by 1 and
+// flagged, as before.
+template <typename T>
+__device__ __forceinline__ void factor16_acc(typename Tr<T>::acc_t& t, typename Tr<T>::acc_t& y, const double tol_lane,
+                                             const int lane, int& bad) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+  constexpr bool F64 = sizeof(T) == 8;
+  // row k sits in the lanes l4 = lk4, register rk: (k & 3, k >> 2) in the f64 result layout, (k >> 2, k & 3) in the f32
+  // one.  The register index must be static, the lane group need not: the loop over the register index is unrolled,
+  // the other one is a run-time loop (sixteen unrolled steps cost instruction cache and scalar registers for nothing).
+  auto step = [&](const int k, const int lk4, auto rk_tag) {
+    constexpr int rk = decltype(rk_tag)::value;
+    T d = bcast_lane<T>(t[rk], k + 16 * lk4);
+    const double tol = bcast_lane<double>(tol_lane, k);
+    if (!((double)d > tol)) {   // numerically not positive definite (or NaN): flag it, go on with a unit pivot
+      d = (T)1;
+      bad = 1;
+      if (lane == k + 16 * lk4) t[rk] = (T)1;
+    }
+    const T rinv = fast_recip<T>(d);
+    const bool rowk = (l4 == lk4);
+    const T vt = rowk ? t[rk] : (T)0;                       // T[k][l15] in the one live k-slot
+    const T vy = rowk ? y[rk] : (T)0;                       // Y[k][l15]
+    const T a = (rowk && l15 > k) ? -vt * rinv : (T)0;      // -T[l15][k] / d for the rows below the pivot
+    t = Tr<T>::mfma(a, vt, t);
+    y = Tr<T>::mfma(a, vy, y);
+  };
+  auto sweep = [&](auto rk_tag) {
+    constexpr int rk = decltype(rk_tag)::value;
+#pragma unroll 1
+    for (int lk4 = 0; lk4 < 4; ++lk4) step(F64 ? 4 * rk + lk4 : 4 * lk4 + rk, lk4, rk_tag);
+  };
+  if constexpr (F64) {      // k = 4 rk + lk4: pivots in order when the register index is the outer loop
+    sweep(std::integral_constant<int, 0>());
+    sweep(std::integral_constant<int, 1>());
+    sweep(std::integral_constant<int, 2>());
+    sweep(std::integral_constant<int, 3>());
+  } else {                  // k = 4 lk4 + rk: the lane group is the outer loop
+#pragma unroll 1
+    for (int lk4 = 0; lk4 < 4; ++lk4) {
+      step(4 * lk4 + 0, lk4, std::integral_constant<int, 0>());
+      step(4 * lk4 + 1, lk4, std::integral_constant<int, 1>());
+      step(4 * lk4 + 2, lk4, std::integral_constant<int, 2>());
+      step(4 * lk4 + 3, lk4, std::integral_constant<int, 3>());
+    }
   }
 }
 

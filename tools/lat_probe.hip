@@ -1,0 +1,151 @@
+// Dependent-chain latencies of the instructions on the 16 x 16 elimination's critical path (one wave, alone on its CU;
+// cycles by s_memtime).   hipcc --offload-arch=gfx950 -O3 tools/lat_probe.hip -o tools/bin/lat_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef double d4 __attribute__((ext_vector_type(4)));
+__global__ void probe(double* out, long long* cyc, double seed) {
+  const int lane = threadIdx.x;
+  double x = seed + lane * 1e-3;
+  long long t0, t1;
+  constexpr int N = 256;
+  // (a) dependent v_rcp_f64
+  t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 16
+  for (int i = 0; i < N; ++i) x = __builtin_amdgcn_rcp(x);
+  asm volatile("" : "+v"(x));
+  t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[0] = (t1 - t0);
+  // (b) dependent v_fma_f64
+  t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 16
+  for (int i = 0; i < N; ++i) x = fma(x, 0.999999, 1e-9);
+  asm volatile("" : "+v"(x));
+  t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[1] = (t1 - t0);
+  // (c) dependent MFMA f64 16x16x4 (accumulator chain)
+  d4 acc = {x, x, x, x};
+  t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 16
+  for (int i = 0; i < N; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(1e-3, 1e-3, acc, 0, 0, 0);
+  asm volatile("" : "+v"(acc));
+  t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[2] = (t1 - t0);
+  // (d) MFMA whose A operand depends on the previous MFMA's result through a VALU op
+  t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 16
+  for (int i = 0; i < N; ++i) {
+    const double a = acc[0] * 1e-3;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, 1e-3, acc, 0, 0, 0);
+  }
+  asm volatile("" : "+v"(acc));
+  t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[3] = (t1 - t0);
+  // (e) the same through readlane -> scalar -> VALU
+  t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 16
+  for (int i = 0; i < N; ++i) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(acc[0]), 5), hi = __builtin_amdgcn_readlane(__double2hiint(acc[0]), 5);
+    const double a = __hiloint2double(hi, lo) * 1e-3;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, 1e-3, acc, 0, 0, 0);
+  }
+  asm volatile("" : "+v"(acc));
+  t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[4] = (t1 - t0);
+  // (f) readlane -> rcp + two Newton steps -> mul -> MFMA -> second independent MFMA (the pivot step)
+  d4 acc2 = acc;
+  t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 8
+  for (int i = 0; i < N; ++i) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(acc[0]), 5), hi = __builtin_amdgcn_readlane(__double2hiint(acc[0]), 5);
+    const double d = __hiloint2double(hi, lo);
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double a = -acc[1] * r * 1e-9;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[1], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc2[1], acc2, 0, 0, 0);
+  }
+  asm volatile("" : "+v"(acc), "+v"(acc2));
+  t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[5] = (t1 - t0);
+  // (g) the 4x4x4 f64 MFMA (4 blocks): latency of the small shape
+  t0 = __builtin_amdgcn_s_memtime();
+  double s = acc[0];
+#pragma unroll 16
+  for (int i = 0; i < N; ++i) s = __builtin_amdgcn_mfma_f64_4x4x4f64(1e-3, 1e-3, s, 0, 0, 0);
+  asm volatile("" : "+v"(s));
+  t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[6] = (t1 - t0);
+  // (h) dependent ds_bpermute chain
+  t0 = __builtin_amdgcn_s_memtime();
+  int v = lane;
+#pragma unroll 16
+  for (int i = 0; i < N; ++i) v = __builtin_amdgcn_ds_bpermute(((v + 1) & 63) * 4, v);
+  asm volatile("" : "+v"(v));
+  t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[7] = (t1 - t0);
+  out[lane] = x + acc[0] + acc[1] + acc2[2] + s + v;
+}
+int main() {
+  double* out;
+  long long* cyc;
+  hipMalloc(&out, 64 * 8);
+  hipMalloc(&cyc, 64 * 8);
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, out, cyc, 1.25);
+  hipDeviceSynchronize();
+  long long h[8];
+  hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
+  const char* names[8] = {"v_rcp_f64 dependent", "v_fma_f64 dependent", "mfma_f64_16x16x4 accumulator chain",
+                          "mfma <- VALU <- mfma result", "mfma <- readlane <- mfma result",
+                          "pivot step (readlane, rcp + 2 Newton, mul, 2 mfma)", "mfma_f64_4x4x4 chain", "ds_bpermute dependent"};
+  for (int i = 0; i < 8; ++i) printf("%-55s %7.1f s_memtime ticks per iteration\n", names[i], h[i] / 256.0);
+  int main2();
+  return main2();
+}
+
+// ---- the whole 16 x 16 elimination (tiles.h: factor16_acc) on one wave, repeated: cycles per call --------------------
+#include "../ls-spa_amd/csrc/tiles.h"
+__global__ void probe_factor(double* out, long long* cyc, double seed) {
+  using namespace lsspa;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wave = threadIdx.x >> 6;
+  if (wave != 0 && wave != 5) {     // the other waves of a 512-thread workgroup wait at the barrier, as in small_p
+    __syncthreads();
+    return;
+  }
+  d4 t0v, y0v;
+  for (int r = 0; r < 4; ++r) {
+    const int row = acc_row(l4, r);
+    t0v[r] = (row == l15) ? 4.0 + 0.01 * row : 0.01 * seed / (1 + row + l15);
+    y0v[r] = (row == l15) ? 1.0 : 0.0;
+  }
+  double sink = 0.0;
+  int bad = 0;
+  const long long c0 = __builtin_amdgcn_s_memtime();
+  for (int rep = 0; rep < 64; ++rep) {
+    lsspa::d4 t = t0v, y = y0v;
+    t[0] += sink * 1e-30;
+    factor16_acc<double>(t, y, 1e-12, lane, bad);
+    sink += t[3] + y[1];
+  }
+  const long long c1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = c1 - c0;
+  out[lane] = sink + bad;
+  __syncthreads();
+}
+int main2() {
+  double* out;
+  long long* cyc;
+  (void)hipMalloc(&out, 64 * 8);
+  (void)hipMalloc(&cyc, 64 * 8);
+  const int cfg[4][2] = {{1, 64}, {1, 512}, {256, 512}, {2048, 512}};
+  for (int c = 0; c < 4; ++c) {
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(probe_factor, dim3(cfg[c][0]), dim3(cfg[c][1]), 0, 0, out, cyc, 1.25);
+    (void)hipDeviceSynchronize();
+    long long h[1];
+    (void)hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
+    printf("factor16_acc<double>, grid %4d x %3d threads: %.0f ticks per 16 x 16 block (%.1f per pivot)\n", cfg[c][0], cfg[c][1],
+           h[0] / 64.0, h[0] / 64.0 / 16.0);
+  }
+  return 0;
+}

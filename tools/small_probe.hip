@@ -33,6 +33,16 @@ int main(int argc, char** argv) {
     printf("launch %s  %.1f us total | perm %.1f gather %.1f chol %.1f zcopy %.1f vsolve %.1f terms %.1f sums %.1f (us, 100 MHz clock)\n", hipGetErrorString(e), ms * 1e3,
            (st[1]-st[0])/100.0, (st[2]-st[1])/100.0, (st[3]-st[2])/100.0, (st[4]-st[3])/100.0, (st[5]-st[4])/100.0, (st[6]-st[5])/100.0, (st[7]-st[6])/100.0);
   }
+  {
+    long long st[16]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_small_stamps), sizeof st);
+    long long cy[16]; hipMemcpyFromSymbol(cy, HIP_SYMBOL(g_small_cycles), sizeof cy);
+    printf("shader clock over the kernel: %.3f GHz; first factor16: %lld cycles, second: %lld cycles\n",
+           (cy[7] - cy[0]) / ((st[7] - st[0]) * 10.0), cy[8] - cy[2], cy[11] - cy[10]);
+    long long hh[16]; hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_small_helper), sizeof hh);
+    printf("helper wave 1, block step 0 (cycles): first 4 tiles %lld, next %lld, rest %lld\n", hh[1] - hh[0], hh[2] - hh[1], hh[3] - hh[2]);
+    printf("cholesky detail (us): first factor16 %.2f | barrier+panel(0) %.2f | own trailing tile %.2f | factor16 %.2f | wait for helpers %.2f\n",
+           (st[8]-st[2])/100.0, (st[9]-st[8])/100.0, (st[10]-st[9])/100.0, (st[11]-st[10])/100.0, (st[12]-st[11])/100.0);
+  }
   int info; hipMemcpy(&info, di, 4, hipMemcpyDeviceToHost); printf("info %d lds %zu\n", info, small_p_lds_bytes(a.nb));
   return 0;
 }
