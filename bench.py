@@ -439,8 +439,9 @@ def main():
                 self.tickets[g] = eng.launch_batch(self.perms[lo:min(lo + self.d, self.end)].reshape(-1, p), True)
 
         def __call__(self, k):
+            acc = True if multi else 2      # one rank: fold and merge at once (lsspa_lift_collect, accumulate = 2)
             if self.d == 1:
-                eng.run_batch(self.perms[k], True, want_lifts=False, accumulate=True)
+                eng.run_batch(self.perms[k], True, want_lifts=False, accumulate=acc)
             else:
                 g, j = divmod(k - self.base, self.d)
                 if j == 0:
@@ -448,12 +449,13 @@ def main():
                     if eng.lanes == 2:
                         self.launch(g + 1)       # the second lane holds the next group: its upload and kernels run
                                                  # while this group is accumulated step by step
-                eng.collect_batch(self.tickets[g], want_lifts=False, accumulate=True, first=j * self.b_rank,
+                eng.collect_batch(self.tickets[g], want_lifts=False, accumulate=acc, first=j * self.b_rank,
                                   count=self.b_rank)
                 if j == self.d - 1 or k == self.end - 1:
                     del self.tickets[g]
-            comm.allreduce_pending(eng)
-            eng.merge()
+            if multi:
+                comm.allreduce_pending(eng)
+                eng.merge()
 
     def timed_region(step, n_warm, n_total):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; returns this rank's

@@ -105,8 +105,11 @@ int lsspa_get_factors(lsspa_ctx* ctx, double* R_tr, double* q_tr, double* F_te, 
 /* a2 + a3 -- replaces square_shapley over a batch of orderings and the antithetical
  * pairing (ls_spa/ls_spa.py:203-208, :256-287).  perms: host int32 [B][p].  With
  * antithetical != 0 every ordering is also evaluated reversed and the two lift vectors are
- * averaged (one sample).  lifts_out: host [B][p] or NULL.  accumulate != 0: add the batch's
- * moments about the running mean to the pending-batch buffer (a4). */
+ * averaged (one sample).  lifts_out: host [B][p] or NULL.  accumulate = 1: add the batch's
+ * moments about the running mean to the pending-batch buffer (a4: all-reduce it over the ranks if there are several,
+ * then lsspa_stats_merge).  accumulate = 2, one GPU: fold the batch into the running statistics at once -- the effect
+ * of accumulate = 1 followed by lsspa_stats_merge (ls_spa/ls_spa.py:212-216 for the whole batch), in one launch for
+ * p <= 128; refused (LSSPA_ERR_STATE) while a batch is pending. */
 int lsspa_lift_batch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t antithetical,
                      double* lifts_out, int32_t accumulate);
 /* The two halves of lsspa_lift_batch.  lsspa_lift_launch enqueues every kernel of a batch up to its lift vectors and

@@ -308,6 +308,81 @@ __global__ __launch_bounds__(64) void stats_small_kernel(const double* __restric
   if (blockIdx.x == 0 && lane == 0) buf[0] = accumulate ? buf[0] + (double)n_samples : (double)n_samples;
 }
 
+// The same tiles with the Chan merge folded in, for a single GPU (nothing to all-reduce between the batch moments and
+// the merge): the workgroup of tile (ti, tj) also sums the columns of its two blocks of D, so it can add
+//     Q + (n nb / (n + nb) - nb) (S_a / nb) (S_b / nb)
+// to its tile of M2 at once; the diagonal tiles write the advanced mean.  The mean (and n) are READ by every tile,
+// so the new ones go to a second buffer (mean_out, state_out) that the host swaps in afterwards: one launch, no
+// pending buffer, no ticket -- the two launches it replaces were a fifth of a p = 100 step.
+__global__ __launch_bounds__(64) void stats_small_fused_kernel(const double* __restrict__ lifts,
+                                                               const double* __restrict__ mean,
+                                                               const double* __restrict__ state,
+                                                               double* __restrict__ mean_out,
+                                                               double* __restrict__ state_out, double* __restrict__ M2,
+                                                               int n_samples, int p) {
+  const int lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
+  int ti = 0, t = blockIdx.x;
+  while (t >= ti + 1) {
+    t -= ti + 1;
+    ++ti;
+  }
+  const int tj = t;
+  const bool diag = ti == tj;
+  const int a = 16 * ti + l15, b = 16 * tj + l15;
+  const int ac = a < p ? a : p - 1, bc = b < p ? b : p - 1;     // clamped addresses, value selected afterwards
+  const double mua = mean[ac], mub = mean[bc];
+  const double n = state[0], nb = (double)n_samples;
+  d4 acc = d4_zero(), suma = d4_zero(), sumb = d4_zero();
+  constexpr int KT = 32;
+  for (int s0 = 0; s0 < n_samples; s0 += 4 * KT) {
+    double ra[KT], rb[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+      const int s = s0 + 4 * kk + l4;
+      const int sc = s < n_samples ? s : n_samples - 1;
+      ra[kk] = lifts[(int64_t)sc * p + ac];
+      rb[kk] = lifts[(int64_t)sc * p + bc];
+    }
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+      const int s = s0 + 4 * kk + l4;
+      const double av = (s < n_samples && a < p) ? ra[kk] - mua : 0.0;
+      const double bv = (s < n_samples && b < p) ? rb[kk] - mub : 0.0;
+      acc = mfma(av, bv, acc);
+      suma = mfma(av, 1.0, suma);     // element (row a, any column) = sum over the samples of D[., a]
+      sumb = mfma(1.0, bv, sumb);     // element (any row, column b) = sum over the samples of D[., b]
+    }
+  }
+  const double coef = n * nb / (n + nb) - nb;
+  const double inv = 1.0 / nb;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ai = 16 * ti + acc_row(l4, r), bi = 16 * tj + l15;
+    if (ai < p && bi < p) {
+      const int64_t o = (int64_t)ai * p + bi, om = (int64_t)bi * p + ai;
+      const double v = M2[o] + (acc[r] + coef * (suma[r] * inv) * (sumb[r] * inv));
+      M2[o] = v;
+      if (!diag) M2[om] = v;
+    }
+    if (diag && l15 == 0 && ai < p) mean_out[ai] = mean[ai] + suma[r] / (n + nb);
+  }
+  if (blockIdx.x == 0 && lane == 0) {
+    state_out[0] = n + nb;
+    state_out[1] = 0.0;     // the fused merge kernel's ticket, kept clear in both buffers
+  }
+}
+
+hipError_t launch_stats_small_fused(const double* lifts, const double* mean, const double* state, double* mean_out,
+                                    double* state_out, double* M2, int n_samples, int p, hipStream_t st) {
+  if (!stats_small_fusable(n_samples, p)) return hipErrorInvalidValue;
+  const int t16 = (p + 15) / 16, n_tiles = t16 * (t16 + 1) / 2;
+  hipLaunchKernelGGL(stats_small_fused_kernel, dim3(n_tiles), dim3(64), 0, st, lifts, mean, state, mean_out, state_out,
+                     M2, n_samples, p);
+  return hipGetLastError();
+}
+
+bool stats_small_fusable(int n_samples, int p) { return p >= 1 && p <= 128 && n_samples >= 1 && n_samples <= 512; }
+
 int stats_batch_slices(int n_samples, int p) {
   // a handful of tiles and a few hundred samples: one launch beats slices plus their reduction (every launch
   // costs the host more than this kernel runs)

@@ -153,22 +153,35 @@ __global__ __launch_bounds__(512) void small_p_kernel(SmallArgs a) {
     const double aug = a.aug[half];
     const int r = t2 >> 4, c = t2 & 15;
     const int swrc = sw(r, c);
-    for (int bi = 0; bi < nb; ++bi) {
-      const int i = 16 * bi + r;
-      const int64_t rowoff = (int64_t)s_perm[min(i, p - 1)] * a.ld_src;
-#pragma unroll 4
-      for (int bj = 0; bj <= bi; ++bj) {
-        const int j = 16 * bj + c;
-        // unconditional clamped loads, value selected afterwards (a guarded load is a branch and a wait per element)
-        const double gv = S[rowoff + s_perm[min(j, p - 1)]];
-        const double av = sv[s_perm[min(j, p - 1)]];
-        double v;
-        if (i < p) v = (j <= i) ? gv : 0.0;
-        else if (i == p) v = (j < p) ? av : (j == p ? aug : 0.0);
-        else v = (i == j) ? 1.0 : 0.0;
-        M[tri_blk(bi, bj) * 256 + swrc] = v;
-      }
+    // every index this thread needs, then every element: all of a thread's (up to 36) scattered 8-byte loads are in
+    // flight together -- one round trip to the L2 instead of one per four elements
+    int pr[8], pc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      pr[b] = s_perm[min(16 * b + r, p - 1)];
+      pc[b] = s_perm[min(16 * b + c, p - 1)];
     }
+    double gv[36], av[8];
+#pragma unroll
+    for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+      for (int bj = 0; bj <= bi; ++bj)
+        if (bi < nb) gv[bi * (bi + 1) / 2 + bj] = S[(int64_t)pr[bi] * a.ld_src + pc[bj]];
+#pragma unroll
+    for (int bj = 0; bj < 8; ++bj)
+      if (bj < nb) av[bj] = sv[pc[bj]];
+#pragma unroll
+    for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+      for (int bj = 0; bj <= bi; ++bj)
+        if (bi < nb) {
+          const int i = 16 * bi + r, j = 16 * bj + c;
+          double v;
+          if (i < p) v = (j <= i) ? gv[bi * (bi + 1) / 2 + bj] : 0.0;
+          else if (i == p) v = (j < p) ? av[bj] : (j == p ? aug : 0.0);
+          else v = (i == j) ? 1.0 : 0.0;
+          M[(bi * (bi + 1) / 2 + bj) * 256 + swrc] = v;
+        }
     if (t2 < 128) {
       const int i = t2;
       s_d0[half * 128 + i] = (i < p) ? S[(int64_t)s_perm[i] * a.ld_src + s_perm[i]] : (i == p ? aug : 1.0);
@@ -294,33 +307,25 @@ __global__ __launch_bounds__(512) void small_p_kernel(SmallArgs a) {
   __syncthreads();
   SSTAMP(5);
 
-  // ---- lift terms: thread c walks column c of V downwards, w[j][c] = V[j][c] (2 y~_c - N_j - N_{j-1}) ---------
-  if (tid < p) {
-    const int c = tid, cbk = c >> 4, cc = c & 15;
-    const double y2 = 2.0 * s_y[c];
-    double N = 0.0;
-    int j = c;
-    for (; j + 3 < p; j += 4) {
-      int off[4];
-      double v[4], zz[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        off[u] = tri_blk((j + u) >> 4, cbk) * 256 + sw((j + u) & 15, cc);
-        v[u] = M1[off[u]];
-        zz[u] = s_z[j + u];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const double Nn = fma(zz[u], v[u], N);
-        M0[off[u]] = v[u] * (y2 - Nn - N);      // L is dead: its storage takes the terms
-        N = Nn;
-      }
-    }
-    for (; j < p; ++j) {
+  // ---- lift terms: w[j][c] = V[j][c] (2 y~_c - N_j - N_{j-1}),  N_j = sum_{k <= j} z_k V[k][c], down column c.  Four
+  // threads per column (adjacent lanes), each a quarter of the rows c .. p - 1: the partial sums of the quarters first,
+  // then each quarter's scan from the sum of the quarters above it -- a quarter of the dependent chain.
+  {
+    const int c = tid >> 2, sq = tid & 3;
+    const int cbk = c >> 4, cc = c & 15;
+    const int len = (c < p) ? p - c : 0, per = (len + 3) >> 2;
+    const int j0 = c + min(sq * per, len), j1 = c + min((sq + 1) * per, len);
+    double part = 0.0;
+    for (int j = j0; j < j1; ++j) part = fma(s_z[j], M1[tri_blk(j >> 4, cbk) * 256 + sw(j & 15, cc)], part);
+    // exclusive prefix over the four quarters of the column
+    const double p1 = __shfl_up(part, 1, 4), p2 = __shfl_up(part, 2, 4), p3 = __shfl_up(part, 3, 4);
+    double N = (sq >= 1 ? p1 : 0.0) + (sq >= 2 ? p2 : 0.0) + (sq >= 3 ? p3 : 0.0);
+    const double y2 = 2.0 * s_y[min(c, 127)];
+    for (int j = j0; j < j1; ++j) {
       const int off = tri_blk(j >> 4, cbk) * 256 + sw(j & 15, cc);
       const double v = M1[off];
       const double Nn = fma(s_z[j], v, N);
-      M0[off] = v * (y2 - Nn - N);
+      M0[off] = v * (y2 - Nn - N);      // L is dead: its storage takes the terms
       N = Nn;
     }
   }

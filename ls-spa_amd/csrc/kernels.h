@@ -128,6 +128,11 @@ hipError_t launch_lift(const LiftArgs& a, hipStream_t st);
 int stats_batch_slices(int n_samples, int p);
 hipError_t launch_stats_batch(const double* lifts, const double* mean, double* buf, int n_samples, int p,
                               int accumulate, double* parts, hipStream_t st);
+// single GPU, small p: batch moments AND merge in one launch (no pending buffer): reads (mean, state[0] = n), writes
+// the advanced ones to (mean_out, state_out) -- the caller swaps the buffers -- and updates M2 in place
+bool stats_small_fusable(int n_samples, int p);
+hipError_t launch_stats_small_fused(const double* lifts, const double* mean, const double* state, double* mean_out,
+                                    double* state_out, double* M2, int n_samples, int p, hipStream_t st);
 // Chan merge of the pending batch into (n, mean, M2); n lives in state[0] (state[1] is the fused kernel's ticket and
 // must start at zero).  *cleared: the launch also zeroed the pending buffer (small p: one fused kernel)
 hipError_t launch_stats_merge(double* buf, double* state_n, double* mean, double* M2, int p, hipStream_t st,

@@ -107,6 +107,7 @@ struct lsspa_ctx {
 
   // running statistics
   DevBuf<double> mean, M2, pend, state_n, stat_parts;
+  DevBuf<double> mean_alt, state_alt;   // the other halves of the (mean, n) pair: lsspa_lift_collect(accumulate = 2)
   bool pend_dirty = false;
   // history of lift vectors + device-side error estimator
   DevBuf<double> hist, xi_d, draws, err_out;
@@ -331,6 +332,8 @@ int set_dims(lsspa_ctx* ctx, int p, int m, int tri) {
   TRY(dev_alloc(ctx, ctx->M2, (size_t)p * p));
   TRY(dev_alloc(ctx, ctx->pend, (size_t)1 + p + (size_t)p * p));
   TRY(dev_alloc(ctx, ctx->state_n, 8));
+  TRY(dev_alloc(ctx, ctx->mean_alt, (size_t)p));
+  TRY(dev_alloc(ctx, ctx->state_alt, 8));
   TRY(dev_alloc(ctx, ctx->info_d, 8));
   // so does the lift history (row stride): it has to be enabled again for the new problem
   ctx->hist_cap = 0;
@@ -344,6 +347,7 @@ int stats_reset(lsspa_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->M2.ptr, 0, sizeof(double) * (size_t)p * p, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->pend.ptr, 0, sizeof(double) * ((size_t)1 + p + (size_t)p * p), ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->state_n.ptr, 0, sizeof(double) * 8, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->state_alt.ptr, 0, sizeof(double) * 8, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->info_d.ptr, 0, sizeof(int32_t) * 8, ctx->stream));
   ctx->pend_dirty = false;
   ctx->hist_n = 0;
@@ -780,14 +784,28 @@ int lift_collect(lsspa_ctx* ctx, Lane& L, int first, int count, double* lifts_ou
     return ctx->fail(LSSPA_ERR_ARG, "parts of a launched batch are collected front to back, without gaps");
   const double* src = L.lifts.ptr + (size_t)first * p;
   if (ctx->n_lanes == 2 && first == 0) HIPCHK(hipStreamWaitEvent(ctx->stream, L.ev_done, 0));
-  if (accumulate) {
+  if (accumulate == 2 && ctx->pend_dirty)
+    return ctx->fail(LSSPA_ERR_STATE, "accumulate = 2 (fold and merge at once) with a batch pending: merge it first");
+  if (accumulate == 2 && stats_small_fusable(count, p)) {
+    // single GPU, small p: moments and merge in ONE launch; the advanced mean and n land in the other halves of the
+    // pairs, which then become the current ones
     ProfScope ps(ctx, LSSPA_K_STATS);
-    const int nz = stats_batch_slices(count, p);
-    if (nz > 1) TRY(dev_alloc(ctx, ctx->stat_parts, (size_t)nz * ((size_t)1 + p + (size_t)p * p)));
-    HIPCHK(launch_stats_batch(src, ctx->mean.ptr, ctx->pend.ptr, count, p, ctx->pend_dirty ? 1 : 0,
-                              nz > 1 ? ctx->stat_parts.ptr : nullptr, ctx->stream));
-    ctx->pend_dirty = true;
+    HIPCHK(launch_stats_small_fused(src, ctx->mean.ptr, ctx->state_n.ptr, ctx->mean_alt.ptr, ctx->state_alt.ptr,
+                                    ctx->M2.ptr, count, p, ctx->stream));
+    std::swap(ctx->mean, ctx->mean_alt);
+    std::swap(ctx->state_n, ctx->state_alt);
     if (ctx->hist_cap > 0) TRY(hist_append(ctx, src, count, hipMemcpyDeviceToDevice));
+  } else if (accumulate) {
+    {
+      ProfScope ps(ctx, LSSPA_K_STATS);
+      const int nz = stats_batch_slices(count, p);
+      if (nz > 1) TRY(dev_alloc(ctx, ctx->stat_parts, (size_t)nz * ((size_t)1 + p + (size_t)p * p)));
+      HIPCHK(launch_stats_batch(src, ctx->mean.ptr, ctx->pend.ptr, count, p, ctx->pend_dirty ? 1 : 0,
+                                nz > 1 ? ctx->stat_parts.ptr : nullptr, ctx->stream));
+      ctx->pend_dirty = true;
+      if (ctx->hist_cap > 0) TRY(hist_append(ctx, src, count, hipMemcpyDeviceToDevice));
+    }
+    if (accumulate == 2) TRY(lsspa_stats_merge(ctx));   // the general path: the same effect in its usual launches
   }
   if (lifts_out) {
     HIPCHK(hipMemcpyAsync(lifts_out, src, sizeof(double) * (size_t)count * p, hipMemcpyDeviceToHost, ctx->stream));
@@ -914,6 +932,7 @@ int lsspa_destroy(lsspa_ctx* ctx) try {
   dev_free(ctx->G); dev_free(ctx->g); dev_free(ctx->H); dev_free(ctx->h); dev_free(ctx->Ft);
   dev_free(ctx->ytil); dev_free(ctx->scal); dev_free(ctx->info_d);
   dev_free(ctx->mean); dev_free(ctx->M2); dev_free(ctx->pend); dev_free(ctx->state_n);
+  dev_free(ctx->mean_alt); dev_free(ctx->state_alt);
   dev_free(ctx->Cred);
   dev_free(ctx->Gf); dev_free(ctx->Hf);
   free_workspace(ctx);

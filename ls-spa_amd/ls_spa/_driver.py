@@ -226,6 +226,10 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
 
     estimate = p >= 9
     keep_lifts = return_attribution_history or error_estimator == "lowrank"
+    # one rank: nothing to all-reduce between a chunk's moments and their merge -- the engine folds the chunk into the
+    # running statistics at once (accumulate = 2; one launch instead of two plus the merge call for small p)
+    single = comm.world == 1 and not getattr(comm, "_force", False)
+    acc_mode = 2 if single else True
     engine.reset_stats()
     on_device = error_estimator == "device" and estimate
     if on_device:
@@ -357,14 +361,15 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
         local = None
         if len(mine):
             if ticket is not None:
-                local = engine.collect_batch(ticket, want_lifts=keep_lifts, accumulate=True, first=first,
+                local = engine.collect_batch(ticket, want_lifts=keep_lifts, accumulate=acc_mode, first=first,
                                              count=len(mine))
             else:
-                local = engine.run_batch(mine, antithetical, want_lifts=keep_lifts, accumulate=True)
+                local = engine.run_batch(mine, antithetical, want_lifts=keep_lifts, accumulate=acc_mode)
             if on_device:
                 local_idx.append(np.arange(i + comm.rank, i + n_new, comm.world))
-        comm.allreduce_pending(engine)
-        engine.merge()
+        if not single:
+            comm.allreduce_pending(engine)
+            engine.merge()
         if keep_lifts:
             counts = [len(chunk[r::comm.world]) for r in range(comm.world)]
             parts = comm.gather_lifts(local if local is not None else np.empty((0, p)), counts)

@@ -196,8 +196,14 @@ class HipEngine:
         B = perms.shape[0]
         out = np.empty((B, self.p)) if want_lifts else None
         self._check(self._lib.lsspa_lift_batch(self._h, N.iptr(perms), B, int(bool(antithetical)),
-                                               N.dptr(out), int(bool(accumulate))))
+                                               N.dptr(out), self._acc_mode(accumulate)))
         return out
+
+    @staticmethod
+    def _acc_mode(accumulate):
+        """False / True / 2: nothing, into the pending buffer (all-reduce + merge() follow), or -- one GPU -- folded
+        into the running statistics at once (no merge() call; include/lsspa.h)."""
+        return 2 if (accumulate is not True and accumulate == 2) else int(bool(accumulate))
 
     def set_lanes(self, n: int):
         """1: batches run one after the other (default).  2: successive batches alternate between two workspaces on
@@ -222,7 +228,8 @@ class HipEngine:
         t, B = ticket
         count = B - first if count is None else int(count)
         out = np.empty((count, self.p)) if want_lifts else None
-        self._check(self._lib.lsspa_lift_collect(self._h, t, int(first), count, N.dptr(out), int(bool(accumulate))))
+        self._check(self._lib.lsspa_lift_collect(self._h, t, int(first), count, N.dptr(out),
+                                                 self._acc_mode(accumulate)))
         return out
 
     def discard_batch(self, ticket):

@@ -43,6 +43,8 @@ class OracleEngine:
         self.calls.append(len(lifts))
         if accumulate:
             self._accumulate(lifts)
+            if accumulate is not True and accumulate == 2:
+                self.merge()
         return lifts if want_lifts else None
 
     def discard_batch(self, ticket):
@@ -104,6 +106,8 @@ class OracleEngine:
         lifts = np.array([O.sample_lift(*self._red, self.y_norm_sq, o, antithetical) for o in perms])
         if accumulate:
             self._accumulate(lifts)
+            if accumulate is not True and accumulate == 2:
+                self.merge()
         return lifts if want_lifts else None
 
     def _accumulate(self, lifts):

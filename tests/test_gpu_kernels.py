@@ -578,3 +578,49 @@ def test_fused_small_p_flags_collinear_features():
         assert eng.info() & 1      # LSSPA_INFO_NOT_PD, as on the general path
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("p,bsz", [(12, 7), (100, 128), (100, 16), (127, 40), (130, 24)])
+def test_accumulate_and_merge_at_once(p, bsz):
+    """lsspa_lift_collect / lsspa_lift_batch with accumulate = 2 (one GPU: batch moments and Chan merge in one launch
+    for p <= 128, the usual launches beyond) leaves the running statistics where accumulate = 1 followed by
+    lsspa_stats_merge leaves them, batch after batch; a pending batch is refused."""
+    from ls_spa._engine import HipEngine
+    Xa, Xe, ya, ye = problem(31, p, 4 * p + 50, 3 * p + 40)
+    rng = np.random.default_rng(5)
+    two, one = HipEngine(0), HipEngine(0)
+    try:
+        for eng in (two, one):
+            eng.load_data(Xa, Xe, ya, ye, 1e-3)
+        for _ in range(4):
+            perms = np.array([rng.permutation(p) for _ in range(bsz)])
+            two.run_batch(perms, True, accumulate=True)
+            two.merge()
+            one.run_batch(perms, True, accumulate=2)
+            n2, m2, c2 = two.stats()
+            n1, m1, c1 = one.stats()
+            assert n1 == n2
+            np.testing.assert_allclose(m1, m2, rtol=0, atol=1e-15)
+            np.testing.assert_allclose(c1, c2, rtol=1e-13, atol=1e-18)
+        # launch / collect in parts, the second part at once
+        perms = np.array([rng.permutation(p) for _ in range(2 * bsz)])
+        t2, t1 = two.launch_batch(perms, True), one.launch_batch(perms, True)
+        for first in (0, bsz):
+            two.collect_batch(t2, accumulate=True, first=first, count=bsz)
+            two.merge()
+            one.collect_batch(t1, accumulate=2, first=first, count=bsz)
+        np.testing.assert_allclose(one.stats()[2], two.stats()[2], rtol=1e-13, atol=1e-18)
+        assert one.stats()[0] == two.stats()[0] == 6 * bsz
+        # against numpy on the lift vectors themselves
+        one.reset_stats()
+        lifts = one.run_batch(perms, True, want_lifts=True, accumulate=2)
+        n, mean, cov = one.stats()
+        assert n == 2 * bsz
+        np.testing.assert_allclose(mean, lifts.mean(0), rtol=0, atol=1e-14)
+        np.testing.assert_allclose(cov, np.cov(lifts, rowvar=False, bias=True), rtol=0, atol=1e-14)
+        one.run_batch(perms[:3], True, accumulate=True)
+        with pytest.raises(Exception, match="pending"):
+            one.run_batch(perms[:3], True, accumulate=2)
+    finally:
+        two.close()
+        one.close()
