@@ -904,7 +904,14 @@ __device__ __forceinline__ void factor_block64_core(T* __restrict__ M, int p_pad
   for (int kb = 0; kb < 4; ++kb) {
     T* const blk = s_t + (16 * kb) * DI_LD + 16 * kb;
     T* const inv = s_x + kb * 16 * XD_LD;
-    if (w == 0) wave_factor16<T>(blk, inv, s_dd, __shfl(tol64, 16 * kb + (lane & 15)), lane, bad);
+    if (w == 0) {
+      // the pivot chain is a sequence of DEPENDENT matrix instructions (two per pivot, a third of the pipe's time):
+      // with priority over the co-resident workgroup's k-loop, which fills the pipe, each issues when it is ready
+      // instead of queueing behind independent work that can wait
+      __builtin_amdgcn_s_setprio(3);
+      wave_factor16<T>(blk, inv, s_dd, __shfl(tol64, 16 * kb + (lane & 15)), lane, bad);
+      __builtin_amdgcn_s_setprio(0);
+    }
     __syncthreads();
     FSTAMP(2 + 3 * kb);
     // (2): 3 - kb panel tiles and kb inverse tiles: three tiles in all, one per wave

@@ -202,6 +202,9 @@ __global__ __launch_bounds__(512) void small_p_kernel(SmallArgs a) {
     const int fw = half;
     if (w == fw) wave_factor16_sw(M, inv, rd, d0, a.piv_tol, lane, bad);
     SSTAMP(8);
+    // the factoring waves' pivot chains are dependent matrix instructions; the helpers' trailing products are not:
+    // priority lets each link of the chain issue when it is ready
+    if (w == fw) __builtin_amdgcn_s_setprio(3);
     __syncthreads();
     for (int kb = 0; kb < nb; ++kb) {
       // panel: L[ib][kb] = T[ib][kb] Ld^-T, in place

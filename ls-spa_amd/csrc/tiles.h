@@ -363,6 +363,10 @@ __device__ __forceinline__ T bperm(int addr, T v) {
 //     Y[i][j], j <= i  =  (L^-1)[i][j] L[i][i].
 // tol_lane: lane l holds the pivot threshold of row l & 15.  A pivot at or below it (or NaN) is replaced by 1 and
 // flagged, as before.
+// Measured (tools/lat_probe.hip, one wave): 337 cycles per pivot, of which the matrix instruction is 64 + 15 wait
+// states; the rest is the scalar chain pivot -> threshold test -> reciprocal (20 + two Newton steps of 2 x 7.4) ->
+// multiplier.  A two-pivots-per-step form (2 x 2 pivot blocks: half the matrix instructions and reciprocals, one
+// lane-pair exchange per step) was written and measured slower, 755 against 674 cycles per pair, and not kept.
 template <typename T>
 __device__ __forceinline__ void factor16_acc(typename Tr<T>::acc_t& t, typename Tr<T>::acc_t& y, const double tol_lane,
                                              const int lane, int& bad) {
