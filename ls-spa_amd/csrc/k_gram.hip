@@ -448,6 +448,42 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
     C[(int64_t)(j0 + r0 + 8 * q) * P1pad + i0 + c] = s_t[c][r0 + 8 * q];
 }
 
+// The same sum for problems with only a few tile pairs (p <= ~250), where 16 workgroups a pair leave the chip empty
+// and the slices are many and short: one workgroup per 16 x 16 block of the pair, one element per thread, the slices
+// fetched eight at a time (independent loads) and added in their fixed order.
+__global__ __launch_bounds__(256) void gram_reduce_small_kernel(const double* __restrict__ slabs, GramPlan plan,
+                                                                int n_pairs, int P1pad, double* __restrict__ C,
+                                                                int accumulate) {
+  int pair = blockIdx.x, ti = 0;
+  while (pair >= ti + 1) {
+    pair -= ti + 1;
+    ++ti;
+  }
+  const int tj = pair;
+  const int by = blockIdx.y >> 3, bx = blockIdx.y & 7;          // 16 x 16 block (rows, columns) of the 128 x 128 tile
+  const bool diag = (ti == tj);
+  if (diag && by < bx) return;     // above the diagonal of a diagonal tile: never written, never read
+  const int n_split = diag ? plan.slices[2] : (plan.cnt[1] > 0 && ti == plan.nt - 1) ? plan.slices[1] : plan.slices[0];
+  const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+  const int row = 16 * by + r, col = 16 * bx + c;
+  const double* src = slabs + (int64_t)blockIdx.x * (128 * 128) + row * 128 + col;
+  const int64_t slice_stride = (int64_t)n_pairs * (128 * 128);
+  double v = 0.0;
+  int k = 0;
+  for (; k + 8 <= n_split; k += 8) {
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)(k + u) * slice_stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; k < n_split; ++k) v += src[(int64_t)k * slice_stride];
+  const int64_t o = (int64_t)(ti * 128 + row) * P1pad + tj * 128 + col;
+  if (accumulate) v += C[o];       // fixed chunk order: still reproducible
+  C[o] = v;
+  if (!diag) C[(int64_t)(tj * 128 + col) * P1pad + ti * 128 + row] = v;
+}
+
 __global__ __launch_bounds__(256) void gram_finalize_kernel(const double* __restrict__ C, int P1pad, int p,
                                                             double scale, double reg, double* __restrict__ G,
                                                             int64_t ldg, double* __restrict__ g,
@@ -508,7 +544,10 @@ int gram_default_split(int64_t n, int p) {
   // whole rounds of 512 best (p = 1000: 16 -> 21 x 16 + 7 x 14 + 4 x 18 = 506), with slices of at least 256 rows
   // and at most ~8 rounds
   const int nt = n_tiles_of(p);
-  const int64_t cap = std::max<int64_t>(1, (n + 255) / 256);
+  // slices of at least 256 rows -- 128 where the units are so few (one or two tiles) that the launch is a chain of
+  // load round trips, one per 16-row chunk, whatever the slice count
+  const int64_t min_rows = (nt <= 2) ? 128 : 256;
+  const int64_t cap = std::max<int64_t>(1, (n + min_rows - 1) / min_rows);
   int best = 1;
   double best_eff = 0.0;
   for (int64_t s = 1; s <= cap; ++s) {
@@ -543,7 +582,11 @@ hipError_t launch_gram(const GramArgs& a, hipStream_t st) {
                        (const double*)a.y, a.n, a.ld, a.p, g, a.slabs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(np, 16), dim3(256), 0, st, a.slabs, g, np, P1pad, a.C, a.accumulate);
+  if (np <= 3)
+    hipLaunchKernelGGL(gram_reduce_small_kernel, dim3(np, 64), dim3(256), 0, st, a.slabs, g, np, P1pad, a.C,
+                       a.accumulate);
+  else
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(np, 16), dim3(256), 0, st, a.slabs, g, np, P1pad, a.C, a.accumulate);
   return hipGetLastError();
 }
 

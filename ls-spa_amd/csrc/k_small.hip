@@ -25,6 +25,7 @@ __device__ long long g_small_stamps[16];
 __device__ long long g_small_cycles[16];
 #define SSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_small_stamps[i] = wall_clock64(); g_small_cycles[i] = __builtin_amdgcn_s_memtime(); } } while (0)
 __device__ long long g_small_helper[16];
+__device__ long long g_small_fstamp[4];
 #define HSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 64) g_small_helper[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SSTAMP(i) do { } while (0)
@@ -52,7 +53,16 @@ __device__ __forceinline__ void wave_factor16_sw(double* blk, double* s_inv, dou
     t[r] = (l15 <= row) ? blk[sw(row, l15)] : blk[sw(l15, row)];   // upper part: mirrored (what is stored there is ignored)
     y[r] = (row == l15) ? 1.0 : 0.0;
   }
-  factor16_acc<double>(t, y, piv_tol * d0[l15], lane, bad);
+  const double tol_lane = piv_tol * d0[l15];
+#ifdef LSSPA_SMALL_STAMPS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_small_fstamp[0] = __builtin_amdgcn_s_memtime();
+#endif
+  factor16_acc<double>(t, y, tol_lane, lane, bad);
+#ifdef LSSPA_SMALL_STAMPS
+  asm volatile("" : "+v"(t), "+v"(y));
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_small_fstamp[1] = __builtin_amdgcn_s_memtime();
+#endif
   double dj;
   const bool holds = acc_diag<double>(t, l15, l4, dj);
   const double rs_mine = fast_rsqrt<double>(dj);                  // 1 / L[j][j]: one reciprocal square root per lane

@@ -1,4 +1,4 @@
-"""Copy the artefacts of tools/r02_final.sh from gpurun_out/ (scratch) into profiles/ (tracked) and derive the
+"""Copy the artefacts of tools/r03_final.sh (python tools/collect_profiles.py r03) from gpurun_out/ (scratch) into profiles/ (tracked) and derive the
 PMC traffic summaries.  Run in the build container after the gpurun call has merged its output."""
 import os
 import shutil
@@ -6,7 +6,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r02_final")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"      # round tag: gpurun_out/<tag>_final -> profiles/<tag>_*
+SRC = os.path.join(ROOT, "gpurun_out", f"{TAG}_final")
 DST = os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
 
@@ -16,33 +17,33 @@ def cp(src, dst):
     print("profiles/" + dst)
 
 
-for name in ("bench_c3", "bench_c2", "bench_c5", "bench_c3_f32", "bench_c3_rehearse", "bench_c3_strong16_rehearse"):
-    cp(name + ".json", "r02_" + name + ".json")
-with open(os.path.join(DST, "r02_mfma_bench5.log"), "w") as out:
-    out.write("# tools/mfma_bench5.hip on the MI355X of this run: the k-loop of the two-level kernels in isolation\n"
-              "# (global prefetch -> LDS -> barrier -> fragments -> MFMA, 128 x 128 tile per workgroup, 16 flop per operand byte)\n\n"
-              "## all-zero operands\n" + open(os.path.join(SRC, "mfma_bench5_zero.log")).read() +
-              "\n## random operands (./mfma_bench5 random)\n" + open(os.path.join(SRC, "mfma_bench5_random.log")).read())
-print("profiles/r02_mfma_bench5.log")
-with open(os.path.join(DST, "r02_kloop_ceiling.log"), "w") as out:
-    out.write("# What the fp64 / fp32 matrix pipe delivers on the MI355X of this run (tools/r02_final.sh)\n\n"
-              "## tools/mfma_bench6.hip: the fp64 k-loop of the two-level kernels in isolation, steady-state clock\n" +
-              open(os.path.join(SRC, "mfma_bench6.log")).read() +
-              "\n## tools/mfma_bench7.hip: the fp32 k-loop\n" + open(os.path.join(SRC, "mfma_bench7.log")).read() +
-              "\n## tools/dgemm_probe.py: the vendor library's GEMM / batched GEMM / batched Cholesky / triangular solve (torch -> rocBLAS / hipBLASLt / rocSOLVER)\n" +
-              "".join(l for l in open(os.path.join(SRC, "dgemm_probe.log")) if "amdgpu.ids" not in l) +
-              "\n## tools/dgemm_probe2.py: shapes like ours (X^T X at C3, batched 1024^3 NN / NT)\n" +
-              "".join(l for l in open(os.path.join(SRC, "dgemm_probe2.log")) if "amdgpu.ids" not in l) +
-              "\n## tools/gram_time.py: our Gram reduction, both sides per line (C3: 2 x 1.003e11 flop; C5 per side as printed)\n" +
-              "".join(l for l in open(os.path.join(SRC, "gram_time.log")) if "amdgpu.ids" not in l))
-print("profiles/r02_kloop_ceiling.log")
+for name in ("bench_c3", "bench_c3_correlated", "bench_c2", "bench_c5", "bench_c3_f32", "bench_c3_rehearse",
+             "bench_c3_strong16_rehearse"):
+    cp(name + ".json", f"{TAG}_" + name + ".json")
+with open(os.path.join(DST, f"{TAG}_probes.log"), "w") as out:
+    for title, f in (("tools/gram_time.py: the Gram reduction, both sides per line (C3: 2 x 1.003e11 flop; C5 per side as printed); "
+                      "flags 0 = XCD-contiguous unit map, 65536 = natural map", "gram_time.log"),
+                     ("tools/gram_pmc.sh: FETCH_SIZE / WRITE_SIZE (KiB as reported; FETCH to be doubled) per gram_kernel dispatch, "
+                      "the dispatches alternating between the two maps as in gram_time.py", "gram_pmc.log"),
+                     ("tools/lat_probe.hip: dependent-chain latencies on the 16 x 16 elimination's critical path", "lat_probe.log"),
+                     ("tools/small_probe.hip: phases of the fused small-p kernel (p = 100, 2048 orderings)", "small_probe.log"),
+                     ("tools/factor_probe.hip: phases of the 64 x 64 / 128 x 128 diagonal factorisations", "factor_probe.log")):
+        out.write(f"## {title}\n" + "".join(l for l in open(os.path.join(SRC, f)) if "amdgpu.ids" not in l) + "\n")
+print(f"profiles/{TAG}_probes.log")
+if os.path.exists(os.path.join(SRC, "pmc_diag_summary.txt")):
+    shutil.copyfile(os.path.join(SRC, "pmc_diag_summary.txt"), os.path.join(DST, f"{TAG}_c3_pmc_diag.txt"))
+    print(f"profiles/{TAG}_c3_pmc_diag.txt")
 # (config, p, batch, dtype, steps executed by the PMC runs = warm-up + timed + event pass)
 for cfg, p, b, dt, steps in (("c3", 1000, 128, "f64", 2 + 6 + 6), ("c5", 5000, 128, "f32", 1 + 3 + 3),
                              ("c2", 100, 128, "f64", 8 + 16 + 16)):
-    cp(f"stats_{cfg}/{cfg}_kernel_stats.csv", f"r02_{cfg}_kernel_stats.csv")
-    cp(f"stats_{cfg}.json", f"r02_{cfg}_bench_under_rocprof.json")
-    cp(f"fetch_{cfg}/{cfg}_counter_collection.csv", f"r02_{cfg}_pmc_fetch_size.csv")
-    cp(f"write_{cfg}/{cfg}_counter_collection.csv", f"r02_{cfg}_pmc_write_size.csv")
+    if not os.path.exists(os.path.join(SRC, f"stats_{cfg}", f"{cfg}_kernel_stats.csv")):
+        print(f"(no {cfg} artefacts in {SRC})")
+        continue
+    cp(f"stats_{cfg}/{cfg}_kernel_stats.csv", f"{TAG}_{cfg}_kernel_stats.csv")
+    cp(f"stats_{cfg}.json", f"{TAG}_{cfg}_bench_under_rocprof.json")
+    cp(f"fetch_{cfg}/{cfg}_counter_collection.csv", f"{TAG}_{cfg}_pmc_fetch_size.csv")
+    cp(f"write_{cfg}/{cfg}_counter_collection.csv", f"{TAG}_{cfg}_pmc_write_size.csv")
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"),
-                    os.path.join(DST, f"r02_{cfg}_pmc_fetch_size.csv"), os.path.join(DST, f"r02_{cfg}_pmc_write_size.csv"),
-                    "--label", cfg, "--p", str(p), "--batch-size", str(b), "--dtype", dt, "--steps", str(steps)], check=True)
+                    os.path.join(DST, f"{TAG}_{cfg}_pmc_fetch_size.csv"), os.path.join(DST, f"{TAG}_{cfg}_pmc_write_size.csv"),
+                    "--label", cfg, "--p", str(p), "--batch-size", str(b), "--dtype", dt, "--steps", str(steps), "--tag", TAG],
+                   check=True)

@@ -1,7 +1,7 @@
 # Per-dispatch hardware counters of a few C3 steps (developer diagnosis): what the panel launches are bound by.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/pmc_diag; mkdir -p $O
+O=gpurun_out/pmc_diag; rm -rf $O; mkdir -p $O
 P="--steps 3 --warmup 1 --no-probe --no-ttt --no-cpu-baseline"
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --output-format csv -d $O/a -o a -- python3 bench.py $P > $O/a.json 2> $O/a.err
 echo a done

@@ -8,7 +8,7 @@ The profiled command must be `bench.py ... --no-probe --no-ttt --no-cpu-baseline
 belongs to a full-size step).  Units and corrections: both counters are in KiB; on gfx950 FETCH_SIZE reads exactly 1/2
 of the bytes of a wide (16 B/lane) coalesced stream, so it is doubled; WRITE_SIZE is exact for 16-B/lane stores.
 Infinity-Cache hits are counted (the counters sit on the L2's memory side), so this is fabric traffic, an upper bound
-of the DRAM traffic.  Writes profiles/r02_pmc_summary_<label>.csv and merges the per-class figures into
+of the DRAM traffic.  Writes profiles/<tag>_pmc_summary_<label>.csv and merges the per-class figures into
 profiles/pmc_traffic.json (read by bench.py for the `traffic` field of its roofline object).
 """
 import argparse
@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--p", type=int, required=True)
     ap.add_argument("--batch-size", type=int, required=True)
     ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--tag", default="r03", help="round tag of the output file name")
     ap.add_argument("--steps", type=int, required=True, help="steps the profiled run executed (warm-up + timed + event pass)")
     args = ap.parse_args()
     fetch, write = load(args.fetch), load(args.write)
@@ -58,7 +59,7 @@ def main():
         rows.append((k, n, f_raw, 2.0 * f_raw, w, total / n, 0.0 if k in ONE_TIME else total / args.steps))
         if k in CLASS_OF:
             per_class[CLASS_OF[k]] = total / n
-    out_csv = os.path.join(ROOT, "profiles", f"r02_pmc_summary_{args.label}.csv")
+    out_csv = os.path.join(ROOT, "profiles", f"{args.tag}_pmc_summary_{args.label}.csv")
     with open(out_csv, "w") as fh:
         fh.write("kernel,launches,FETCH_SIZE_bytes_raw,fetch_bytes_corrected_x2,WRITE_SIZE_bytes,"
                  "bytes_per_launch,bytes_per_step (0 for the once-per-problem reduction kernels)\n")

@@ -40,6 +40,8 @@ int main(int argc, char** argv) {
            (cy[7] - cy[0]) / ((st[7] - st[0]) * 10.0), cy[8] - cy[2], cy[11] - cy[10]);
     long long hh[16]; hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_small_helper), sizeof hh);
     printf("helper wave 1, block step 0 (cycles): first 4 tiles %lld, next %lld, rest %lld\n", hh[1] - hh[0], hh[2] - hh[1], hh[3] - hh[2]);
+    long long ff[4]; hipMemcpyFromSymbol(ff, HIP_SYMBOL(g_small_fstamp), sizeof ff);
+    printf("inside the last 16 x 16 factorisation of workgroup 0: the pivot sweep alone %lld cycles\n", ff[1] - ff[0]);
     printf("cholesky detail (us): first factor16 %.2f | barrier+panel(0) %.2f | own trailing tile %.2f | factor16 %.2f | wait for helpers %.2f\n",
            (st[8]-st[2])/100.0, (st[9]-st[8])/100.0, (st[10]-st[9])/100.0, (st[11]-st[10])/100.0, (st[12]-st[11])/100.0);
   }
