@@ -281,40 +281,56 @@ __global__ __launch_bounds__(512) void small_p_kernel(SmallArgs a) {
   __syncthreads();
 
   SSTAMP(4);
-  // ---- V = L^-1 L_t: wave cb solves the 16-column block cb, top down, in place of L_t -------------------------
+  // ---- V = L^-1 L_t: wave cb solves the 16-column block cb, top down, in place of L_t.  The solved blocks V[k][cb] stay
+  // in the wave's registers: an accumulator tile is, as it stands, the B operand of the products that sum over its row
+  // index (tiles.h), so the products of a row need only the fragments of L[i][.] from LDS -- fetched all at once, then
+  // the matrix instructions back to back (one LDS round trip in front of every product made this phase 9 us of 53).
   if (wv < nb) {
     const int cb = wv;
-    for (int i = cb; i < nb; ++i) {
-      d4 acc = d4_zero();
-      for (int k = cb; k < i; ++k) {
-        const double* const Ab = M0 + tri_blk(i, k) * 256;
-        const double* const Bb = M1 + tri_blk(k, cb) * 256;
+    d4 vreg[8];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int kx = 4 * kk + l4;
-          acc = mfma(Ab[sw(l15, kx)], Bb[sw(kx, l15)], acc);
+    for (int ii = 0; ii < 8; ++ii) {            // row block i = cb + ii
+      const int i = cb + ii;
+      if (i >= nb) break;                        // uniform
+      double af[7][4];                           // fragments of L[i][cb + kk2], kk2 < ii
+#pragma unroll
+      for (int kk2 = 0; kk2 < 7; ++kk2)
+        if (kk2 < ii) {
+          const double* const Ab = M0 + tri_blk(i, cb + kk2) * 256;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) af[kk2][kk] = Ab[sw(l15, 4 * kk + l4)];
         }
-      }
       double* const Tb = M1 + tri_blk(i, cb) * 256;
       double t[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) t[r] = Tb[sw(acc_row(l4, r), l15)] - acc[r];
-      if (i == cb) {   // L_t's diagonal block is lower triangular; its upper positions hold other data by now
+      for (int r = 0; r < 4; ++r) t[r] = Tb[sw(acc_row(l4, r), l15)];
+      const double* const Ld = M0 + tri_blk(i, i) * 256;
+      const double* const rd = s_rdb + 16 * i;
+      double ie[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ie[r] = inv_elem(Ld, rd, l15, 4 * r + l4);
+      d4 acc = d4_zero();
+#pragma unroll
+      for (int kk2 = 0; kk2 < 7; ++kk2)
+        if (kk2 < ii) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) acc = mfma(af[kk2][kk], vreg[kk2][kk], acc);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[r] -= acc[r];
+      if (ii == 0) {   // L_t's diagonal block is lower triangular; its upper positions hold other data by now
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (l15 > acc_row(l4, r)) t[r] = 0.0;
       }
-      // X = L_d^-1 t: the accumulator registers are, as they stand, the B operand of the k-steps {4 r .. 4 r + 3}
-      // (tiles.h); L_d^-1 sits in the diagonal block's upper triangle and in s_rdb (wave_factor16_sw)
-      const double* const Ld = M0 + tri_blk(i, i) * 256;
-      const double* const rd = s_rdb + 16 * i;
+      // X = L_d^-1 t: the registers of t are the B operand of the k-steps {4 r .. 4 r + 3}; L_d^-1 sits in the diagonal
+      // block's upper triangle and in s_rdb (wave_factor16_sw)
       d4 x = d4_zero();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) x = mfma(inv_elem(Ld, rd, l15, 4 * r + l4), t[r], x);
+      for (int r = 0; r < 4; ++r) x = mfma(ie[r], t[r], x);
+      vreg[ii] = x;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) t[r] = x[r];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Tb[sw(acc_row(l4, r), l15)] = t[r];
+      for (int r = 0; r < 4; ++r) Tb[sw(acc_row(l4, r), l15)] = x[r];
     }
   }
   __syncthreads();

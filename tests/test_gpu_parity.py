@@ -396,6 +396,29 @@ def test_c4_end_to_end_from_host_arrays():
     np.testing.assert_array_equal(again.attribution, res.attribution)
 
 
+def test_c4_sampler_and_hip_path_against_the_oracle():
+    """BASELINE config 4's sampler and the HIP path TOGETHER against the oracle (the full-size test above checks
+    properties only): p = 1000, the row count cut to 3000 so that the oracle's per-ordering QR finishes in seconds,
+    method='permutohedron' (MultivariateNormalQMC(zeros(p - 1), seed = 42, inv_transform = False), the basis of
+    experiments/ground_truth_medium.py:56-67), antithetical, one batch of 16 -- the orderings the driver drew are
+    the oracle's own sampler's, the attribution is the oracle's to 1e-10, the estimator's generator stream the same."""
+    from scipy.stats.qmc import MultivariateNormalQMC
+    p, n = 1000, 3000
+    d = O.gaussian_workload(p, n, n, seed=4)
+    res = ls_spa(*d, method="permutohedron", batch_size=16, num_batches=1, tolerance=0.0, seed=42,
+                 return_attribution_history=True)
+    orders = O.orderings_permutohedron(MultivariateNormalQMC(np.zeros(p - 1), seed=42, inv_transform=False), 16, p)
+    want = O.estimate(*d, perms=orders, batch_size=16, tolerance=0.0, seed=42, return_attribution_history=True)
+    np.testing.assert_allclose(res.attribution, want.attribution, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(res.attribution_history, want.attribution_history, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(res.theta, want.theta, rtol=1e-9, atol=1e-12)
+    assert abs(res.r_squared - want.r_squared) < 1e-10
+    # checks at i = max_samples - 1 = 15 and at 16 (the reference's trigger rule, ls_spa/ls_spa.py:222); the oracle, fed the
+    # orderings through perms=, has no sample cap and checks at 16 only
+    assert len(res.error_history) == 2 and len(want.error_history) == 1
+    np.testing.assert_allclose(res.error_history[-1], want.error_history[-1], rtol=0.25)   # singular covariance: statistical pin
+
+
 # ------------------------------------------------------------------ (f3) the experiment harness
 def test_medium_experiment_harness(tmp_path):
     """experiments/medium_experiment.py at reduced size (rows 2000, ground truth from 2^10 samples, 512-sample
