@@ -21,6 +21,8 @@ LIBNAME = "liblsspa_hip.so"
 SOURCES = ["k_factor.hip", "k_small.hip", "k_lift.hip", "k_gram.hip", "k_error.hip", "lsspa_comm.hip", "lsspa_api.hip"]
 HEADERS = ["tiles.h", "kernels.h", "comm.h", os.path.join("..", "..", "include", "lsspa.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# developer A/B builds: LSSPA_CXXFLAGS="-DSOMETHING" python ls-spa_amd/build.py --force --out ls-spa_amd/lib/ab/new.so
+FLAGS += os.environ.get("LSSPA_CXXFLAGS", "").split()
 
 
 def _hipcc() -> str:
@@ -39,11 +41,11 @@ def _newest_input() -> float:
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build_native(force: bool = False, verbose: bool = True) -> str:
-    out = lib_path()
+def build_native(force: bool = False, verbose: bool = True, out: str | None = None) -> str:
+    out = out or lib_path()
     if not force and os.path.exists(out) and os.path.getmtime(out) >= _newest_input():
         return out
-    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
 
@@ -69,4 +71,5 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build_native(force="--force" in sys.argv)
+    build_native(force="--force" in sys.argv,
+                 out=os.path.abspath(sys.argv[sys.argv.index("--out") + 1]) if "--out" in sys.argv else None)

@@ -1140,6 +1140,9 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
   }
 
   // acc[x][y][r] <-> (panel column j = 16 x + acc_row(l4, r), tile row i = RW w + 16 y + l15); holds -C^T.
+  // (Round 3, measured and not kept: -A^T entering through the matrix pipe instead -- the tile's own eight chunks
+  // staged like the k-loop's operands and multiplied by -I, no transposition in front of the k-loop: 4.05 against
+  // 3.98 ms of panel time per C3 step in alternating processes on one box.)
   // Each wave stages its own rows through its slice of the output buffer (coalesced reads, no
   // workgroup barrier).
   acc_t acc[8][YT];
@@ -1199,6 +1202,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
         }
     }
   }
+
 
   PSTAMP(2);
   // two-level solve on the accumulators (they hold -C^T):
