@@ -731,8 +731,10 @@ def main():
 
         breakdown_note = ("e2e_breakdown: host seconds of the faster of two calls -- engine_create (context, stream), setup "
                           "(communicator, precision), sampler_start (generator + QMC constructor handed to a helper thread), "
-                          "reduction_h2d_gram (page-lock of X's interior pages, chunked H2D over PCIe, Gram kernels, "
-                          "Cholesky-side finalize, un-lock), sampler (drawing orderings), sampling (upload + kernels + "
+                          "reduction_pin / reduction_copy_gram / reduction_unpin / reduction_finalize (page-lock of X's "
+                          "interior pages; chunked H2D over PCIe under the Gram kernels; un-lock; scaling and sync -- the library's "
+                          "own timers, lsspa_reduce_timing) and reduction_host (what is left of the phase: coercion of the arrays, "
+                          "buffer allocation, the call), sampler (drawing orderings), sampling (upload + kernels + "
                           "statistics of the loop, incl. workspace allocation on the first batch), estimator (statistics "
                           "read-back + error estimate), final_fit (theta, r^2), teardown (free, destroy)")
         if world == 1:

@@ -55,15 +55,19 @@ int lsspa_synchronize(lsspa_ctx* ctx);
  * p is limited by the LDS of a CU (the gather stages one source row and the ordering: 12 B a feature of the padded
  * count, 160 KB): p <= 13567; a larger p is refused here with LSSPA_ERR_ARG and a message naming it (the reference
  * has no limit, ls_spa/ls_spa.py:163).
- * Host arrays are never written and stay the caller's: they are read during the call only.  A dense X (ld == p) of
- * 8 MB or more is page-locked in place for the duration of the call (hipHostRegister) -- only the whole pages that
- * lie strictly inside the array, so no page shared with a neighbouring allocation (y, another thread's block) is
- * ever locked; the unaligned ends, y, strided X (ld > p) and memory the HIP runtime already knows (hipHostMalloc'ed
- * or registered by the caller) go through ordinary copies and are left exactly as they were.
+ * Host arrays are never written and stay the caller's: they are read during the call only, through ordinary copies
+ * (nothing of the caller's is page-locked: measured, the runtime's own pageable path is faster than registering the
+ * arrays first; developer flag 4096 page-locks the whole pages strictly inside a dense X of 8 MB or more for the
+ * duration of the call, never y, strided X or memory the HIP runtime already knows).
  * No C++ exception leaves any entry point of this header: host allocation failure is LSSPA_ERR_NOMEM. */
 int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const void* y_train, int64_t N,
                  const void* X_test, int64_t ld_test, const void* y_test, int64_t M, int32_t p, double reg,
                  int32_t dtype, int32_t location);
+
+/* Host seconds the last reduction from HOST arrays spent in its parts: [0] page-locking the caller's X (both sides),
+ * [1] the streamed copies and Gram kernels (to the last one's completion), [2] un-locking, [3] finalize (scaling,
+ * statistics reset, sync).  bench.py's e2e_breakdown. */
+int lsspa_reduce_timing(const lsspa_ctx* ctx, double* seconds4);
 
 /* a1, rows spread over several GPUs: every rank reduces the rows it holds,
  *   lsspa_reduce_partial : unscaled Gram sums of n_local training rows and m_local test rows.  M_total is the
@@ -220,7 +224,7 @@ int lsspa_profile_reset(lsspa_ctx* ctx);
  *   256  unpaired gather                              512  256-column strips (512-thread workgroups)
  *  2048  no skipping of the all-padding 16 x 16 tiles in the panel / strip products
  *  1024  general path also for small problems (p + 1 <= 128 normally takes the fused one-workgroup kernel)
- *  4096  streamed reduction never page-locks the caller's X (A/B of the PCIe path)
+ *  4096  streamed reduction page-locks the caller's X in place (interior pages only; off by default: slower)
  * 65536  Gram kernel: workgroup id = unit (the units of a row slice spread over the XCDs instead of sharing one L2)
  *  8192  whole factorisation in one launch, a workgroup per matrix (measured slower than a launch per panel step)
  * Every combination computes the same lifts (tests/test_gpu_kernels.py). */

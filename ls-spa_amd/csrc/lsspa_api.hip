@@ -7,6 +7,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -125,6 +126,10 @@ struct lsspa_ctx {
   std::vector<int32_t> perm_mark;   // scratch of the ordering validation
   bool general_path_once = false;   // set while the factors themselves are wanted (full_fit, get_factors, debug_factor)
   int fail_alloc_in = 0;   // test hook (lsspa_debug_fail_alloc): the n-th device allocation from now fails
+
+  // host seconds of the last reduction's parts (lsspa_reduce_timing): page-locking, streamed copies + Gram kernels,
+  // un-locking, finalize (scaling, Cholesky-side set-up of the statistics, sync)
+  double red_pin_s = 0.0, red_stream_s = 0.0, red_unpin_s = 0.0, red_finalize_s = 0.0;
 
   // profiling
   bool prof_on = false;
@@ -1105,9 +1110,10 @@ static hipError_t copy_h2d_split(char* dst, const char* src, size_t n, const Pin
 
 // Gram of a HOST-resident [n][ld] matrix, streamed: the rows cross PCIe in chunks through two device
 // buffers on a copy stream while the previous chunk's Gram runs on the compute stream; the chunk
-// Grams accumulate in C in chunk order.  A dense X (ld == p) of 8 MB or more is pinned in place for the
-// duration -- its interior pages only, see pin_interior -- so that its copies are true DMA.  y (1 / p of the
-// bytes) and strided X (ld > p: the extent (n - 1) ld + p ends inside somebody else's row) are never pinned.
+// Grams accumulate in C in chunk order.  The copies read the caller's pageable memory through the runtime's ordinary
+// path.  Behind developer flag 4096 a dense X (ld == p) of 8 MB or more is pinned in place for the duration -- its
+// interior pages only, see pin_interior; y (1 / p of the bytes) and strided X (ld > p: the extent (n - 1) ld + p
+// ends inside somebody else's row) are never pinned.
 static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, int64_t ld, int p,
                               int is_f32, double* C_out) {
   const size_t es = is_f32 ? 4 : 8;
@@ -1133,8 +1139,16 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
     if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_NOMEM, "streamed reduction buffers", e);
   }
+  const auto t_pin0 = std::chrono::steady_clock::now();
+  auto seconds_since = [](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  };
   if (rc == LSSPA_OK) {
-    if (ld == p && !(ctx->flags & 4096)) pin = pin_interior(X, (size_t)n * p * es);   // flag 4096: never pin (A/B)
+    // Page-locking the caller's X is OFF by default (round 3, tools/host_reduce_probe.py at the C3 shape: registering
+    // 2 x 800 MB costs 14-21 ms and saves about 10 ms of copy time -- the runtime's own pageable path pins and DMAs
+    // chunk by chunk; 52-59 ms for the whole call without, 53-69 ms with, on two boxes).  Developer flag 4096 turns it on.
+    if (ld == p && (ctx->flags & 4096)) pin = pin_interior(X, (size_t)n * p * es);
+    ctx->red_pin_s += seconds_since(t_pin0);
     ProfScope ps(ctx, LSSPA_K_GRAM);
     int k = 0;
     for (int64_t r0 = 0; r0 < n && e == hipSuccess; r0 += rows, ++k) {
@@ -1183,7 +1197,10 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
   }
   if (rc == LSSPA_OK && es1 != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "streamed gram sync", es1);
   if (rc == LSSPA_OK && es2 != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "streamed gram copy sync", es2);
+  ctx->red_stream_s += seconds_since(t_pin0);      // pin included; taken out again in lsspa_reduce_timing
+  const auto t_unpin0 = std::chrono::steady_clock::now();
   unpin(pin);
+  ctx->red_unpin_s += seconds_since(t_unpin0);
   for (int b = 0; b < 2; ++b) {
     if (dX[b]) (void)hipFree(dX[b]);
     if (dy[b]) (void)hipFree(dy[b]);
@@ -1202,6 +1219,7 @@ static int reduce_rows(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, co
   const size_t es = dtype == LSSPA_F32 ? 4 : 8;
   const int is_f32 = dtype == LSSPA_F32;
   const size_t c_elems = (size_t)round_up(p + 1, 128) * round_up(p + 1, 128);
+  ctx->red_pin_s = ctx->red_stream_s = ctx->red_unpin_s = ctx->red_finalize_s = 0.0;
   TRY(dev_alloc(ctx, ctx->Cred, 2 * c_elems));
   HIPCHK(hipMemsetAsync(ctx->Cred.ptr, 0, 2 * c_elems * 8, ctx->stream));
   auto side = [&](const void* X, const void* y, int64_t n, int64_t ld, bool train) -> int {
@@ -1257,6 +1275,12 @@ static int reduce_rows(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, co
 // G = C_train / N + reg I, g, (tri) H = C_test, h, ||y_test||^2 from the summed Gram buffers
 static int reduce_finalize(lsspa_ctx* ctx, int64_t N_total, double reg) {
   const int p = ctx->p;
+  const auto t_fin0 = std::chrono::steady_clock::now();
+  struct Stop {
+    lsspa_ctx* c;
+    std::chrono::steady_clock::time_point t0;
+    ~Stop() { c->red_finalize_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+  } stop{ctx, t_fin0};
   const size_t c_elems = (size_t)round_up(p + 1, 128) * round_up(p + 1, 128);
   // (not part of the LSSPA_K_GRAM timing class: that class counts the Gram contractions, one launch per side)
   HIPCHK(launch_gram_finalize(ctx->Cred.ptr, p, 1.0 / (double)N_total, reg, ctx->G.ptr, ctx->p_pad, ctx->g.ptr,
@@ -1296,6 +1320,15 @@ int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const vo
   return reduce_finalize(ctx, N, reg);
 } catch (...) {
   return abi_caught(ctx);
+}
+
+int lsspa_reduce_timing(const lsspa_ctx* ctx, double* seconds4) {
+  if (!ctx || !seconds4) return LSSPA_ERR_ARG;
+  seconds4[0] = ctx->red_pin_s;
+  seconds4[1] = ctx->red_stream_s - ctx->red_pin_s;
+  seconds4[2] = ctx->red_unpin_s;
+  seconds4[3] = ctx->red_finalize_s;
+  return LSSPA_OK;
 }
 
 int lsspa_reduce_partial(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const void* y_train,

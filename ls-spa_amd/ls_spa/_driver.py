@@ -504,6 +504,14 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         else:
             engine.load_data(X_train, X_test, y_train, y_test, reg)
         t0 = lap("reduction_h2d_gram", t0)
+        if _timings is not None and hasattr(engine, "reduce_timing"):
+            # the library's own split of that phase: page-locking the caller's X, chunked copies + Gram kernels,
+            # un-locking, finalize; what is left of the phase is host-side coercion and the call itself
+            parts = engine.reduce_timing()
+            whole = tm.pop("reduction_h2d_gram")
+            tm["reduction_pin"], tm["reduction_copy_gram"] = parts["pin"], parts["h2d_gram"]
+            tm["reduction_unpin"], tm["reduction_finalize"] = parts["unpin"], parts["finalize"]
+            tm["reduction_host"] = whole - sum(parts.values())
         attribution, feat_err, total_err, err_hist, history, _ = run_estimator(
             engine, p, max_samples=max_samples, batch_size=batch_size, tolerance=tolerance, seed=seed,
             perms=perms, antithetical=antithetical, return_attribution_history=return_attribution_history,

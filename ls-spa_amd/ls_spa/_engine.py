@@ -100,6 +100,13 @@ class HipEngine:
             float(reg), N.F32 if dt == np.float32 else N.F64, N.HOST))
         self._refresh_dims()
 
+    def reduce_timing(self):
+        """Host seconds of the last reduction from host arrays: page-locking, streamed copies + Gram kernels,
+        un-locking, finalize (include/lsspa.h, lsspa_reduce_timing)."""
+        out = np.zeros(4)
+        self._check(self._lib.lsspa_reduce_timing(self._h, N.dptr(out)))
+        return dict(zip(("pin", "h2d_gram", "unpin", "finalize"), (float(v) for v in out)))
+
     def load_data_sharded(self, X_train, X_test, y_train, y_test, reg: float, comm, shard_test: bool = True):
         """Row-sharded reduction: the arrays are THIS rank's rows; one all-reduce of the Gram sums
         (2 (p+1)^2 fp64, padded) replaces moving the rows.  shard_test=False: every rank passes all the

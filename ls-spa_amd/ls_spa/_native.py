@@ -40,6 +40,7 @@ SIGNATURES = {
     "lsspa_set_stream": (C.c_int, [_vp, _vp]),
     "lsspa_synchronize": (C.c_int, [_vp]),
     "lsspa_reduce": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _dbl, _i32, _i32]),
+    "lsspa_reduce_timing": (C.c_int, [_vp, _pd]),
     "lsspa_reduce_partial": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32]),
     "lsspa_reduce_buffer": (C.c_int, [_vp, C.POINTER(_vp), _pi64]),
     "lsspa_reduce_finish": (C.c_int, [_vp, _i64, _dbl]),

@@ -615,7 +615,8 @@ def test_streamed_reduction_pinning_corner_cases():
     abort once seen in this path: (i) X and y carved out of ONE buffer so that they share pages, each >= 8 MB;
     (ii) arrays the caller has already page-locked; (iii) a strided X (ld > p) whose last row ends exactly at the end
     of a memory mapping, so that n * ld elements would reach past it.  Each must give the Gram matrices of the plain
-    call, and leave the caller's memory usable (still registered in (ii))."""
+    call, and leave the caller's memory usable (still registered in (ii)).  Page-locking is behind developer flag 4096
+    (the default transport is the runtime's pageable path); the test turns it on."""
     import ctypes as C
     import mmap
     from ls_spa import _native as N
@@ -633,6 +634,7 @@ def test_streamed_reduction_pinning_corner_cases():
         return eng.gram()
 
     try:
+        eng.set_flags(4096)               # page-locking on (off by default since round 3: it is the slower transport)
         # reference result: well-separated, aligned arrays
         Xa, Xe = rng.standard_normal((n, p)), rng.standard_normal((n, p))
         ya, ye = rng.standard_normal(n), rng.standard_normal(n)
@@ -685,10 +687,9 @@ def test_streamed_reduction_pinning_corner_cases():
         got = reduce_host(views[0], ya, views[1], ye, ld)
         for a, b in zip(got, base):
             np.testing.assert_array_equal(a, b)
-        # flag 4096 (never page-lock) gives the same bits: the pinning is transport only
-        eng.set_flags(4096)
-        got = reduce_host(Xa1, ya1, Xe1, ye1, p)
+        # without page-locking (the default): the same bits, the pinning is transport only
         eng.set_flags(0)
+        got = reduce_host(Xa1, ya1, Xe1, ye1, p)
         for a, b in zip(got, base):
             np.testing.assert_array_equal(a, b)
     finally:
