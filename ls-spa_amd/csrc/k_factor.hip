@@ -706,6 +706,14 @@ __device__ __forceinline__ void syrk_tile(int t, int& ti, int& tj) {
   tj = (int)(((t < 21 ? TJ_LO : TJ_HI) >> sh) & 7);
 }
 
+// the same enumeration as compile-time functions (row ti of the t-th lower tile, row by row)
+__host__ __device__ constexpr int syrk_ti_c(int t) {
+  int i = 0;
+  while ((i + 1) * (i + 2) / 2 <= t) ++i;
+  return i;
+}
+__host__ __device__ constexpr int syrk_tj_c(int t) { return t - syrk_ti_c(t) * (syrk_ti_c(t) + 1) / 2; }
+
 // acc[4 h + xp][y] <- sign * sum_{x <= xp} D[xp][x] acc[4 h + x][y]  (D lower triangular, 64 x 64 in LDS),
 // one column tile y at a time so that only four extra tiles are live
 template <typename T>
@@ -1127,7 +1135,6 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
   // of the k-loop for full tiles was measured too: no faster (it costs registers the epilogue then spills).
   const int ws = __builtin_amdgcn_readfirstlane(w);
   const int ylive = min(YT, max(0, (p_live - (I0 + RW * ws) + 15) / 16));   // live 16-row tiles of this wave
-  const int tlive = min(8, max(0, (p_live - I0 + 15) / 16));                // live 16-row tiles of the whole tile
 
   const T* srcJ = M + cm_off(p_pad, J0, 0);
   const T* srcI = M + cm_off(p_pad, I0, 0);
@@ -1253,9 +1260,10 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const T av = s_dinv[(16 * xp + l15) * DI_LD + 16 * x + Tr<T>::acc_row(l4, r)];
+        // no padding test here: the accumulators of padding rows are zeros and add zeros, and a branch around every
+        // product put the LDS latency of its fragment in front of it
 #pragma unroll
-        for (int y = 0; y < YT; ++y)
-          if (y < ylive) acc[4 + xp][y] = Tr<T>::mfma(av, acc[x][y][r], acc[4 + xp][y]);
+        for (int y = 0; y < YT; ++y) acc[4 + xp][y] = Tr<T>::mfma(av, acc[x][y][r], acc[4 + xp][y]);
       }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -1293,19 +1301,25 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
   // chunks just written are staged once more (they come back from L2) instead of keeping both sets of
   // accumulators alive through the store loop.
   __threadfence_block();
-  acc_t upd[NU];
-  int ti[NU], tj[NU];
+  // The tiles of a wave -- t = ws + NW q of the row-by-row enumeration -- are COMPILE-TIME constants in four (eight)
+  // copies of the loop, one per wave index: with run-time tile indices every product had its own pair of LDS reads,
+  // its own full wait for them and a branch around it (a padding test per tile), i.e. the LDS latency in front of each
+  // of the 36 matrix instructions of a chunk.  Here the (at most eight) row-block fragments of a k-step are fetched
+  // together and the products follow back to back.  Padding row blocks (rows at or beyond p_live) are exact zeros in
+  // L[I, panel]: their products add zeros, so they are no longer tested for.
+  auto diag_update = [&](auto ws_tag) {
+    constexpr int WS = decltype(ws_tag)::value;
+    acc_t upd[NU];
 #pragma unroll
-  for (int q = 0; q < NU; ++q) {
-    const int t = ws + NW * q;
-    syrk_tile(t < 36 ? t : 0, ti[q], tj[q]);
-    // start from -A[I,I] (unconditional loads: the block's upper triangle exists, its content is never stored):
-    // the reads are in flight under the re-staging loop instead of being a dependent read-modify-write at the end
+    for (int q = 0; q < NU; ++q) {
+      const int t = WS + NW * q;
+      const int ti = syrk_ti_c(t < 36 ? t : 0), tj = syrk_tj_c(t < 36 ? t : 0);
+      // start from -A[I,I] (unconditional loads: the block's upper triangle exists, its content is never stored):
+      // the reads are in flight under the re-staging loop instead of being a dependent read-modify-write at the end
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      upd[q][r] = -M[cm_off(p_pad, I0 + 16 * ti[q] + Tr<T>::acc_row(l4, r), I0 + 16 * tj[q] + l15)];
-  }
-  {
+      for (int r = 0; r < 4; ++r)
+        upd[q][r] = -M[cm_off(p_pad, I0 + 16 * ti + Tr<T>::acc_row(l4, r), I0 + 16 * tj + l15)];
+    }
     const T* srcP = M + cm_off(p_pad, I0, J0);
     RKRegs<T, 128, NT> rp = {};
     __syncthreads();   // all stores above are issued and fenced
@@ -1321,25 +1335,37 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
       if (c + 1 < 8) rk_load_full<T, 128, NT>(rp, srcP + (c + 1) * chunk, CM_LD, tid);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
+        T z[8];
+#pragma unroll
+        for (int bk = 0; bk < 8; ++bk) z[bk] = s_out[(16 * bk + l15) * RK_LD + 4 * kk + l4];
 #pragma unroll
         for (int q = 0; q < NU; ++q) {
-          if (ws + NW * q >= 36 || ti[q] >= tlive) continue;   // wave-uniform; padding rows add nothing
-          const T av = s_out[(16 * ti[q] + l15) * RK_LD + 4 * kk + l4];
-          const T bv = s_out[(16 * tj[q] + l15) * RK_LD + 4 * kk + l4];
-          upd[q] = Tr<T>::mfma(av, bv, upd[q]);
+          const int t = WS + NW * q;
+          if (t < 36) upd[q] = Tr<T>::mfma(z[syrk_ti_c(t)], z[syrk_tj_c(t)], upd[q]);
         }
       }
     }
-  }
-  PSTAMP(5);
+    PSTAMP(5);
 #pragma unroll
-  for (int q = 0; q < NU; ++q) {
-    if (ws + NW * q >= 36) continue;
+    for (int q = 0; q < NU; ++q) {
+      const int t = WS + NW * q;
+      if (t >= 36) continue;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * ti[q] + Tr<T>::acc_row(l4, r), col = 16 * tj[q] + l15;
-      if (col <= row) M[cm_off(p_pad, I0 + row, I0 + col)] = -upd[q][r];
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * syrk_ti_c(t) + Tr<T>::acc_row(l4, r), col = 16 * syrk_tj_c(t) + l15;
+        if (col <= row) M[cm_off(p_pad, I0 + row, I0 + col)] = -upd[q][r];
+      }
     }
+  };
+  switch (ws) {     // scalar: the wave index
+    case 0: diag_update(std::integral_constant<int, 0>()); break;
+    case 1: diag_update(std::integral_constant<int, 1>()); break;
+    case 2: diag_update(std::integral_constant<int, 2>()); break;
+    case 3: diag_update(std::integral_constant<int, 3>()); break;
+    case 4: if constexpr (NW > 4) diag_update(std::integral_constant<int, 4>()); break;
+    case 5: if constexpr (NW > 4) diag_update(std::integral_constant<int, 5>()); break;
+    case 6: if constexpr (NW > 4) diag_update(std::integral_constant<int, 6>()); break;
+    default: if constexpr (NW > 4) diag_update(std::integral_constant<int, 7>()); break;
   }
   PSTAMP(6);
 
@@ -1356,8 +1382,10 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
 
 // Workgroup of NT threads (NT / 64 waves): wave w owns tile rows RW w .. RW w + RW - 1 (RW = 128 / waves)
 // for all 128 panel columns, i.e. 8 x YT accumulator tiles.
+// fp32, 256 threads: capped at 168 registers for a third workgroup per CU (as the fp32 strip kernel); fp64 needs all
+// 256 for its accumulators
 template <typename T, int NT>
-__global__ __launch_bounds__(NT, NT / 128) void chol_panel2_kernel(T* __restrict__ A, T* __restrict__ Dinv,
+__global__ __launch_bounds__(NT, (sizeof(T) == 4 && NT == 256) ? 3 : NT / 128) void chol_panel2_kernel(T* __restrict__ A, T* __restrict__ Dinv,
                                                                  const double* __restrict__ diag0,
                                                                  double piv_tol, int32_t* __restrict__ info,
                                                                  int p_pad, int Jo, int nblk, int n_mats,

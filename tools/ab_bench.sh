@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/ab_bench; mkdir -p $O
 L=ls-spa_amd/lib
 cp $L/liblsspa_hip.so $L/keep.so
-for r in 1 2 3; do
+for r in $(seq 1 ${AB_ROUNDS:-3}); do
   for v in old new; do
     cp $L/ab/$v.so $L/liblsspa_hip.so
     timeout -k 10 300 python3 bench.py --steps 40 --warmup 5 --no-probe --no-ttt --no-cpu-baseline "$@" > $O/${v}_$r.json 2> $O/${v}_$r.err || (tail -20 $O/${v}_$r.err; cp $L/keep.so $L/liblsspa_hip.so; exit 1)
