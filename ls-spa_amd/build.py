@@ -23,6 +23,11 @@ HEADERS = ["tiles.h", "kernels.h", "comm.h", os.path.join("..", "..", "include",
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # developer A/B builds: LSSPA_CXXFLAGS="-DSOMETHING" python ls-spa_amd/build.py --force --out ls-spa_amd/lib/ab/new.so
 FLAGS += os.environ.get("LSSPA_CXXFLAGS", "").split()
+# per-file flags.  k_small.hip: its register-resident kernel needs more than 256 registers a wave, and with such a
+# budget the compiler gives every matrix instruction an AGPR result by default -- the pivot chain's vector
+# instructions then copy both accumulator tiles to VGPRs and back for every pivot (7.3 k instead of 6.0 k cycles per
+# 16 x 16 block, measured).  VGPR-form matrix instructions leave only the spill traffic on the AGPR side.
+FILE_FLAGS = {"k_small.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:
@@ -51,7 +56,7 @@ def build_native(force: bool = False, verbose: bool = True, out: str | None = No
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

@@ -27,7 +27,13 @@ __device__ long long g_small_cycles[16];
 __device__ long long g_small_helper[16];
 __device__ long long g_small_fstamp[4];
 #define HSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 64) g_small_helper[i] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ long long g_reg_stamps[2][12];
+__device__ long long g_reg_chol[2][8][4];
+#define CSTAMP(kb, i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_reg_chol[threadIdx.x >> 6][kb][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define RSTAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_reg_stamps[threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define RSTAMP(i) do { } while (0)
+#define CSTAMP(kb, i) do { } while (0)
 #define SSTAMP(i) do { } while (0)
 #define HSTAMP(i) do { } while (0)
 #endif
@@ -380,6 +386,343 @@ __global__ __launch_bounds__(512) void small_p_kernel(SmallArgs a) {
   SSTAMP(7);
 }
 
+// ---- the register-resident form (round 3) ---------------------------------------------------------------------
+// What bounds the kernel above is not work but the number of pivot chains a CU has in flight: LDS holds two matrices,
+// so two chains, and every block step of each is a workgroup affair (barriers, LDS round trips between the phases).
+// The registers of a CU are 512 KB against the LDS's 160: here ONE WAVE owns a matrix outright -- its lower 16 x 16
+// blocks, transposed (U = L^T), in MFMA accumulator layout, 8 registers a block, 224 at p + 1 <= 112 -- and runs the
+// whole right-looking factorisation on them without a barrier or an LDS operand:
+//   * the diagonal block is factored where it sits (tiles.h: factor16_acc);
+//   * a panel block  U[kb][ib] = L_d^-1 T^T[kb][ib]  takes its B operand from the block's own registers (an accumulator
+//     tile is the B operand of a product over its row index) and L_d^-1 from a 2 KB scratch (the one transposition);
+//   * a trailing block  T^T[jb][ib] -= U[kb][jb]^T U[kb][ib]  takes BOTH operands from registers: the accumulator tile of
+//     U[kb][jb], read as an A operand, is U[kb][jb]^T with the same row index as the summation index.
+// A workgroup is two waves, one per matrix of an ordering, each alone on its SIMD with the 512-register budget of a
+// single-wave SIMD; 77 KB of LDS (L_t, then V; the training matrix's block inverses; vectors) lets two workgroups share a
+// CU: four chains in flight instead of two, and no workgroup barrier inside the factorisation.  Afterwards the test
+// wave hands L_t over through LDS, the training wave solves V = L^-1 L_t column block by column block with L still in
+// its registers, and both waves run the lift scan, a thread per column and then per row.
+// p + 1 <= 112 (seven block rows); the eight-block-row case keeps the LDS kernel above (its 288 registers of matrix
+// would fit, its 93 KB of LDS would leave one workgroup per CU).
+namespace {
+
+__device__ __forceinline__ constexpr int ublk(int kb, int ib) { return ib * (ib + 1) / 2 + kb; }   // kb <= ib
+
+// the region of L_t / V doubles as the gather's staging area: two waves x 16 source rows of up to 16 nb + 2 elements
+constexpr int small_reg_vregion(int nb) {
+  return (nb * (nb + 1) / 2) * 256 > 32 * (16 * nb + 2) ? (nb * (nb + 1) / 2) * 256 : 32 * (16 * nb + 2);
+}
+constexpr int small_reg_lds_doubles(int nb) { return small_reg_vregion(nb) + (nb + 2) * 256 + 32 + 128 + 128; }
+
+}  // namespace
+
+template <int NB>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void small_reg_kernel(SmallArgs a) {
+  constexpr int NTRI = NB * (NB + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int VREG = small_reg_vregion(NB);
+  double* const s_V = smem;                         // [NTRI][256]: the gather's staging area, L_t, V, the lift terms
+  double* const s_linv = s_V + VREG;                // [NB][256]: -L_d^-1 of the training matrix's diagonal blocks
+  double* const s_scr = s_linv + NB * 256;          // [2][256]: per wave, the current block inverse on its way to operand form
+  double* const s_rd = s_scr + 512;                 // [2][16]: 1 / L[i][i] of the current diagonal block
+  double* const s_z = s_rd + 32;                    // [128]
+  double* const s_y = s_z + 128;                    // [128]
+  int32_t* const s_perm = reinterpret_cast<int32_t*>(s_y + 128);   // [128]
+  __shared__ int s_bad;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0: training matrix, 1: test matrix
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int p = a.p, pr = p & 15;                   // p = 16 (NB - 1) + pr: the augmented row sits in the last block row
+  const int ord = blockIdx.x;
+  const int32_t* perm = a.perms + (int64_t)ord * p;
+  RSTAMP(0);
+  {
+    const int src = (tid < p) ? perm[tid] : 0;
+    s_perm[tid] = src;
+    s_z[tid] = a.s[0][src];          // the permuted right-hand sides g_pi, h_pi (row p of the two matrices) until the
+    s_y[tid] = a.s[1][src];          // factorisations have produced z and y~, which take their place
+  }
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  RSTAMP(8);
+
+  // ---- permuted gather straight into the accumulator layout: register r of block (kb, ib) holds element
+  //      (row 16 kb + l4 + 4 r, column 16 ib + l15) of U = the transposed lower triangle.
+  // Picking the elements out of the source one by one costs a cache line each (7168 lines a matrix: with four matrices
+  // per CU in flight that alone was 29 k cycles of the first version's 167 k -- the L1 passes a line per clock).  The
+  // sixteen source rows of a block column are fetched whole instead (coalesced, seven lines a row) into the LDS region
+  // that will hold L_t later, and the lanes pick from there. ---------------------------------------------------------
+  const double* __restrict__ S = a.S[wv];
+  const double aug = a.aug[wv];
+  const double* const svp = wv ? s_y : s_z;         // s[perm[j]]
+  d4 U[NTRI];
+  double tol[NB];
+  {
+    const int RS = (p + 3) & ~1;                    // row stride of the staging area (even: 16-byte rows)
+    double* const stage = s_V + wv * (VREG / 2);    // 16 RS <= VREG / 2 by the definition of VREG
+    // lanes past the end of a row repeat its last pair (same value to the same place): no predicated regions
+    const int col2 = min(2 * lane, (p - 1) & ~1);
+    const int ld = (int)a.ld_src;                   // element offsets fit 32 bits (p_pad^2); a local, or every load re-reads
+                                                    // the argument from memory
+    int pk[NB][4], pi[NB];
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      pi[kb] = s_perm[min(16 * kb + l15, p - 1)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pk[kb][r] = s_perm[min(16 * kb + l4 + 4 * r, p - 1)];
+    }
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 rows[16];
+    // source row of position i as a scalar: lane i & 63 of one of two registers (a uniform LDS read per row and a wait
+    // for each made a fetch sixteen LDS round trips)
+    const int perm_lo = s_perm[min(lane, p - 1)], perm_hi = s_perm[min(64 + lane, p - 1)];
+    const double* const Scol = S + col2;
+    auto fetch = [&](const int ib) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = 16 * ib + q;          // static after unrolling
+        const int src = __builtin_amdgcn_readlane(i < 64 ? perm_lo : perm_hi, i & 63);   // positions >= p repeat row p - 1
+        rows[q] = *reinterpret_cast<const d2*>(Scol + src * ld);
+      }
+    };
+    fetch(0);
+    RSTAMP(9);
+    double d0[NB];
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) *reinterpret_cast<d2*>(stage + q * RS + col2) = rows[q];
+      if (ib + 1 < NB) fetch(ib + 1);               // the next block column's rows travel while this one is picked
+      __builtin_amdgcn_wave_barrier();
+      const double* const mine = stage + l15 * RS;
+#pragma unroll
+      for (int kb = 0; kb <= ib; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) U[ublk(kb, ib)][r] = mine[pk[kb][r]];
+      d0[ib] = mine[pi[ib]];
+      __builtin_amdgcn_wave_barrier();
+    }
+    RSTAMP(10);
+    // the last block column holds the augmented row (column index p of U) and the identity padding behind it
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      double svk[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) svk[r] = svp[min(16 * kb + l4 + 4 * r, p - 1)];
+      if (kb < NB - 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double g = U[ublk(kb, NB - 1)][r];
+          U[ublk(kb, NB - 1)][r] = (l15 < pr) ? g : (l15 == pr ? svk[r] : 0.0);
+        }
+      } else {
+        const double svi = svp[min(16 * (NB - 1) + l15, p - 1)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kr = l4 + 4 * r, hi = max(l15, kr), lo = min(l15, kr);
+          const double g = U[ublk(kb, NB - 1)][r];
+          const double edge = (lo < pr) ? (lo == kr ? svk[r] : svi) : aug;
+          U[ublk(kb, NB - 1)][r] = (hi < pr) ? g : (hi == pr ? edge : (l15 == kr ? 1.0 : 0.0));
+        }
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      const int i = 16 * kb + l15;
+      tol[kb] = a.piv_tol * ((i < p) ? d0[kb] : (i == p ? aug : 1.0));
+    }
+  }
+  __syncthreads();           // the staging area is the other wave's too from its hand-over on
+#ifdef LSSPA_SMALL_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  RSTAMP(1);
+  // ---- blocked Cholesky in registers ------------------------------------------------------------------------------
+  int bad = 0;
+  double* const scr = s_scr + wv * 256;
+  double* const rd = s_rd + wv * 16;
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    d4 t = U[ublk(kb, kb)], y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = (acc_row(l4, r) == l15) ? 1.0 : 0.0;
+    CSTAMP(kb, 0);
+    factor16_acc<double>(t, y, tol[kb], lane, bad);
+#ifdef LSSPA_SMALL_STAMPS
+    asm volatile("" : "+v"(t), "+v"(y));
+#endif
+    CSTAMP(kb, 1);
+    double dj;
+    const bool holds = acc_diag<double>(t, l15, l4, dj);
+    const double rs_mine = fast_rsqrt<double>(dj);             // 1 / L[j][j]
+    if (holds) rd[l15] = rs_mine;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = acc_row(l4, r);
+      const double rs_row = rd[row];
+      // t: (row, col) for col >= row is the unscaled L[col][row] -- row `row` of U_d; y: (L^-1)[row][col] L[row][row]
+      U[ublk(kb, kb)][r] = t[r] * rs_row;
+      const double xv = (l15 <= row) ? y[r] * rs_row : 0.0;    // (L_d^-1)[row][l15]
+      scr[sw(row, l15)] = xv;
+      if (wv == 0) s_linv[kb * 256 + sw(row, l15)] = -xv;      // the V solve multiplies by -L_d^-1
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (kb + 1 < NB) {
+      double la[4];                                            // A operand: (L_d^-1)[l15][l4 + 4 r]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) la[r] = scr[sw(l15, l4 + 4 * r)];
+      __builtin_amdgcn_wave_barrier();                         // the scratch is rewritten in the next block step
+      CSTAMP(kb, 2);
+      // panel: U[kb][ib] = L_d^-1 T^T[kb][ib]; the block's registers are the B operand
+#pragma unroll
+      for (int ib = kb + 1; ib < NB; ++ib) {
+        d4 o = d4_zero();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o = mfma(la[r], U[ublk(kb, ib)][r], o);
+        U[ublk(kb, ib)] = o;
+      }
+      // trailing blocks: T^T[jb][ib] -= U[kb][jb]^T U[kb][ib], both operands as they sit in the registers
+#pragma unroll
+      for (int jb = kb + 1; jb < NB; ++jb) {
+        double na[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) na[r] = -U[ublk(kb, jb)][r];
+#pragma unroll
+        for (int ib = jb; ib < NB; ++ib)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) U[ublk(jb, ib)] = mfma(na[r], U[ublk(kb, ib)][r], U[ublk(jb, ib)]);
+      }
+    }
+  }
+  if (bad && lane == 0) s_bad = 1;
+  RSTAMP(2);
+
+  // ---- z = row p of L, y~ = row p of L_t: column pr of the last block column of U; L_t into LDS -------------------
+  {
+    double* const dst = wv ? s_y : s_z;
+    if (l15 == pr) {
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[16 * kb + l4 + 4 * r] = U[ublk(kb, NB - 1)][r];
+    }
+    if (wv == 1) {
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int ib = kb; ib < NB; ++ib)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = l4 + 4 * r;       // L_t[ib][kb] (row l15, column c) = U_t[kb][ib] (row c, column l15)
+            const double v = U[ublk(kb, ib)][r];
+            s_V[ublk(kb, ib) * 256 + sw(l15, c)] = (ib == kb && c > l15) ? 0.0 : v;
+          }
+    }
+  }
+  __syncthreads();
+  RSTAMP(3);
+
+  // ---- V = L^-1 L_t by the training wave, column block by column block, top down; L comes from its registers:
+  //      the accumulator tile of U[k][i], read as an A operand, is L[i][k] with the summation index on the rows ----------
+  if (wv == 0) {
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      d4 vcol[NB];
+#pragma unroll
+      for (int i = cb; i < NB; ++i) {
+        double* const Tb = s_V + ublk(cb, i) * 256;
+        d4 w;                                   // sum_k L[i][k] V[k][cb] - L_t[i][cb]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = -Tb[sw(acc_row(l4, r), l15)];
+        double nl[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nl[r] = s_linv[i * 256 + sw(l15, l4 + 4 * r)];
+#pragma unroll
+        for (int k = cb; k < i; ++k)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w = mfma(U[ublk(k, i)][r], vcol[k][r], w);
+        d4 x = d4_zero();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x = mfma(nl[r], w[r], x);
+        vcol[i] = x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tb[sw(acc_row(l4, r), l15)] = x[r];
+      }
+    }
+  }
+  RSTAMP(4);
+  __syncthreads();
+  RSTAMP(5);
+
+  // ---- lift terms  w[j][c] = V[j][c] (2 y~_c - N_j - N_{j-1}),  N_j = sum_{k <= j} z_k V[k][c]: a thread per column.
+  //      No branch per element (the first version's per-row conditions became 112 masked regions, each with its own LDS
+  //      round trip, and one pass per column block: 19 k cycles): every thread walks all block rows, rows outside its
+  //      column's range enter with z = 0 (N stays put, the term of a zero above the diagonal is zero) and only the store
+  //      is predicated, once per block. ---------------------------------------------------------------------------------
+  {
+    const int c = min(tid, p - 1), cbk = c >> 4, cc = c & 15;
+    const double y2 = 2.0 * s_y[c];
+    double N = 0.0;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
+      const bool blk = (jb >= cbk) && (tid < p);
+      const int jbx = max(jb, cbk);                   // above its range a column re-reads its first block (nothing stored)
+      double* const B = s_V + (jbx * (jbx + 1) / 2 + cbk) * 256;
+      double v[16], zz[16];
+#pragma unroll
+      for (int jr = 0; jr < 16; ++jr) {
+        v[jr] = B[sw(jr, cc)];
+        zz[jr] = s_z[16 * jb + jr];
+      }
+      double wv_[16];
+#pragma unroll
+      for (int jr = 0; jr < 16; ++jr) {
+        const int j = 16 * jb + jr;
+        const double zj = (blk && j >= c && j < p) ? zz[jr] : 0.0;
+        const double Nn = fma(zj, v[jr], N);
+        wv_[jr] = v[jr] * (y2 - Nn - N);
+        N = Nn;
+      }
+      if (blk) {
+#pragma unroll
+        for (int jr = 0; jr < 16; ++jr) B[sw(jr, cc)] = wv_[jr];
+      }
+    }
+  }
+  __syncthreads();
+  RSTAMP(6);
+
+  // ---- lift_j = z_j / ||y||^2 * sum_{c <= j} w[j][c]: a thread per row, 16-byte reads (the swizzle moves whole pairs) ----
+  {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int j = min(tid, p - 1), jb = j >> 4, jr = j & 15, swz = (jr >> 1) << 1;
+    double sacc = 0.0;
+#pragma unroll
+    for (int cbk = 0; cbk < NB; ++cbk) {
+      const double* const B = s_V + (jb * (jb + 1) / 2 + min(cbk, jb)) * 256 + 16 * jr;
+      d2 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const d2*>(B + ((2 * q) ^ swz));
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c0 = 16 * cbk + 2 * q;
+        sacc += (cbk <= jb && c0 <= j) ? v[q][0] : 0.0;
+        sacc += (cbk <= jb && c0 + 1 <= j) ? v[q][1] : 0.0;
+      }
+    }
+    if (tid < p) {
+      const double lift = s_z[j] * sacc / a.y_norm_sq;
+      double* dst = a.lifts + (int64_t)(ord / a.per_sample) * p + s_perm[j];
+      if (a.per_sample == 2) atomicAdd(dst, 0.5 * lift);   // the pair's two terms commute: order-independent sum
+      else *dst = lift;
+    }
+  }
+  if (tid == 0 && s_bad) atomicOr(a.info, 1);
+  RSTAMP(7);
+}
+
 size_t small_p_lds_bytes(int nb) {
   const size_t ntri = (size_t)nb * (nb + 1) / 2;
   return (2 * ntri * 256 + 2 * 16 * SINV_LD + 256 + 256 + 128 + 128) * sizeof(double) + 128 * sizeof(int32_t);
@@ -387,10 +730,32 @@ size_t small_p_lds_bytes(int nb) {
 
 bool small_p_eligible(int p) { return p >= 1 && p + 1 <= 128; }
 
+template <int NB>
+static hipError_t launch_small_reg(const SmallArgs& a, hipStream_t st) {
+  const size_t bytes = (size_t)small_reg_lds_doubles(NB) * sizeof(double) + 128 * sizeof(int32_t);
+  static DynLdsGrant grant;   // per device, per instance
+  hipError_t e = grant.ensure(reinterpret_cast<const void*>(small_reg_kernel<NB>), bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(small_reg_kernel<NB>, dim3(a.n_ord), dim3(128), bytes, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_small_p(const SmallArgs& a, hipStream_t st) {
   if (!small_p_eligible(a.p) || a.nb != (a.p + 1 + 15) / 16 || a.n_ord < 1 || (a.per_sample != 1 && a.per_sample != 2) ||
       (a.n_ord % a.per_sample) != 0 || !a.S[0] || !a.S[1] || !a.perms || !a.lifts)
     return hipErrorInvalidValue;
+  if (a.variant == 0) {       // the register-resident form wherever the matrix fits its wave (see small_reg_kernel)
+    switch (a.nb) {
+      case 1: return launch_small_reg<1>(a, st);
+      case 2: return launch_small_reg<2>(a, st);
+      case 3: return launch_small_reg<3>(a, st);
+      case 4: return launch_small_reg<4>(a, st);
+      case 5: return launch_small_reg<5>(a, st);
+      case 6: return launch_small_reg<6>(a, st);
+      case 7: return launch_small_reg<7>(a, st);
+      default: break;
+    }
+  }
   const size_t bytes = small_p_lds_bytes(a.nb);
   static DynLdsGrant grant;   // per device (a second engine on another GPU sets the attribute there too)
   hipError_t e = grant.ensure(reinterpret_cast<const void*>(small_p_kernel), bytes);

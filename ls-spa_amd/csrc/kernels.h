@@ -68,6 +68,7 @@ struct SmallArgs {
   double y_norm_sq;
   double piv_tol;
   int32_t* info;
+  int variant;             // 0: the register-resident kernel where it applies (nb <= 7); 1: the LDS-resident kernel
 };
 bool small_p_eligible(int p);
 size_t small_p_lds_bytes(int nb);

@@ -504,6 +504,7 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
     sa.y_norm_sq = ctx->y_norm_sq;
     sa.piv_tol = 16.0 * (double)p * 2.220446049250313e-16;
     sa.info = ctx->info_d.ptr;
+    sa.variant = (ctx->flags & 16384) ? 1 : 0;
     if (per_sample == 2)
       HIPCHK(hipMemsetAsync(sa.lifts, 0, sizeof(double) * (size_t)(n_ord / 2) * p, st));
     HIPCHK(launch_small_p(sa, st));

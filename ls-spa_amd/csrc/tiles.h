@@ -363,53 +363,82 @@ __device__ __forceinline__ T bperm(int addr, T v) {
 //     Y[i][j], j <= i  =  (L^-1)[i][j] L[i][i].
 // tol_lane: lane l holds the pivot threshold of row l & 15.  A pivot at or below it (or NaN) is replaced by 1 and
 // flagged, as before.
-// Measured (tools/lat_probe.hip, one wave): 337 cycles per pivot, of which the matrix instruction is 64 + 15 wait
-// states; the rest is the scalar chain pivot -> threshold test -> reciprocal (20 + two Newton steps of 2 x 7.4) ->
-// multiplier.  A two-pivots-per-step form (2 x 2 pivot blocks: half the matrix instructions and reciprocals, one
-// lane-pair exchange per step) was written and measured slower, 755 against 674 cycles per pair, and not kept.
+// The pivot chain.  Taking pivot k + 1 out of the result of matrix instruction k (wait for it, read a lane, test,
+// reciprocal with two Newton steps, multiply, issue) made a pivot cost 337-377 cycles of which the instruction itself
+// is 64 + 15 (tools/lat_probe.hip).  Pivot k + 1 does not need that result:
+//     d_{k+1} = T_k[k+1][k+1] - T_k[k][k+1]^2 / d_k
+// is made of two elements of T_k, read off the accumulators BEFORE instruction k takes them, so the threshold test
+// and the reciprocal of pivot k + 1 run on the vector pipe while instruction k runs on the matrix pipe; what is left
+// between two matrix instructions is a select and one multiplication.  (The diagonal element the instruction writes
+// and the d the multipliers were made with may differ in the last bit: rounding-level, like any reordering.)
+// The pivot row enters the B operand without its own diagonal element (column k of the rows below is never read again,
+// and a NaN there would spread over the whole column through 0 * NaN); a pivot at or below its threshold is replaced by
+// 1 for the multipliers at once and on the block's diagonal after the sweep.
+// A two-pivots-per-step form (2 x 2 pivot blocks: half the matrix instructions and reciprocals, one lane-pair exchange
+// per step) was written against the old chain and measured slower, 755 against 674 cycles per pair, and not kept.
 template <typename T>
 __device__ __forceinline__ void factor16_acc(typename Tr<T>::acc_t& t, typename Tr<T>::acc_t& y, const double tol_lane,
                                              const int lane, int& bad) {
   const int l15 = lane & 15, l4 = lane >> 4;
   constexpr bool F64 = sizeof(T) == 8;
-  // row k sits in the lanes l4 = lk4, register rk: (k & 3, k >> 2) in the f64 result layout, (k >> 2, k & 3) in the f32
-  // one.  The register index must be static, the lane group need not: the loop over the register index is unrolled,
-  // the other one is a run-time loop (sixteen unrolled steps cost instruction cache and scalar registers for nothing).
-  auto step = [&](const int k, const int lk4, auto rk_tag) {
-    constexpr int rk = decltype(rk_tag)::value;
-    T d = bcast_lane<T>(t[rk], k + 16 * lk4);
+  unsigned replaced = 0;      // bit k: pivot k was not positive (or NaN)
+  auto accept = [&](T d, const int k) -> T {      // pivot k against its threshold; 1 / pivot
     const double tol = bcast_lane<double>(tol_lane, k);
-    if (!((double)d > tol)) {   // numerically not positive definite (or NaN): flag it, go on with a unit pivot
+    if (!((double)d > tol)) {
       d = (T)1;
-      bad = 1;
-      if (lane == k + 16 * lk4) t[rk] = (T)1;
+      replaced |= 1u << k;
     }
-    const T rinv = fast_recip<T>(d);
+    return fast_recip<T>(d);
+  };
+  T rinv = accept(bcast_lane<T>(t[0], 0), 0);
+  // row k sits in the lanes l4 = lk4, register rk: (k & 3, k >> 2) in the f64 result layout, (k >> 2, k & 3) in the f32
+  // one; row k + 1 in (lkn, rkn).  The register indices must be static, the lane groups need not: the loops over the
+  // lane group stay run-time loops (sixteen unrolled steps cost instruction cache and scalar registers for nothing).
+  auto step = [&](const int k, const int lk4, auto rk_tag, const int lkn, auto rkn_tag, auto last_tag) {
+    constexpr int rk = decltype(rk_tag)::value, rkn = decltype(rkn_tag)::value;
+    constexpr bool last = decltype(last_tag)::value;
     const bool rowk = (l4 == lk4);
-    const T vt = rowk ? t[rk] : (T)0;                       // T[k][l15] in the one live k-slot
+    const T vt = (rowk && l15 > k) ? t[rk] : (T)0;          // T[k][l15], l15 > k, in the one live k-slot ...
     const T vy = rowk ? y[rk] : (T)0;                       // Y[k][l15]
-    const T a = (rowk && l15 > k) ? -vt * rinv : (T)0;      // -T[l15][k] / d for the rows below the pivot
+    const T a = -vt * rinv;                                 // ... and, T_k being symmetric, -T[l15][k] / d as well
+    T sx = (T)0, sdn = (T)1;
+    if constexpr (!last) {
+      sx = bcast_lane<T>(t[rk], k + 1 + 16 * lk4);          // T_k[k][k+1]
+      sdn = bcast_lane<T>(t[rkn], k + 1 + 16 * lkn);        // T_k[k+1][k+1]
+    }
     t = Tr<T>::mfma(a, vt, t);
     y = Tr<T>::mfma(a, vy, y);
+    if constexpr (!last) rinv = accept((T)fma(-(sx * rinv), sx, sdn), k + 1);   // the same operations as the instruction's
   };
-  auto sweep = [&](auto rk_tag) {
-    constexpr int rk = decltype(rk_tag)::value;
-#pragma unroll 1
-    for (int lk4 = 0; lk4 < 4; ++lk4) step(F64 ? 4 * rk + lk4 : 4 * lk4 + rk, lk4, rk_tag);
-  };
+  using std::integral_constant;
+  typedef integral_constant<bool, false> more_t;
   if constexpr (F64) {      // k = 4 rk + lk4: pivots in order when the register index is the outer loop
-    sweep(std::integral_constant<int, 0>());
-    sweep(std::integral_constant<int, 1>());
-    sweep(std::integral_constant<int, 2>());
-    sweep(std::integral_constant<int, 3>());
-  } else {                  // k = 4 lk4 + rk: the lane group is the outer loop
+    auto sweep = [&](auto rk_tag, auto rkn_tag, auto last_tag) {
+      constexpr int rk = decltype(rk_tag)::value;
 #pragma unroll 1
-    for (int lk4 = 0; lk4 < 4; ++lk4) {
-      step(4 * lk4 + 0, lk4, std::integral_constant<int, 0>());
-      step(4 * lk4 + 1, lk4, std::integral_constant<int, 1>());
-      step(4 * lk4 + 2, lk4, std::integral_constant<int, 2>());
-      step(4 * lk4 + 3, lk4, std::integral_constant<int, 3>());
-    }
+      for (int lk4 = 0; lk4 < 3; ++lk4) step(4 * rk + lk4, lk4, rk_tag, lk4 + 1, rk_tag, more_t());
+      step(4 * rk + 3, 3, rk_tag, 0, rkn_tag, last_tag);
+    };
+    sweep(integral_constant<int, 0>(), integral_constant<int, 1>(), more_t());
+    sweep(integral_constant<int, 1>(), integral_constant<int, 2>(), more_t());
+    sweep(integral_constant<int, 2>(), integral_constant<int, 3>(), more_t());
+    sweep(integral_constant<int, 3>(), integral_constant<int, 3>(), integral_constant<bool, true>());
+  } else {                  // k = 4 lk4 + rk: the lane group is the outer loop
+    auto group = [&](const int lk4, auto last_tag) {
+      step(4 * lk4 + 0, lk4, integral_constant<int, 0>(), lk4, integral_constant<int, 1>(), more_t());
+      step(4 * lk4 + 1, lk4, integral_constant<int, 1>(), lk4, integral_constant<int, 2>(), more_t());
+      step(4 * lk4 + 2, lk4, integral_constant<int, 2>(), lk4, integral_constant<int, 3>(), more_t());
+      step(4 * lk4 + 3, lk4, integral_constant<int, 3>(), lk4 + 1, integral_constant<int, 0>(), last_tag);
+    };
+#pragma unroll 1
+    for (int lk4 = 0; lk4 < 3; ++lk4) group(lk4, more_t());
+    group(3, integral_constant<bool, true>());
+  }
+  if (replaced) {             // numerically not positive definite: flagged, unit pivots on the diagonal
+    bad = 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (Tr<T>::acc_row(l4, r) == l15 && ((replaced >> l15) & 1u)) t[r] = (T)1;
   }
 }
 

@@ -84,7 +84,57 @@ __global__ void probe(double* out, long long* cyc, double seed) {
   asm volatile("" : "+v"(v));
   t1 = __builtin_amdgcn_s_memtime();
   if (lane == 0) cyc[7] = (t1 - t0);
-  out[lane] = x + acc[0] + acc[1] + acc2[2] + s + v;
+  // (i) one f64 MFMA (accumulator chain) + eight INDEPENDENT-of-it dependent v_fma_f64 per iteration: 64 if the vector
+  //     pipe's f64 operations run beside the matrix instruction, 64 + 8 x 7.4 if they queue behind it
+  double z = x;
+  t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 4
+  for (int i = 0; i < N; ++i) {
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(1e-3, 1e-3, acc, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z = fma(z, 0.999999, 1e-9);
+  }
+  asm volatile("" : "+v"(acc), "+v"(z));
+  t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[8] = (t1 - t0);
+  // (j) the same with eight dependent v_fma_f32
+  float zf = (float)x;
+  t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 4
+  for (int i = 0; i < N; ++i) {
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(1e-3, 1e-3, acc, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zf = fmaf(zf, 0.999999f, 1e-9f);
+  }
+  asm volatile("" : "+v"(acc), "+v"(zf));
+  t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[9] = (t1 - t0);
+  // (k) two independent MFMA chains + the eight f64 fma: does the second instruction hold the vector operations back?
+  t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 4
+  for (int i = 0; i < N; ++i) {
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(1e-3, 1e-3, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(1e-3, 1e-3, acc2, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z = fma(z, 0.999999, 1e-9);
+  }
+  asm volatile("" : "+v"(acc), "+v"(acc2), "+v"(z));
+  t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[10] = (t1 - t0);
+  // (l) v_rcp_f64 + 4 fma beside one MFMA
+  t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 4
+  for (int i = 0; i < N; ++i) {
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(1e-3, 1e-3, acc, 0, 0, 0);
+    double r = __builtin_amdgcn_rcp(z);
+    r = fma(fma(-z, r, 1.0), r, r);
+    r = fma(fma(-z, r, 1.0), r, r);
+    z = r + 1.5;
+  }
+  asm volatile("" : "+v"(acc), "+v"(z));
+  t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[11] = (t1 - t0);
+  out[lane] = x + acc[0] + acc[1] + acc2[2] + s + v + z + zf;
 }
 int main() {
   double* out;
@@ -93,12 +143,14 @@ int main() {
   hipMalloc(&cyc, 64 * 8);
   for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, out, cyc, 1.25);
   hipDeviceSynchronize();
-  long long h[8];
+  long long h[12];
   hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
-  const char* names[8] = {"v_rcp_f64 dependent", "v_fma_f64 dependent", "mfma_f64_16x16x4 accumulator chain",
+  const char* names[12] = {"v_rcp_f64 dependent", "v_fma_f64 dependent", "mfma_f64_16x16x4 accumulator chain",
                           "mfma <- VALU <- mfma result", "mfma <- readlane <- mfma result",
-                          "pivot step (readlane, rcp + 2 Newton, mul, 2 mfma)", "mfma_f64_4x4x4 chain", "ds_bpermute dependent"};
-  for (int i = 0; i < 8; ++i) printf("%-55s %7.1f s_memtime ticks per iteration\n", names[i], h[i] / 256.0);
+                          "pivot step (readlane, rcp + 2 Newton, mul, 2 mfma)", "mfma_f64_4x4x4 chain", "ds_bpermute dependent",
+                          "1 mfma + 8 dependent v_fma_f64 (independent of it)", "1 mfma + 8 dependent v_fma_f32",
+                          "2 mfma + 8 dependent v_fma_f64", "1 mfma + rcp, 4 fma, add (f64)"};
+  for (int i = 0; i < 12; ++i) printf("%-55s %7.1f s_memtime ticks per iteration\n", names[i], h[i] / 256.0);
   int main2();
   return main2();
 }

@@ -24,6 +24,7 @@ int main(int argc, char** argv) {
   hipMemcpy(dG, G.data(), G.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dg, g.data(), g.size() * 8, hipMemcpyHostToDevice);
   hipMemcpy(dp, perms.data(), perms.size() * 4, hipMemcpyHostToDevice); hipMemset(di, 0, 32); hipMemset(dl, 0, (size_t)n_ord * p * 8);
   SmallArgs a; a.S[0] = a.S[1] = dG; a.s[0] = a.s[1] = dg; a.aug[0] = a.aug[1] = 10.0; a.ld_src = ld; a.perms = dp; a.p = p; a.nb = (p + 16) / 16;
+  a.variant = argc > 3 ? atoi(argv[3]) : 0;
   a.n_ord = n_ord; a.per_sample = 1; a.lifts = dl; a.y_norm_sq = 5.0; a.piv_tol = 1e-12; a.info = di;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
@@ -45,6 +46,20 @@ int main(int argc, char** argv) {
     printf("cholesky detail (us): first factor16 %.2f | barrier+panel(0) %.2f | own trailing tile %.2f | factor16 %.2f | wait for helpers %.2f\n",
            (st[8]-st[2])/100.0, (st[9]-st[8])/100.0, (st[10]-st[9])/100.0, (st[11]-st[10])/100.0, (st[12]-st[11])/100.0);
   }
+  if (a.variant == 0 && a.nb <= 7) {
+    long long rs[2][12]; hipMemcpyFromSymbol(rs, HIP_SYMBOL(g_reg_stamps), sizeof rs);
+    for (int w = 0; w < 2; ++w)
+      printf("   gather detail, wave %d: perm + rhs %lld | indices, first fetch issued %lld | block columns %lld | edge %lld\n", w, rs[w][8] - rs[w][0], rs[w][9] - rs[w][8], rs[w][10] - rs[w][9], rs[w][1] - rs[w][10]);
+    long long cs[2][8][4]; hipMemcpyFromSymbol(cs, HIP_SYMBOL(g_reg_chol), sizeof cs);
+    for (int kb = 0; kb + 1 < a.nb; ++kb)
+      printf("   block step %d, wave 0: elimination %lld | scaling, inverse to operand form %lld | panel + trailing products %lld\n", kb,
+             cs[0][kb][1] - cs[0][kb][0], cs[0][kb][2] - cs[0][kb][1], cs[0][kb + 1][0] - cs[0][kb][2]);
+    for (int w = 0; w < 2; ++w)
+      printf("register kernel, wave %d (cycles): perm %lld gather %lld cholesky %lld handover %lld vsolve %lld wait %lld terms %lld sums %lld | total %lld\n", w,
+             rs[w][1] - rs[w][0], 0LL, rs[w][2] - rs[w][1], rs[w][3] - rs[w][2], rs[w][4] - rs[w][3], rs[w][5] - rs[w][4], rs[w][6] - rs[w][5], rs[w][7] - rs[w][6], rs[w][7] - rs[w][0]);
+  }
+  std::vector<double> hl((size_t)n_ord * p); hipMemcpy(hl.data(), dl, hl.size() * 8, hipMemcpyDeviceToHost);
+  double cs = 0; for (double v : hl) cs += v; printf("checksum of the lifts %.15e\n", cs);
   int info; hipMemcpy(&info, di, 4, hipMemcpyDeviceToHost); printf("info %d lds %zu\n", info, small_p_lds_bytes(a.nb));
   return 0;
 }
