@@ -227,6 +227,7 @@ int lsspa_profile_reset(lsspa_ctx* ctx);
  *  4096  streamed reduction page-locks the caller's X in place (interior pages only; off by default: slower)
  * 65536  Gram kernel: workgroup id = unit (the units of a row slice spread over the XCDs instead of sharing one L2)
  *  8192  whole factorisation in one launch, a workgroup per matrix (measured slower than a launch per panel step)
+ * 16384  small problems: the LDS-resident kernel also where the register-resident one applies (p + 1 <= 112)
  * Every combination computes the same lifts (tests/test_gpu_kernels.py). */
 int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);
 

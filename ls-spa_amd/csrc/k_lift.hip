@@ -256,56 +256,101 @@ __global__ __launch_bounds__(256) void stats_reduce_kernel(const double* __restr
 // n_samples x p), operands straight from memory (16 consecutive features of one sample = one 128-byte segment),
 // the tile and its mirror stored together (Q stays exactly symmetric).  The last workgroup sums the columns (S) and
 // writes n_b.  A few microseconds where the 64 x 64-tile kernel above, with a handful of workgroups, takes forty.
-__global__ __launch_bounds__(64) void stats_small_kernel(const double* __restrict__ lifts,
-                                                         const double* __restrict__ mean, double* __restrict__ buf,
-                                                         int n_samples, int p, int accumulate) {
-  const int lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
-  double* S = buf + 1;
-  double* Q = buf + 1 + p;
-  int ti = 0, t = blockIdx.x;
-  while (t >= ti + 1) {
-    t -= ti + 1;
-    ++ti;
-  }
-  const int tj = t;
-  const bool diag = ti == tj;
+// Moments of one 16 x 16 tile by a 256-thread workgroup: four waves, a quarter of the samples each (one wave per tile
+// was a chain of 2-3 x 32 dependent matrix instructions: on this chip a matrix instruction also holds the SIMD's
+// vector pipe, so nothing hides behind it).  The column sums are plain vector adds over a lane's samples plus two
+// cross-lane steps; the four partial tiles and column sums meet in LDS and are added in fixed order (bitwise
+// reproducible).  Thread tid gets element (row tid / 16, column tid % 16) of the tile: q = sum_s D[s][a] D[s][b],
+// sa = sum_s D[s][a], sb = sum_s D[s][b] with D = lifts - mean.  Both small-p statistics kernels go through here, so
+// the one-GPU fused merge and the all-reduce path add the same numbers in the same order.
+struct TileMoments {
+  double q, sa, sb;
+};
+__device__ __forceinline__ TileMoments small_tile_moments(const double* __restrict__ lifts,
+                                                          const double* __restrict__ mean, int n_samples, int p,
+                                                          int ti, int tj) {
+  __shared__ double s_acc[4][256];
+  __shared__ double s_sa[4][16], s_sb[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int a = 16 * ti + l15, b = 16 * tj + l15;
   const int ac = a < p ? a : p - 1, bc = b < p ? b : p - 1;     // clamped addresses, value selected afterwards
   const double mua = mean[ac], mub = mean[bc];
-  d4 acc = d4_zero(), colsum = d4_zero();
-  // 128 samples per trip: 64 independent loads per lane in flight (the wave has the register file to itself), then
-  // 32 (+32) MFMAs -- the kernel is a chain of load round trips, two of them for a batch of 256 instead of eight
-  constexpr int KT = 32;
-  for (int s0 = 0; s0 < n_samples; s0 += 4 * KT) {
+  // samples of this wave: a contiguous quarter, a multiple of four long
+  const int per = ((n_samples + 15) / 16) * 4;
+  const int s_lo = wv * per, s_hi = min(n_samples, s_lo + per);
+  d4 acc = d4_zero();
+  double ca = 0.0, cb = 0.0;
+  constexpr int KT = 8;
+  for (int s0 = s_lo; s0 < s_hi; s0 += 4 * KT) {
     double ra[KT], rb[KT];
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk) {
       const int s = s0 + 4 * kk + l4;
-      const int sc = s < n_samples ? s : n_samples - 1;
+      const int sc = s < s_hi ? s : n_samples - 1;
       ra[kk] = lifts[(int64_t)sc * p + ac];
       rb[kk] = lifts[(int64_t)sc * p + bc];
     }
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk) {
       const int s = s0 + 4 * kk + l4;
-      const double av = (s < n_samples && a < p) ? ra[kk] - mua : 0.0;
-      const double bv = (s < n_samples && b < p) ? rb[kk] - mub : 0.0;
+      const double av = (s < s_hi && a < p) ? ra[kk] - mua : 0.0;
+      const double bv = (s < s_hi && b < p) ? rb[kk] - mub : 0.0;
       acc = mfma(av, bv, acc);
-      if (diag) colsum = mfma(av, 1.0, colsum);     // every column of the result = sum over the samples of D[., a]
+      ca += av;
+      cb += bv;
     }
   }
+  // column sums over the four sample residues (lanes 16 apart)
+  ca += __shfl_xor(ca, 16);
+  ca += __shfl_xor(ca, 32);
+  cb += __shfl_xor(cb, 16);
+  cb += __shfl_xor(cb, 32);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int ai = 16 * ti + acc_row(l4, r), bi = 16 * tj + l15;
-    if (ai < p && bi < p) {
-      const int64_t o = (int64_t)ai * p + bi, om = (int64_t)bi * p + ai;
-      const double v = accumulate ? Q[o] + acc[r] : acc[r];
-      Q[o] = v;
-      if (!diag) Q[om] = v;
-    }
-    if (diag && l15 == 0 && ai < p) S[ai] = accumulate ? S[ai] + colsum[r] : colsum[r];
+  for (int r = 0; r < 4; ++r) s_acc[wv][16 * acc_row(l4, r) + l15] = acc[r];
+  if (l4 == 0) {
+    s_sa[wv][l15] = ca;
+    s_sb[wv][l15] = cb;
   }
-  if (blockIdx.x == 0 && lane == 0) buf[0] = accumulate ? buf[0] + (double)n_samples : (double)n_samples;
+  __syncthreads();
+  const int er = tid >> 4, ec = tid & 15;
+  TileMoments m;
+  m.q = ((s_acc[0][tid] + s_acc[1][tid]) + s_acc[2][tid]) + s_acc[3][tid];
+  m.sa = ((s_sa[0][er] + s_sa[1][er]) + s_sa[2][er]) + s_sa[3][er];
+  m.sb = ((s_sb[0][ec] + s_sb[1][ec]) + s_sb[2][ec]) + s_sb[3][ec];
+  return m;
+}
+
+__device__ __forceinline__ void tile_of(int t, int& ti, int& tj) {   // lower tiles, row by row
+  ti = 0;
+  while (t >= ti + 1) {
+    t -= ti + 1;
+    ++ti;
+  }
+  tj = t;
+}
+
+__global__ __launch_bounds__(256) void stats_small_kernel(const double* __restrict__ lifts,
+                                                          const double* __restrict__ mean, double* __restrict__ buf,
+                                                          int n_samples, int p, int accumulate) {
+  double* S = buf + 1;
+  double* Q = buf + 1 + p;
+  int ti, tj;
+  tile_of(blockIdx.x, ti, tj);
+  const bool diag = ti == tj;
+  const int tid = threadIdx.x, er = tid >> 4, ec = tid & 15;
+  const int ai = 16 * ti + er, bi = 16 * tj + ec;
+  const bool live = ai < p && bi < p;
+  const int64_t o = live ? (int64_t)ai * p + bi : 0;
+  const double q_old = accumulate ? Q[o] : 0.0;                         // fetched before the moments, used after
+  const double s_old = (accumulate && diag && ec == 0 && ai < p) ? S[ai] : 0.0;
+  const TileMoments m = small_tile_moments(lifts, mean, n_samples, p, ti, tj);
+  if (live) {
+    const double v = accumulate ? q_old + m.q : m.q;
+    Q[o] = v;
+    if (!diag) Q[(int64_t)bi * p + ai] = v;
+  }
+  if (diag && ec == 0 && ai < p) S[ai] = accumulate ? s_old + m.sa : m.sa;
+  if (blockIdx.x == 0 && tid == 0) buf[0] = accumulate ? buf[0] + (double)n_samples : (double)n_samples;
 }
 
 // The same tiles with the Chan merge folded in, for a single GPU (nothing to all-reduce between the batch moments and
@@ -314,59 +359,33 @@ __global__ __launch_bounds__(64) void stats_small_kernel(const double* __restric
 // to its tile of M2 at once; the diagonal tiles write the advanced mean.  The mean (and n) are READ by every tile,
 // so the new ones go to a second buffer (mean_out, state_out) that the host swaps in afterwards: one launch, no
 // pending buffer, no ticket -- the two launches it replaces were a fifth of a p = 100 step.
-__global__ __launch_bounds__(64) void stats_small_fused_kernel(const double* __restrict__ lifts,
-                                                               const double* __restrict__ mean,
-                                                               const double* __restrict__ state,
-                                                               double* __restrict__ mean_out,
-                                                               double* __restrict__ state_out, double* __restrict__ M2,
-                                                               int n_samples, int p) {
-  const int lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
-  int ti = 0, t = blockIdx.x;
-  while (t >= ti + 1) {
-    t -= ti + 1;
-    ++ti;
-  }
-  const int tj = t;
+// Round 3, second form: the tile's moments by four waves (small_tile_moments), thread (row, column) of the 256 applies the
+// merge to its element of M2, fetched at the start of the kernel.
+__global__ __launch_bounds__(256) void stats_small_fused_kernel(const double* __restrict__ lifts,
+                                                                const double* __restrict__ mean,
+                                                                const double* __restrict__ state,
+                                                                double* __restrict__ mean_out,
+                                                                double* __restrict__ state_out, double* __restrict__ M2,
+                                                                int n_samples, int p) {
+  int ti, tj;
+  tile_of(blockIdx.x, ti, tj);
   const bool diag = ti == tj;
-  const int a = 16 * ti + l15, b = 16 * tj + l15;
-  const int ac = a < p ? a : p - 1, bc = b < p ? b : p - 1;     // clamped addresses, value selected afterwards
-  const double mua = mean[ac], mub = mean[bc];
+  const int tid = threadIdx.x, er = tid >> 4, ec = tid & 15;
+  const int ai = 16 * ti + er, bi = 16 * tj + ec;
+  const bool live = ai < p && bi < p;
+  const int64_t o = live ? (int64_t)ai * p + bi : 0;
+  const double m2_old = M2[o];
   const double n = state[0], nb = (double)n_samples;
-  d4 acc = d4_zero(), suma = d4_zero(), sumb = d4_zero();
-  constexpr int KT = 32;
-  for (int s0 = 0; s0 < n_samples; s0 += 4 * KT) {
-    double ra[KT], rb[KT];
-#pragma unroll
-    for (int kk = 0; kk < KT; ++kk) {
-      const int s = s0 + 4 * kk + l4;
-      const int sc = s < n_samples ? s : n_samples - 1;
-      ra[kk] = lifts[(int64_t)sc * p + ac];
-      rb[kk] = lifts[(int64_t)sc * p + bc];
-    }
-#pragma unroll
-    for (int kk = 0; kk < KT; ++kk) {
-      const int s = s0 + 4 * kk + l4;
-      const double av = (s < n_samples && a < p) ? ra[kk] - mua : 0.0;
-      const double bv = (s < n_samples && b < p) ? rb[kk] - mub : 0.0;
-      acc = mfma(av, bv, acc);
-      suma = mfma(av, 1.0, suma);     // element (row a, any column) = sum over the samples of D[., a]
-      sumb = mfma(1.0, bv, sumb);     // element (any row, column b) = sum over the samples of D[., b]
-    }
-  }
+  const TileMoments m = small_tile_moments(lifts, mean, n_samples, p, ti, tj);
   const double coef = n * nb / (n + nb) - nb;
   const double inv = 1.0 / nb;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int ai = 16 * ti + acc_row(l4, r), bi = 16 * tj + l15;
-    if (ai < p && bi < p) {
-      const int64_t o = (int64_t)ai * p + bi, om = (int64_t)bi * p + ai;
-      const double v = M2[o] + (acc[r] + coef * (suma[r] * inv) * (sumb[r] * inv));
-      M2[o] = v;
-      if (!diag) M2[om] = v;
-    }
-    if (diag && l15 == 0 && ai < p) mean_out[ai] = mean[ai] + suma[r] / (n + nb);
+  if (live) {
+    const double v = m2_old + (m.q + coef * (m.sa * inv) * (m.sb * inv));
+    M2[o] = v;
+    if (!diag) M2[(int64_t)bi * p + ai] = v;
   }
-  if (blockIdx.x == 0 && lane == 0) {
+  if (diag && ec == 0 && ai < p) mean_out[ai] = mean[ai] + m.sa * (1.0 / (n + nb));   // as stats_merge_fused_kernel rounds it
+  if (blockIdx.x == 0 && tid == 0) {
     state_out[0] = n + nb;
     state_out[1] = 0.0;     // the fused merge kernel's ticket, kept clear in both buffers
   }
@@ -376,7 +395,7 @@ hipError_t launch_stats_small_fused(const double* lifts, const double* mean, con
                                     double* state_out, double* M2, int n_samples, int p, hipStream_t st) {
   if (!stats_small_fusable(n_samples, p)) return hipErrorInvalidValue;
   const int t16 = (p + 15) / 16, n_tiles = t16 * (t16 + 1) / 2;
-  hipLaunchKernelGGL(stats_small_fused_kernel, dim3(n_tiles), dim3(64), 0, st, lifts, mean, state, mean_out, state_out,
+  hipLaunchKernelGGL(stats_small_fused_kernel, dim3(n_tiles), dim3(256), 0, st, lifts, mean, state, mean_out, state_out,
                      M2, n_samples, p);
   return hipGetLastError();
 }
@@ -398,7 +417,7 @@ hipError_t launch_stats_batch(const double* lifts, const double* mean, double* b
   if (n_samples < 1 || p < 1) return hipErrorInvalidValue;
   if (p <= 128 && n_samples <= 512) {
     const int t16 = (p + 15) / 16, n_tiles = t16 * (t16 + 1) / 2;
-    hipLaunchKernelGGL(stats_small_kernel, dim3(n_tiles), dim3(64), 0, st, lifts, mean, buf, n_samples, p,
+    hipLaunchKernelGGL(stats_small_kernel, dim3(n_tiles), dim3(256), 0, st, lifts, mean, buf, n_samples, p,
                        accumulate);
     return hipGetLastError();
   }

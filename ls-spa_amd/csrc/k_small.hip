@@ -412,12 +412,17 @@ __device__ __forceinline__ constexpr int ublk(int kb, int ib) { return ib * (ib 
 constexpr int small_reg_vregion(int nb) {
   return (nb * (nb + 1) / 2) * 256 > 32 * (16 * nb + 2) ? (nb * (nb + 1) / 2) * 256 : 32 * (16 * nb + 2);
 }
-constexpr int small_reg_lds_doubles(int nb) { return small_reg_vregion(nb) + (nb + 2) * 256 + 32 + 128 + 128; }
+constexpr int small_reg_lds_doubles(int nb) { return small_reg_vregion(nb) + (nb + 2) * 256 + 32 + 128 + 128 + 256; }
 
 }  // namespace
 
+// waves per SIMD the register budget is cut for: one at six or seven block rows (up to 512 registers), two at four or
+// five (256), three below (168); LDS lets as many workgroups in
+constexpr int small_reg_waves(int nb) { return nb <= 3 ? 3 : (nb <= 4 ? 2 : 1); }
+
 template <int NB>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void small_reg_kernel(SmallArgs a) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(small_reg_waves(NB), small_reg_waves(NB))))
+void small_reg_kernel(SmallArgs a) {
   constexpr int NTRI = NB * (NB + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int VREG = small_reg_vregion(NB);
@@ -427,8 +432,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   double* const s_rd = s_scr + 512;                 // [2][16]: 1 / L[i][i] of the current diagonal block
   double* const s_z = s_rd + 32;                    // [128]
   double* const s_y = s_z + 128;                    // [128]
-  int32_t* const s_perm = reinterpret_cast<int32_t*>(s_y + 128);   // [128]
-  __shared__ int s_bad;
+  double* const s_tol = s_y + 128;                  // [2][128]: pivot thresholds (fourteen registers for the whole
+                                                    // factorisation otherwise, in a kernel that has none to spare)
+  int32_t* const s_perm = reinterpret_cast<int32_t*>(s_tol + 256);   // [128]
+  __shared__ int s_bad, s_flag;                     // s_flag: column blocks of V the training wave has finished
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0: training matrix, 1: test matrix
@@ -443,7 +450,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     s_z[tid] = a.s[0][src];          // the permuted right-hand sides g_pi, h_pi (row p of the two matrices) until the
     s_y[tid] = a.s[1][src];          // factorisations have produced z and y~, which take their place
   }
-  if (tid == 0) s_bad = 0;
+  if (tid == 0) {
+    s_bad = 0;
+    s_flag = 0;
+  }
   __syncthreads();
   RSTAMP(8);
 
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const double aug = a.aug[wv];
   const double* const svp = wv ? s_y : s_z;         // s[perm[j]]
   d4 U[NTRI];
-  double tol[NB];
+  double* const tol = s_tol + wv * 128;
   {
     const int RS = (p + 3) & ~1;                    // row stride of the staging area (even: 16-byte rows)
     double* const stage = s_V + wv * (VREG / 2);    // 16 RS <= VREG / 2 by the definition of VREG
@@ -530,7 +540,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
       const int i = 16 * kb + l15;
-      tol[kb] = a.piv_tol * ((i < p) ? d0[kb] : (i == p ? aug : 1.0));
+      if (l4 == 0) tol[i] = a.piv_tol * ((i < p) ? d0[kb] : (i == p ? aug : 1.0));
     }
   }
   __syncthreads();           // the staging area is the other wave's too from its hand-over on
@@ -548,7 +558,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int r = 0; r < 4; ++r) y[r] = (acc_row(l4, r) == l15) ? 1.0 : 0.0;
     CSTAMP(kb, 0);
-    factor16_acc<double>(t, y, tol[kb], lane, bad);
+    factor16_acc<double>(t, y, tol[16 * kb + l15], lane, bad);
 #ifdef LSSPA_SMALL_STAMPS
     asm volatile("" : "+v"(t), "+v"(y));
 #endif
@@ -595,6 +605,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int r = 0; r < 4; ++r) U[ublk(jb, ib)] = mfma(na[r], U[ublk(kb, ib)][r], U[ublk(jb, ib)]);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (bad && lane == 0) s_bad = 1;
   RSTAMP(2);
@@ -625,7 +636,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   RSTAMP(3);
 
   // ---- V = L^-1 L_t by the training wave, column block by column block, top down; L comes from its registers:
-  //      the accumulator tile of U[k][i], read as an A operand, is L[i][k] with the summation index on the rows ----------
+  //      the accumulator tile of U[k][i], read as an A operand, is L[i][k] with the summation index on the rows.
+  //      The test wave follows one column block behind with the lift scan (a flag in LDS, no barrier): its work hides
+  //      behind the solve instead of following it (18.6 k of 133 k cycles when both waves scanned afterwards). ----------
   if (wv == 0) {
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
@@ -649,74 +662,79 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         vcol[i] = x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) Tb[sw(acc_row(l4, r), l15)] = x[r];
+        __builtin_amdgcn_sched_barrier(0);      // keep the next blocks' LDS reads from climbing up here: with 224 registers
+                                                // of matrix there is no room for them (scratch otherwise)
       }
+      if (lane == 0) __hip_atomic_store(&s_flag, cb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-  }
-  RSTAMP(4);
-  __syncthreads();
-  RSTAMP(5);
-
-  // ---- lift terms  w[j][c] = V[j][c] (2 y~_c - N_j - N_{j-1}),  N_j = sum_{k <= j} z_k V[k][c]: a thread per column.
-  //      No branch per element (the first version's per-row conditions became 112 masked regions, each with its own LDS
-  //      round trip, and one pass per column block: 19 k cycles): every thread walks all block rows, rows outside its
-  //      column's range enter with z = 0 (N stays put, the term of a zero above the diagonal is zero) and only the store
-  //      is predicated, once per block. ---------------------------------------------------------------------------------
-  {
-    const int c = min(tid, p - 1), cbk = c >> 4, cc = c & 15;
-    const double y2 = 2.0 * s_y[c];
-    double N = 0.0;
-#pragma unroll
-    for (int jb = 0; jb < NB; ++jb) {
-      const bool blk = (jb >= cbk) && (tid < p);
-      const int jbx = max(jb, cbk);                   // above its range a column re-reads its first block (nothing stored)
-      double* const B = s_V + (jbx * (jbx + 1) / 2 + cbk) * 256;
-      double v[16], zz[16];
-#pragma unroll
-      for (int jr = 0; jr < 16; ++jr) {
-        v[jr] = B[sw(jr, cc)];
-        zz[jr] = s_z[16 * jb + jr];
-      }
-      double wv_[16];
-#pragma unroll
-      for (int jr = 0; jr < 16; ++jr) {
-        const int j = 16 * jb + jr;
-        const double zj = (blk && j >= c && j < p) ? zz[jr] : 0.0;
-        const double Nn = fma(zj, v[jr], N);
-        wv_[jr] = v[jr] * (y2 - Nn - N);
-        N = Nn;
-      }
-      if (blk) {
-#pragma unroll
-        for (int jr = 0; jr < 16; ++jr) B[sw(jr, cc)] = wv_[jr];
-      }
-    }
-  }
-  __syncthreads();
-  RSTAMP(6);
-
-  // ---- lift_j = z_j / ||y||^2 * sum_{c <= j} w[j][c]: a thread per row, 16-byte reads (the swizzle moves whole pairs) ----
-  {
+    RSTAMP(4);
+  } else {
+    // lift terms  w[j][c] = V[j][c] (2 y~_c - N_j - N_{j-1}),  N_j = sum_{k <= j} z_k V[k][c]  down column c, then
+    // lift_j = z_j / ||y||^2 * sum_{c <= j} w[j][c].  A lane takes column cc = lane & 15 of the block and rows
+    // 4 sq .. 4 sq + 3 (sq = lane / 16) of every block row: a block row's scan is four partial sums, an exclusive prefix
+    // over the four lane groups, four terms.  V is exactly zero above the diagonal (so are its terms), and the rows
+    // from p on come last in a column: no range tests.  Row sums: lane = row (two passes of 64), added up per column block.
     typedef double d2 __attribute__((ext_vector_type(2)));
-    const int j = min(tid, p - 1), jb = j >> 4, jr = j & 15, swz = (jr >> 1) << 1;
-    double sacc = 0.0;
+    const int cc = l15, sq = l4;
+    double racc[2] = {0.0, 0.0};
 #pragma unroll
-    for (int cbk = 0; cbk < NB; ++cbk) {
-      const double* const B = s_V + (jb * (jb + 1) / 2 + min(cbk, jb)) * 256 + 16 * jr;
-      d2 v[8];
+    for (int cb = 0; cb < NB; ++cb) {
+      while (__hip_atomic_load(&s_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= cb) __builtin_amdgcn_s_sleep(8);
+      const double y2 = 2.0 * s_y[16 * cb + cc];
+      double base = 0.0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const d2*>(B + ((2 * q) ^ swz));
+      for (int jb = cb; jb < NB; ++jb) {
+        double* const B = s_V + ublk(cb, jb) * 256;
+        double v[4], z[4];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int c0 = 16 * cbk + 2 * q;
-        sacc += (cbk <= jb && c0 <= j) ? v[q][0] : 0.0;
-        sacc += (cbk <= jb && c0 + 1 <= j) ? v[q][1] : 0.0;
+        for (int i = 0; i < 4; ++i) {
+          v[i] = B[sw(4 * sq + i, cc)];
+          z[i] = s_z[16 * jb + 4 * sq + i];
+        }
+        double q = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q = fma(z[i], v[i], q);
+        const double q1 = __shfl(q, lane - 16), q2 = __shfl(q, lane - 32), q3 = __shfl(q, lane - 48);
+        const double pre = (sq >= 1 ? q1 : 0.0) + (sq >= 2 ? q2 : 0.0) + (sq >= 3 ? q3 : 0.0);
+        const double tot = __shfl(pre + q, 48 + cc);     // the block row's whole sum, from the last lane group
+        double N = base + pre;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const double Nn = fma(z[i], v[i], N);
+          B[sw(4 * sq + i, cc)] = v[i] * (y2 - Nn - N);
+          N = Nn;
+        }
+        base += tot;
       }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int j = lane + 64 * pass, jb = j >> 4, jr = j & 15, swz = (jr >> 1) << 1;
+        if (16 * cb < 64 * (pass + 1) && 64 * pass < 16 * NB) {       // static: this pass has rows of the column block
+          const bool live = jb >= cb && jb < NB;
+          const int jbx = live ? jb : cb;
+          const double* const B = s_V + (jbx * (jbx + 1) / 2 + cb) * 256 + 16 * jr;
+          double sacc = 0.0;
+#pragma unroll
+          for (int qd = 0; qd < 8; ++qd) {
+            const d2 t2 = *reinterpret_cast<const d2*>(B + ((2 * qd) ^ swz));
+            sacc += t2[0] + t2[1];
+          }
+          racc[pass] += live ? sacc : 0.0;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    if (tid < p) {
-      const double lift = s_z[j] * sacc / a.y_norm_sq;
-      double* dst = a.lifts + (int64_t)(ord / a.per_sample) * p + s_perm[j];
-      if (a.per_sample == 2) atomicAdd(dst, 0.5 * lift);   // the pair's two terms commute: order-independent sum
-      else *dst = lift;
+    RSTAMP(4);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int j = lane + 64 * pass;
+      if (j < p) {
+        const double lift = s_z[j] * racc[pass] / a.y_norm_sq;
+        double* dst = a.lifts + (int64_t)(ord / a.per_sample) * p + s_perm[j];
+        if (a.per_sample == 2) atomicAdd(dst, 0.5 * lift);   // the pair's two terms commute: order-independent sum
+        else *dst = lift;
+      }
     }
   }
   if (tid == 0 && s_bad) atomicOr(a.info, 1);

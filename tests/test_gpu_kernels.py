@@ -519,11 +519,14 @@ def test_driver_lookahead_on_the_device():
         eng.close()
 
 
-@pytest.mark.parametrize("p,n,m", [(3, 50, 50), (9, 80, 60), (15, 90, 70), (16, 90, 70), (63, 300, 200), (100, 400, 300),
-                                   (126, 500, 400), (127, 500, 400)])
+@pytest.mark.parametrize("p,n,m", [(3, 50, 50), (9, 80, 60), (15, 90, 70), (16, 90, 70), (31, 150, 120), (47, 200, 160),
+                                   (63, 300, 200), (79, 300, 250), (95, 350, 300), (100, 400, 300), (111, 420, 330),
+                                   (112, 420, 330), (126, 500, 400), (127, 500, 400)])
 def test_fused_small_p_kernel(p, n, m):
-    """p + 1 <= 128: the one-workgroup kernel (gather -> two Choleskys -> V -> lifts in LDS) against the oracle and
-    against the general multi-kernel path (developer flag 1024), single orderings and antithetical pairs."""
+    """p + 1 <= 128: the fused per-ordering kernels (gather -> two Choleskys -> V -> lifts; p + 1 <= 112 with the
+    matrices in registers, every block-row count from one to seven, beyond that in LDS) against the oracle, against each
+    other (developer flag 16384 = the LDS kernel everywhere) and against the general multi-kernel path (flag 1024),
+    single orderings and antithetical pairs."""
     from ls_spa._engine import HipEngine
     d = problem(20 + p, p, n, m)
     rng = np.random.default_rng(p)
@@ -549,8 +552,11 @@ def test_fused_small_p_kernel(p, n, m):
         np.testing.assert_allclose(single.sum(1), single[0].sum(), rtol=0, atol=1e-11)   # every ordering: the full R^2
         eng.set_flags(1024)
         general = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        eng.set_flags(16384)
+        in_lds = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
         eng.set_flags(0)
         np.testing.assert_allclose(paired, general, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(paired, in_lds, rtol=0, atol=1e-12)
         # statistics through the fused path
         eng.reset_stats()
         eng.run_batch(perms, True, accumulate=True)
@@ -601,7 +607,9 @@ def test_accumulate_and_merge_at_once(p, bsz):
             n1, m1, c1 = one.stats()
             assert n1 == n2
             np.testing.assert_allclose(m1, m2, rtol=0, atol=1e-15)
-            np.testing.assert_allclose(c1, c2, rtol=1e-13, atol=1e-18)
+            # the two forms add the samples' outer products up in different orders, and the first batch's are taken
+            # about a zero mean: rounding of the size of the squared lifts (<= 1), not of the covariance
+            np.testing.assert_allclose(c1, c2, rtol=1e-13, atol=1e-15)
         # launch / collect in parts, the second part at once
         perms = np.array([rng.permutation(p) for _ in range(2 * bsz)])
         t2, t1 = two.launch_batch(perms, True), one.launch_batch(perms, True)
@@ -609,7 +617,7 @@ def test_accumulate_and_merge_at_once(p, bsz):
             two.collect_batch(t2, accumulate=True, first=first, count=bsz)
             two.merge()
             one.collect_batch(t1, accumulate=2, first=first, count=bsz)
-        np.testing.assert_allclose(one.stats()[2], two.stats()[2], rtol=1e-13, atol=1e-18)
+        np.testing.assert_allclose(one.stats()[2], two.stats()[2], rtol=1e-13, atol=1e-15)
         assert one.stats()[0] == two.stats()[0] == 6 * bsz
         # against numpy on the lift vectors themselves
         one.reset_stats()

@@ -55,8 +55,9 @@ int main(int argc, char** argv) {
       printf("   block step %d, wave 0: elimination %lld | scaling, inverse to operand form %lld | panel + trailing products %lld\n", kb,
              cs[0][kb][1] - cs[0][kb][0], cs[0][kb][2] - cs[0][kb][1], cs[0][kb + 1][0] - cs[0][kb][2]);
     for (int w = 0; w < 2; ++w)
-      printf("register kernel, wave %d (cycles): perm %lld gather %lld cholesky %lld handover %lld vsolve %lld wait %lld terms %lld sums %lld | total %lld\n", w,
-             rs[w][1] - rs[w][0], 0LL, rs[w][2] - rs[w][1], rs[w][3] - rs[w][2], rs[w][4] - rs[w][3], rs[w][5] - rs[w][4], rs[w][6] - rs[w][5], rs[w][7] - rs[w][6], rs[w][7] - rs[w][0]);
+      printf("register kernel, wave %d (cycles): gather %lld | cholesky %lld | hand-over %lld | %s %lld | tail %lld | total %lld\n", w,
+             rs[w][1] - rs[w][0], rs[w][2] - rs[w][1], rs[w][3] - rs[w][2], w ? "lift scan behind the solve" : "V solve", rs[w][4] - rs[w][3],
+             rs[w][7] - rs[w][4], rs[w][7] - rs[w][0]);
   }
   std::vector<double> hl((size_t)n_ord * p); hipMemcpy(hl.data(), dl, hl.size() * 8, hipMemcpyDeviceToHost);
   double cs = 0; for (double v : hl) cs += v; printf("checksum of the lifts %.15e\n", cs);
