@@ -20,7 +20,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLASS_OF = {"gather_kernel": "gather", "chol_diag2_kernel": "chol_diag", "chol_panel2_kernel": "chol_panel",
-            "strip2_kernel": "strip", "lift_partial_kernel": "lift", "small_p_kernel": "small_p",
+            "strip2_kernel": "strip", "lift_partial_kernel": "lift", "small_p_kernel": "small_p", "small_reg_kernel": "small_p",
             "gram_kernel": "gram"}
 
 

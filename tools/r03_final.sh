@@ -7,7 +7,9 @@ P="--no-probe --no-ttt --no-cpu-baseline"
 if [ "$PART" = "all" ] || [ "$PART" = "a" ]; then
 python3 tools/gram_time.py > $O/gram_time.log 2>&1
 ./tools/bin/lat_probe > $O/lat_probe.log 2>&1
-./tools/bin/small_probe 100 2048 > $O/small_probe.log 2>&1
+./tools/bin/small_probe 100 2048 1 > $O/small_probe.log 2>&1
+./tools/bin/small_probe 100 2048 0 >> $O/small_probe.log 2>&1
+./tools/bin/small_probe 40 2048 0 >> $O/small_probe.log 2>&1
 ./tools/bin/factor_probe > $O/factor_probe.log 2>&1
 echo probes done
 # the driver's command, in full (time to tolerance, CPU baseline)
