@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256) void stats_reduce_kernel(const double* __restr
 // the tile and its mirror stored together (Q stays exactly symmetric).  The last workgroup sums the columns (S) and
 // writes n_b.  A few microseconds where the 64 x 64-tile kernel above, with a handful of workgroups, takes forty.
 // Moments of one 16 x 16 tile by a 256-thread workgroup: four waves, a quarter of the samples each (one wave per tile
-// was a chain of 2-3 x 32 dependent matrix instructions: on this chip a matrix instruction also holds the SIMD's
-// vector pipe, so nothing hides behind it).  The column sums are plain vector adds over a lane's samples plus two
+// was a chain of 2-3 x 32 matrix instructions, each of which holds its wave for 64 cycles, with no other wave on the
+// SIMD to fill them).  The column sums are plain vector adds over a lane's samples plus two
 // cross-lane steps; the four partial tiles and column sums meet in LDS and are added in fixed order (bitwise
 // reproducible).  Thread tid gets element (row tid / 16, column tid % 16) of the tile: q = sum_s D[s][a] D[s][b],
 // sa = sum_s D[s][a], sb = sum_s D[s][b] with D = lifts - mean.  Both small-p statistics kernels go through here, so

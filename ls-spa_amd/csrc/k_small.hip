@@ -483,7 +483,8 @@ void small_reg_kernel(SmallArgs a) {
       for (int r = 0; r < 4; ++r) pk[kb][r] = s_perm[min(16 * kb + l4 + 4 * r, p - 1)];
     }
     typedef double d2 __attribute__((ext_vector_type(2)));
-    d2 rows[16];
+    constexpr int AHEAD = small_reg_waves(NB) == 1 ? 2 : 1;    // block columns in flight (registers permitting)
+    d2 rows[AHEAD][16];
     // source row of position i as a scalar: lane i & 63 of one of two registers (a uniform LDS read per row and a wait
     // for each made a fetch sixteen LDS round trips)
     const int perm_lo = s_perm[min(lane, p - 1)], perm_hi = s_perm[min(64 + lane, p - 1)];
@@ -493,17 +494,18 @@ void small_reg_kernel(SmallArgs a) {
       for (int q = 0; q < 16; ++q) {
         const int i = 16 * ib + q;          // static after unrolling
         const int src = __builtin_amdgcn_readlane(i < 64 ? perm_lo : perm_hi, i & 63);   // positions >= p repeat row p - 1
-        rows[q] = *reinterpret_cast<const d2*>(Scol + src * ld);
+        rows[ib % AHEAD][q] = *reinterpret_cast<const d2*>(Scol + src * ld);
       }
     };
     fetch(0);
+    if (AHEAD > 1 && NB > 1) fetch(1);
     RSTAMP(9);
     double d0[NB];
 #pragma unroll
     for (int ib = 0; ib < NB; ++ib) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) *reinterpret_cast<d2*>(stage + q * RS + col2) = rows[q];
-      if (ib + 1 < NB) fetch(ib + 1);               // the next block column's rows travel while this one is picked
+      for (int q = 0; q < 16; ++q) *reinterpret_cast<d2*>(stage + q * RS + col2) = rows[ib % AHEAD][q];
+      if (ib + AHEAD < NB) fetch(ib + AHEAD);       // the next block columns' rows travel while this one is picked
       __builtin_amdgcn_wave_barrier();
       const double* const mine = stage + l15 * RS;
 #pragma unroll
@@ -663,7 +665,8 @@ void small_reg_kernel(SmallArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) Tb[sw(acc_row(l4, r), l15)] = x[r];
         __builtin_amdgcn_sched_barrier(0);      // keep the next blocks' LDS reads from climbing up here: with 224 registers
-                                                // of matrix there is no room for them (scratch otherwise)
+                                                // of matrix there is no room for them (scratch otherwise; fetching the next
+                                                // block's operands ahead by hand was measured: no gain, more scratch)
       }
       if (lane == 0) __hip_atomic_store(&s_flag, cb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }

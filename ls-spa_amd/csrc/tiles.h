@@ -368,9 +368,12 @@ __device__ __forceinline__ T bperm(int addr, T v) {
 // is 64 + 15 (tools/lat_probe.hip).  Pivot k + 1 does not need that result:
 //     d_{k+1} = T_k[k+1][k+1] - T_k[k][k+1]^2 / d_k
 // is made of two elements of T_k, read off the accumulators BEFORE instruction k takes them, so the threshold test
-// and the reciprocal of pivot k + 1 run on the vector pipe while instruction k runs on the matrix pipe; what is left
-// between two matrix instructions is a select and one multiplication.  (The diagonal element the instruction writes
-// and the d the multipliers were made with may differ in the last bit: rounding-level, like any reordering.)
+// and the reciprocal of pivot k + 1 no longer wait for instruction k's result; what is left between the result and the
+// next instruction is a select and one multiplication.  Measured: 377 -> 349 cycles per pivot, not the ~140 of the
+// dependence graph: an fp64 matrix instruction holds its own wave for its 64 cycles (nothing of the wave issues behind
+// it; the SIMD's other wave is free to), so a pivot is the two instructions plus the chain's vector instructions in
+// series.  (The diagonal element the instruction writes and the d the multipliers were made with may differ in the last
+// bit: rounding-level, like any reordering.)
 // The pivot row enters the B operand without its own diagonal element (column k of the rows below is never read again,
 // and a NaN there would spread over the whole column through 0 * NaN); a pivot at or below its threshold is replaced by
 // 1 for the multipliers at once and on the block's diagonal after the sweep.

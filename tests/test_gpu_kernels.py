@@ -519,7 +519,7 @@ def test_driver_lookahead_on_the_device():
         eng.close()
 
 
-@pytest.mark.parametrize("p,n,m", [(3, 50, 50), (9, 80, 60), (15, 90, 70), (16, 90, 70), (31, 150, 120), (47, 200, 160),
+@pytest.mark.parametrize("p,n,m", [(1, 30, 30), (2, 40, 30), (3, 50, 50), (9, 80, 60), (15, 90, 70), (16, 90, 70), (31, 150, 120), (47, 200, 160),
                                    (63, 300, 200), (79, 300, 250), (95, 350, 300), (100, 400, 300), (111, 420, 330),
                                    (112, 420, 330), (126, 500, 400), (127, 500, 400)])
 def test_fused_small_p_kernel(p, n, m):

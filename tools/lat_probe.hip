@@ -199,5 +199,87 @@ int main2() {
     printf("factor16_acc<double>, grid %4d x %3d threads: %.0f ticks per 16 x 16 block (%.1f per pivot)\n", cfg[c][0], cfg[c][1],
            h[0] / 64.0, h[0] / 64.0 / 16.0);
   }
+  int main3();
+  return main3();
+}
+
+// ---- does an fp64 matrix instruction of ONE wave hold up the vector instructions of ANOTHER wave of the same SIMD? -----
+// 512 threads: waves w and w + 4 share a SIMD.  Wave `busy` runs mode_busy (0: nothing, 1: back-to-back fp64 MFMAs,
+// 2: dependent v_fma_f64) for much longer than wave `timed` needs for 2048 dependent v_fma_f64 (or 256 MFMAs), which is timed.
+__global__ void probe_pair(double* out, long long* cyc, int busy, int timed, int mode_busy, int mode_timed, double seed) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double x = seed + lane * 1e-3;
+  d4 acc = {x, x, x, x};
+  if (wave == busy) {
+    if (mode_busy == 1) {
+#pragma unroll 16
+      for (int i = 0; i < 4096; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);   // register operands
+    } else if (mode_busy == 2) {
+#pragma unroll 16
+      for (int i = 0; i < 40000; ++i) x = fma(x, 0.999999, 1e-9);
+    }
+  } else if (wave == timed) {
+    // let the busy wave get going
+    for (int i = 0; i < 64; ++i) x = fma(x, 0.999999, 1e-9);
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    if (mode_timed == 0) {
+#pragma unroll 16
+      for (int i = 0; i < 2048; ++i) x = fma(x, 0.999999, 1e-9);
+    } else {
+#pragma unroll 16
+      for (int i = 0; i < 256; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+    }
+    asm volatile("" : "+v"(x), "+v"(acc));
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+  }
+  out[threadIdx.x] = x + acc[0];
+}
+int main3() {
+  double* out;
+  long long* cyc;
+  (void)hipMalloc(&out, 512 * 8);
+  (void)hipMalloc(&cyc, 64 * 8);
+  struct { int busy, timed, mb, mt; const char* what; } cfg[] = {
+      {0, 4, 0, 0, "2048 dependent v_fma_f64, the SIMD's other wave idle                    "},
+      {0, 4, 1, 0, "2048 dependent v_fma_f64, the SIMD's other wave issuing fp64 MFMAs      "},
+      {0, 4, 2, 0, "2048 dependent v_fma_f64, the SIMD's other wave issuing v_fma_f64       "},
+      {0, 5, 1, 0, "2048 dependent v_fma_f64, a wave of ANOTHER SIMD issuing fp64 MFMAs     "},
+      {0, 4, 0, 1, "256 fp64 MFMAs, the SIMD's other wave idle                              "},
+      {0, 4, 1, 1, "256 fp64 MFMAs, the SIMD's other wave issuing fp64 MFMAs                "},
+      {0, 4, 2, 1, "256 fp64 MFMAs, the SIMD's other wave issuing dependent v_fma_f64       "}};
+  for (auto& c : cfg) {
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(probe_pair, dim3(1), dim3(512), 0, 0, out, cyc, c.busy, c.timed, c.mb, c.mt, 1.25);
+    (void)hipDeviceSynchronize();
+    long long h[1];
+    (void)hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
+    printf("%s %8lld cycles (%.1f per instruction)\n", c.what, h[0], h[0] / (c.mt ? 256.0 : 2048.0));
+  }
+  // the same pair on every CU of the chip (2048 workgroups): is the rate a property of the SIMD or of the chip?
+  for (int mb = 0; mb < 3; ++mb) {
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(probe_pair, dim3(2048), dim3(512), 0, 0, out, cyc, 0, 4, mb, 1, 1.25);
+    (void)hipDeviceSynchronize();
+    long long h[1];
+    (void)hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
+    printf("2048 workgroups: 256 fp64 MFMAs of wave 4 while wave 0 of the same SIMD %s: %.1f cycles each\n",
+           mb == 0 ? "is idle" : (mb == 1 ? "issues fp64 MFMAs" : "issues v_fma_f64"), h[0] / 256.0);
+  }
+  // which waves of a 512-thread workgroup share a SIMD?  Two MFMA streams on one SIMD must halve each other.
+  for (int timed = 1; timed < 8; ++timed) {
+    long long h[2][1];
+    for (int mb = 0; mb < 2; ++mb) {
+      for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(probe_pair, dim3(1), dim3(512), 0, 0, out, cyc, 0, timed, mb, 1, 1.25);
+      (void)hipDeviceSynchronize();
+      (void)hipMemcpy(h[mb], cyc, sizeof h[mb], hipMemcpyDeviceToHost);
+    }
+    long long v[2][1];
+    for (int mb = 0; mb < 2; ++mb) {
+      for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(probe_pair, dim3(1), dim3(512), 0, 0, out, cyc, 0, timed, mb ? 2 : 0, 0, 1.25);
+      (void)hipDeviceSynchronize();
+      (void)hipMemcpy(v[mb], cyc, sizeof v[mb], hipMemcpyDeviceToHost);
+    }
+    printf("wave %d timed, wave 0 busy: 256 MFMAs %.1f -> %.1f cycles each when wave 0 issues MFMAs too; 2048 v_fma_f64 %.1f -> %.1f each when wave 0 issues v_fma_f64\n",
+           timed, h[0][0] / 256.0, h[1][0] / 256.0, v[0][0] / 2048.0, v[1][0] / 2048.0);
+  }
   return 0;
 }
