@@ -544,9 +544,10 @@ int gram_default_split(int64_t n, int p) {
   // whole rounds of 512 best (p = 1000: 16 -> 21 x 16 + 7 x 14 + 4 x 18 = 506), with slices of at least 256 rows
   // and at most ~8 rounds
   const int nt = n_tiles_of(p);
-  // slices of at least 256 rows -- 128 where the units are so few (one or two tiles) that the launch is a chain of
-  // load round trips, one per 16-row chunk, whatever the slice count
-  const int64_t min_rows = (nt <= 2) ? 128 : 256;
+  // slices of at least 256 rows -- 128 where the units are so few (two tiles) that the launch is a chain of load round
+  // trips, one per 16-row chunk, whatever the slice count, and 48 for a single tile (C2, p = 100, 10^4 rows: 34.2 us a
+  // side at 128 rows, 29.6 at 96, 28.9 at 64, 28.0 at 48, 35.5 at 32 -- below that the slabs' traffic takes over)
+  const int64_t min_rows = (nt == 1) ? 48 : ((nt == 2) ? 128 : 256);
   const int64_t cap = std::max<int64_t>(1, (n + min_rows - 1) / min_rows);
   int best = 1;
   double best_eff = 0.0;
