@@ -570,6 +570,27 @@ def test_fused_small_p_kernel(p, n, m):
         eng.close()
 
 
+def test_fused_small_p_every_feature_count():
+    """Every p from 1 to 127 once (block-row boundaries, ragged last blocks, the switch between the two fused kernels
+    at p = 111 / 112 and to the general path at 127): antithetical pairs against the oracle."""
+    from ls_spa._engine import HipEngine
+    eng = HipEngine(0)
+    try:
+        for p in range(1, 128):
+            d = problem(300 + p, p, 2 * p + 40, p + 50)
+            rng = np.random.default_rng(1000 + p)
+            perms = np.array([rng.permutation(p) for _ in range(4)])
+            red = O.reduce(*d, 1e-3)
+            yy = float(d[3] @ d[3])
+            eng.load_data(*d, 1e-3)
+            got = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+            assert eng.info() == 0, p
+            want = np.array([O.sample_lift(*red, yy, o, True) for o in perms])
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-10, err_msg=f"p = {p}")
+    finally:
+        eng.close()
+
+
 def test_fused_small_p_flags_collinear_features():
     from ls_spa._engine import HipEngine
     d = list(problem(5, 20, 200, 150))
