@@ -1296,10 +1296,10 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
   }
 
   PSTAMP(4);
-  // A[I,I] -= L[I,panel] L[I,panel]^T on the tile's own diagonal block (this workgroup alone owns it):
-  // 36 lower 16 x 16 tiles over the waves.  The accumulators of the solve are dead by now, so the eight
-  // chunks just written are staged once more (they come back from L2) instead of keeping both sets of
-  // accumulators alive through the store loop.
+  // A[I,I] -= L[I,0:J0+128) L[I,0:J0+128)^T on the diagonal block that tile 0 owns and factors next: 36 lower
+  // 16 x 16 tiles over the waves.  The accumulators of the solve are dead by now; the eight chunks just written are
+  // staged once more (they come back from L2) instead of keeping both sets of accumulators alive through the
+  // store loop.
   __threadfence_block();
   // The tiles of a wave -- t = ws + NW q of the row-by-row enumeration -- are COMPILE-TIME constants in four (eight)
   // copies of the loop, one per wave index: with run-time tile indices every product had its own pair of LDS reads,
@@ -1320,30 +1320,42 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
       for (int r = 0; r < 4; ++r)
         upd[q][r] = -M[cm_off(p_pad, I0 + 16 * ti + Tr<T>::acc_row(l4, r), I0 + 16 * tj + l15)];
     }
-    const T* srcP = M + cm_off(p_pad, I0, J0);
+    // LEFT-looking, once per diagonal block (round 3): only the tile-0 workgroup comes here, for the block it is about
+    // to factor, and applies the whole row panel L[I, 0 : J0 + 128) -- the chunks of the earlier panel steps and the
+    // eight just written -- in one loop.  Before, every tile of every panel step read its diagonal block, subtracted its
+    // own 128 columns' worth and wrote it back (28 read-modify-writes of a 128 x 128 block per matrix instead of 7, and
+    // 28 short loops with their ramps instead of 7 long ones): panel launches 3.86 -> 3.72 ms per C3 step in alternating
+    // processes on one box.
+    const T* srcP = srcI;
+    const int ndc = nch + 8;
     RKRegs<T, 128, NT> rp = {};
     __syncthreads();   // all stores above are issued and fenced
     PSTAMP(8);
-    rk_load_full<T, 128, NT>(rp, srcP, CM_LD, tid);
-    for (int c = 0; c < 8; ++c) {
-      __syncthreads();
-      rk_store<T, 128, NT>(rp, s_out, tid);
-      __syncthreads();
-      if (c == 0) PSTAMP(9);
-      if (c == 1) PSTAMP(10);
-      if (c == 2) PSTAMP(11);
-      if (c + 1 < 8) rk_load_full<T, 128, NT>(rp, srcP + (c + 1) * chunk, CM_LD, tid);
+    auto products = [&](const T* buf) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         T z[8];
 #pragma unroll
-        for (int bk = 0; bk < 8; ++bk) z[bk] = s_out[(16 * bk + l15) * RK_LD + 4 * kk + l4];
+        for (int bk = 0; bk < 8; ++bk) z[bk] = buf[(16 * bk + l15) * RK_LD + 4 * kk + l4];
 #pragma unroll
         for (int q = 0; q < NU; ++q) {
           const int t = WS + NW * q;
           if (t < 36) upd[q] = Tr<T>::mfma(z[syrk_ti_c(t)], z[syrk_tj_c(t)], upd[q]);
         }
       }
+    };
+    rk_load_full<T, 128, NT>(rp, srcP, CM_LD, tid);
+    // (two staging buffers and one barrier per chunk instead of two: 3.76-3.77 against 3.77-3.80 ms in alternating
+    // processes, within the noise, and 28 spilled registers in the fp32 instance -- not kept)
+    for (int c = 0; c < ndc; ++c) {
+      __syncthreads();
+      rk_store<T, 128, NT>(rp, s_out, tid);
+      __syncthreads();
+      if (c == 0) PSTAMP(9);
+      if (c == 1) PSTAMP(10);
+      if (c == 2) PSTAMP(11);
+      if (c + 1 < ndc) rk_load_full<T, 128, NT>(rp, srcP + (c + 1) * chunk, CM_LD, tid);
+      products(s_out);
     }
     PSTAMP(5);
 #pragma unroll
@@ -1357,6 +1369,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
       }
     }
   };
+  if (tile == 0)
   switch (ws) {     // scalar: the wave index
     case 0: diag_update(std::integral_constant<int, 0>()); break;
     case 1: diag_update(std::integral_constant<int, 1>()); break;
