@@ -1325,7 +1325,10 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
     // eight just written -- in one loop.  Before, every tile of every panel step read its diagonal block, subtracted its
     // own 128 columns' worth and wrote it back (28 read-modify-writes of a 128 x 128 block per matrix instead of 7, and
     // 28 short loops with their ramps instead of 7 long ones): panel launches 3.86 -> 3.72 ms per C3 step in alternating
-    // processes on one box.
+    // processes on one box.  Measured on top of it and not kept: (a) the columns of all but the last two panel steps
+    // applied one launch ahead by a workgroup of its own per matrix, to shorten this one (the launch's long pole) --
+    // 3.83 against 3.72 ms: the block is then read and written twice, and the extra workgroups delay the tiles;
+    // (b) tile-0 workgroups interleaved with the others in dispatch order instead of first -- 4.43 against 3.70 ms.
     const T* srcP = srcI;
     const int ndc = nch + 8;
     RKRegs<T, 128, NT> rp = {};
