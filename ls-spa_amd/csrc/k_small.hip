@@ -398,7 +398,7 @@ __global__ __launch_bounds__(512) void small_p_kernel(SmallArgs a) {
 //   * a trailing block  T^T[jb][ib] -= U[kb][jb]^T U[kb][ib]  takes BOTH operands from registers: the accumulator tile of
 //     U[kb][jb], read as an A operand, is U[kb][jb]^T with the same row index as the summation index.
 // A workgroup is two waves, one per matrix of an ordering, each alone on its SIMD with the 512-register budget of a
-// single-wave SIMD; 77 KB of LDS (L_t, then V; the training matrix's block inverses; vectors) lets two workgroups share a
+// single-wave SIMD; 79 KB of LDS (L_t, then V; the training matrix's block inverses; vectors) lets two workgroups share a
 // CU: four chains in flight instead of two, and no workgroup barrier inside the factorisation.  Afterwards the test
 // wave hands L_t over through LDS, the training wave solves V = L^-1 L_t column block by column block with L still in
 // its registers, and both waves run the lift scan, a thread per column and then per row.
