@@ -56,17 +56,16 @@ int lsspa_synchronize(lsspa_ctx* ctx);
  * count, 160 KB): p <= 13567; a larger p is refused here with LSSPA_ERR_ARG and a message naming it (the reference
  * has no limit, ls_spa/ls_spa.py:163).
  * Host arrays are never written and stay the caller's: they are read during the call only, through ordinary copies
- * (nothing of the caller's is page-locked: measured, the runtime's own pageable path is faster than registering the
- * arrays first; developer flag 4096 page-locks the whole pages strictly inside a dense X of 8 MB or more for the
- * duration of the call, never y, strided X or memory the HIP runtime already knows).
+ * (nothing of the caller's is ever page-locked: measured, the runtime's own pageable path is faster than registering
+ * the arrays first).
  * No C++ exception leaves any entry point of this header: host allocation failure is LSSPA_ERR_NOMEM. */
 int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const void* y_train, int64_t N,
                  const void* X_test, int64_t ld_test, const void* y_test, int64_t M, int32_t p, double reg,
                  int32_t dtype, int32_t location);
 
-/* Host seconds the last reduction from HOST arrays spent in its parts: [0] page-locking the caller's X (both sides),
- * [1] the streamed copies and Gram kernels (to the last one's completion), [2] un-locking, [3] finalize (scaling,
- * statistics reset, sync).  bench.py's e2e_breakdown. */
+/* Host seconds the last reduction from HOST arrays spent in its parts: [1] the streamed copies and Gram kernels (to
+ * the last one's completion), [3] finalize (scaling, statistics reset, sync); [0] and [2] (page-locking and
+ * un-locking of the caller's arrays, rounds 2-3) are always 0 now.  bench.py's e2e_breakdown. */
 int lsspa_reduce_timing(const lsspa_ctx* ctx, double* seconds4);
 
 /* a1, rows spread over several GPUs: every rank reduces the rows it holds,
@@ -218,17 +217,14 @@ int lsspa_profile_get(lsspa_ctx* ctx, int32_t kernel_class, double* total_ms, in
 int lsspa_profile_reset(lsspa_ctx* ctx);
 
 /* developer switches for in-process A/B timing and cross-checks of kernel variants (0 = shipped configuration):
- *     2  one-level path only: stand-alone diagonal-block launches instead of the fused ones
- *     4  one-level strip kernel (64-row steps)          8  one-level panel / diagonal kernels (64-wide panels)
  *    32  two half-batches on two streams               64  plain (matrix, tile) dispatch order in the panel kernel
- *   256  unpaired gather                              512  256-column strips (512-thread workgroups)
- *  2048  no skipping of the all-padding 16 x 16 tiles in the panel / strip products
- *  1024  general path also for small problems (p + 1 <= 128 normally takes the fused one-workgroup kernel)
- *  4096  streamed reduction page-locks the caller's X in place (interior pages only; off by default: slower)
- * 65536  Gram kernel: workgroup id = unit (the units of a row slice spread over the XCDs instead of sharing one L2)
- *  8192  whole factorisation in one launch, a workgroup per matrix (measured slower than a launch per panel step)
+ *   128  tri mode: V by the strip kernel (the shipped path of rect mode) instead of V^T by the panel launches' X tiles
+ *   256  unpaired gather                             1024  general path also for small problems (p + 1 <= 128
+ *  2048  no skipping of the all-padding 16 x 16 tiles       normally takes the fused one-workgroup kernel)
  * 16384  small problems: the LDS-resident kernel also where the register-resident one applies (p + 1 <= 112)
- * Every combination computes the same lifts (tests/test_gpu_kernels.py). */
+ * 65536  Gram kernel: workgroup id = unit (the units of a row slice spread over the XCDs instead of sharing one L2)
+ * Every combination computes the same lifts (tests/test_gpu_kernels.py).  Rounds 1-3 carried more (one-level kernels,
+ * whole-factorisation kernel, 256-column strips, page-locking of caller memory): measured slower, removed in round 4. */
 int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);
 
 /* test hooks */

@@ -1,5 +1,5 @@
 // Per-ordering factorisation kernels: permuted gather, blocked left-looking Cholesky
-// (diagonal-block and panel steps) and the strip triangular solve.  Templated on the element type
+// (diagonal-block and panel steps, with V^T = L_t^T L^-T as extra block rows) and the strip triangular solve.  Templated on the element type
 // of the work matrices (double: default; float: fp32 mode), see tiles.h.
 //
 // What they replace in the reference (cvxgrp/ls-spa, ls_spa/ls_spa.py):
@@ -166,504 +166,6 @@ hipError_t launch_to_f32(const double* src, float* dst, int64_t count, hipStream
   return hipGetLastError();
 }
 
-// =====================================================================================
-// Blocked Cholesky, left-looking for the off-diagonal tiles and right-looking for the
-// diagonal tiles:
-//   chol_diag,  step J : A[J,J] already carries every update  -sum_{K<J} L[J,K] L[J,K]^T
-//                        (applied by the panel steps below); factor it in place by an
-//                        elimination that carries the identity along, so L_JJ^-1 comes out
-//                        of the same sweep.  One workgroup per matrix, no GEMM.
-//   chol_panel, step J : for a 128-row tile I below the diagonal block,
-//                          C = A[I,J] - sum_{K<J} L[I,K] L[J,K]^T ;  L[I,J] = C * L_JJ^-T ;
-//                        then, while L[I,J] sits in LDS for its coalesced store, the two
-//                        diagonal tiles of the tile's own rows get  -= L[I',J] L[I',J]^T.
-// =====================================================================================
-// LDS scratch of the 64 x 64 elimination
-template <typename T>
-struct ElimScratch {
-  T col[2][64];  // column k of T (unscaled), double-buffered by k parity
-  T row[2][64];  // row k of Y
-  T piv[2];
-  T dd[64];
-  int bad;
-};
-
-// Factor the 64 x 64 diagonal block of M at (r0, r0) (chunk-major, lower part meaningful) in place and
-// write its inverse to Dg.  256 threads.  Owner layout: thread (ty, tx) keeps T(ty + 16 a, tx + 16 c)
-// and Y(ty + 16 a, tx + 16 c) in registers.  Elimination on [T | Y] without scaling: after step k
-// column k of T is final (= L[:,k] * L[k][k]) and row k of Y is final (= (L^-1)[k,:] * L[k][k]).
-// Per step only column k of T, row k of Y and the pivot travel through LDS (one barrier per step).
-// A pivot d is accepted when d > piv_tol * (the matrix's own diagonal entry before any update), i.e.
-// when the feature keeps more than piv_tol of its variance after regressing on the earlier ones.
-template <typename T>
-__device__ __forceinline__ void eliminate_block64(T* __restrict__ M, int p_pad, int r0, T* __restrict__ Dg,
-                                                  const double* __restrict__ diag0, double piv_tol,
-                                                  int32_t* __restrict__ info, ElimScratch<T>* sc, int tid,
-                                                  const bool active = true) {
-  // workgroups larger than 256 threads: the extra threads only keep the barriers company
-  const int ty = active ? tid >> 4 : 0, tx = active ? tid & 15 : 0;
-  T Tm[4][4], Y[4][4];
-  if (tid == 0) sc->bad = 0;
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int row = ty + 16 * a, col = tx + 16 * c;
-      Tm[a][c] = (col <= row && active) ? M[cm_off(p_pad, r0 + row, r0 + col)] : (T)0;
-      Y[a][c] = (row == col) ? (T)1 : (T)0;
-    }
-
-#pragma unroll
-  for (int kc = 0; kc < 4; ++kc) {
-#pragma unroll 1
-    for (int kk = 0; kk < 16; ++kk) {
-      const int k = 16 * kc + kk;
-      const int buf = k & 1;
-      if (tx == kk && active) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) sc->col[buf][ty + 16 * a] = Tm[a][kc];
-      }
-      if (ty == kk && active) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) sc->row[buf][tx + 16 * c] = Y[kc][c];
-        if (tx == kk) sc->piv[buf] = Tm[kc][kc];
-      }
-      __syncthreads();
-      T d = sc->piv[buf];
-      if (!((double)d > piv_tol * diag0[r0 + k])) {  // numerically not positive definite (or NaN): flag it, go on
-        d = (T)1;
-        if (tid == 0) sc->bad = 1;
-      }
-      if (tid == 0) sc->dd[k] = d;
-      const T invd = (T)1 / d;
-      T cj[4], rc[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        cj[c] = sc->col[buf][tx + 16 * c];
-        rc[c] = sc->row[buf][tx + 16 * c];
-      }
-      // kc is a compile-time constant here: row groups a < kc are finished (i <= k), column
-      // groups c < kc only carry Y updates (j <= k), column groups c > kc only T updates (j > k)
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        if (a < kc) continue;
-        const int i = ty + 16 * a;
-        const T f = (i > k) ? sc->col[buf][i] * invd : (T)0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int j = tx + 16 * c;
-          if (c < kc) {
-            Y[a][c] -= f * rc[c];
-          } else if (c > kc) {
-            if (c <= a && j <= i) Tm[a][c] -= f * cj[c];
-          } else {
-            if (j > k && j <= i) Tm[a][c] -= f * cj[c];
-            if (j <= k) Y[a][c] -= f * rc[c];
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (tid < 64) sc->dd[tid] = (T)1 / sqrt(sc->dd[tid]);  // now holds 1 / L[k][k]
-  __syncthreads();
-
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int row = ty + 16 * a, col = tx + 16 * c;
-      T lv = (T)0, xv = (T)0;
-      if (col < row) lv = Tm[a][c] * sc->dd[col];
-      if (col == row) lv = (T)1 / sc->dd[col];
-      if (col <= row) xv = Y[a][c] * sc->dd[row];
-      if (active) {
-        M[cm_off(p_pad, r0 + row, r0 + col)] = lv;
-        Dg[row * 64 + col] = xv;
-      }
-    }
-  if (tid == 0 && sc->bad) atomicOr(&info[0], 1);
-}
-
-// Stand-alone launch: only block 0 needs it (later diagonal blocks are factored by the panel
-// workgroup that applied their last update).
-template <typename T>
-__global__ __launch_bounds__(256, 2) void chol_diag_kernel(T* __restrict__ A, T* __restrict__ Dinv,
-                                                           const double* __restrict__ diag0, double piv_tol,
-                                                           int32_t* __restrict__ info, int p_pad, int J,
-                                                           int nblk) {
-  __shared__ ElimScratch<T> sc;
-  const int mt = blockIdx.x;
-  T* M = A + (int64_t)mt * p_pad * p_pad;
-  eliminate_block64<T>(M, p_pad, J * NB, Dinv + ((int64_t)mt * nblk + J) * 4096, diag0 + (int64_t)mt * p_pad,
-                       piv_tol, info, &sc, threadIdx.x);
-}
-
-hipError_t launch_chol_diag(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
-                            int J, int n_mats, int f32, hipStream_t st) {
-  if (p_pad % NB != 0 || J < 0 || J >= p_pad / NB || n_mats < 1) return hipErrorInvalidValue;
-  if (f32)
-    hipLaunchKernelGGL(chol_diag_kernel<float>, dim3(n_mats), dim3(256), 0, st, (float*)A, (float*)Dinv, diag0,
-                       piv_tol, info, p_pad, J, p_pad / NB);
-  else
-    hipLaunchKernelGGL(chol_diag_kernel<double>, dim3(n_mats), dim3(256), 0, st, (double*)A, (double*)Dinv,
-                       diag0, piv_tol, info, p_pad, J, p_pad / NB);
-  return hipGetLastError();
-}
-
-// The accumulators hold -C^T: they start at -A[I,J]^T (each wave stages its own 32 rows through
-// its slice of the output buffer, coalesced, no workgroup barrier) and collect +L[J,K] L[I,K]^T.
-// -C^T is exactly the B operand of (L_JJ^-1) * C^T: no LDS round trip between the two products.
-template <typename T>
-__global__ __launch_bounds__(256, 3) void chol_panel_kernel(T* __restrict__ A, T* __restrict__ Dinv,
-                                                            const double* __restrict__ diag0, double piv_tol,
-                                                            int32_t* __restrict__ info, int p_pad, int J,
-                                                            int nblk, int flags) {
-  typedef typename Tr<T>::acc_t acc_t;
-  typedef typename Tr<T>::vec_t vec_t;
-  constexpr int VE = Tr<T>::VE;
-  // LDS (fp64: 52,224 B, so that three workgroups fit one CU).  Region A holds the two operand tiles
-  // of the main loop and, after it, L_JJ^-1; region B is the output / update staging tile.
-  __shared__ __attribute__((aligned(16))) T s_a[64 * DI_LD];
-  __shared__ __attribute__((aligned(16))) T s_b[128 * RK_LD];
-  static_assert(64 * DI_LD >= 64 * RK_LD + 128 * RK_LD, "operand tiles must fit region A");
-  static_assert(sizeof(ElimScratch<T>) <= sizeof(T) * 64 * DI_LD, "elimination scratch must fit region A");
-  T* const s_rkj = s_a;
-  T* const s_rki = s_a + 64 * RK_LD;
-  T* const s_dinv = s_a;
-  T* const s_out = s_b;
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  // x = matrix (fastest in dispatch order), y = row tile: the tile-0 workgroups, which also factor
-  // the next diagonal block, start first
-  const int mt = blockIdx.x;
-  const int tile = blockIdx.y;
-  T* M = A + (int64_t)mt * p_pad * p_pad;
-  const int J0 = J * NB;
-  const int I0 = J0 + NB + tile * 128;
-  const int rows_valid = min(128, p_pad - I0);
-
-  // chunk-major: rows J0.. / I0.. of k-chunk c are contiguous blocks, one chunk = p_pad * 16 elements
-  const T* srcJ = M + cm_off(p_pad, J0, 0);
-  const T* srcI = M + cm_off(p_pad, I0, 0);
-  const int64_t chunk = (int64_t)p_pad * 16;
-
-  const int nch = J0 / KCH;
-  RKRegs<T, 64> rj = {};
-  RKRegs<T, 128> ri = {};
-  if (nch > 0) {
-    rk_load<T, 64>(rj, srcJ, CM_LD, tid, 64);
-    rk_load<T, 128>(ri, srcI, CM_LD, tid, rows_valid);
-  }
-
-  // acc[x][y][r] <-> (column j = 16 x + acc_row(l4, r) of block J, row i = 32 w + 16 y + l15 of the tile)
-  acc_t acc[4][2];
-  {
-    constexpr int VPR = 16 / VE;        // 16-byte vectors per 16-column row piece
-    constexpr int RPI = 64 / VPR;       // rows per wave instruction: 8 (fp64) / 16 (fp32)
-    constexpr int NQ = 32 / RPI;        // passes over the wave's 32 rows
-    const int rr = lane / VPR, ch = lane % VPR;
-    vec_t t[4][NQ];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int i = 32 * w + rr + RPI * q;
-        t[x][q] = (i < rows_valid)
-                      ? *reinterpret_cast<const vec_t*>(M + cm_off(p_pad, I0 + i, J0 + 16 * x + VE * ch))
-                      : Tr<T>::vzero();
-      }
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) Tr<T>::lds_store(s_out + (32 * w + rr + RPI * q) * RK_LD + VE * ch, t[x][q]);
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc[x][y][r] = -s_out[(32 * w + 16 * y + l15) * RK_LD + Tr<T>::acc_row(l4, r)];
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-
-  for (int c = 0; c < nch; ++c) {
-    __syncthreads();
-    rk_store<T, 64>(rj, s_rkj, tid);
-    rk_store<T, 128>(ri, s_rki, tid);
-    __syncthreads();
-    if (c + 1 < nch) {
-      rk_load<T, 64>(rj, srcJ + (c + 1) * chunk, CM_LD, tid, 64);
-      rk_load<T, 128>(ri, srcI + (c + 1) * chunk, CM_LD, tid, rows_valid);
-    }
-    if (32 * w >= rows_valid) continue;  // half tile at the bottom: this wave's rows do not exist
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      T av[4], bv[2];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) av[x] = s_rkj[(16 * x + l15) * RK_LD + 4 * kk + l4];
-#pragma unroll
-      for (int y = 0; y < 2; ++y) bv[y] = s_rki[(32 * w + 16 * y + l15) * RK_LD + 4 * kk + l4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
-    }
-  }
-
-  __syncthreads();  // every wave is done with the operand tiles that L_JJ^-1 now overwrites
-  load_block64<T>(s_dinv, Dinv + ((int64_t)mt * nblk + J) * 4096, tid);
-  __syncthreads();
-
-  // out^T[j'][i] = sum_k Dinv[j'][k] C[i][k] = sum_k (-Dinv[j'][k]) acc[k][i]
-  // (Dinv lower triangular: k-blocks above j' vanish)
-  acc_t outv[4][2];
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 2; ++y) outv[x][y] = Tr<T>::zero();
-  if (32 * w < rows_valid) {
-#pragma unroll
-    for (int xp = 0; xp < 4; ++xp)
-#pragma unroll
-      for (int x = 0; x <= xp; ++x)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const T av = -s_dinv[(16 * xp + l15) * DI_LD + 16 * x + Tr<T>::acc_row(l4, r)];
-#pragma unroll
-          for (int y = 0; y < 2; ++y) outv[xp][y] = Tr<T>::mfma(av, acc[x][y][r], outv[xp][y]);
-        }
-  }
-
-  // Store through the output buffer (contiguous row pieces) and, while each 16-column chunk of
-  // L[I,J] is in LDS in operand layout, accumulate the symmetric updates of the tile's own two
-  // diagonal blocks (lower tiles only).  Wave w -> sub-block sb = w >> 1; the 10 lower tiles of a
-  // sub-block are split 5 / 5: tile rows {0, 3} for even waves, {1, 2} for odd ones.
-  acc_t upd[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) upd[a][b] = Tr<T>::zero();
-  const int sb = w >> 1;
-  const int t1[2] = {(w & 1) ? 1 : 0, (w & 1) ? 2 : 3};
-#pragma unroll
-  for (int xp = 0; xp < 4; ++xp) {
-    __syncthreads();
-#pragma unroll
-    for (int y = 0; y < 2; ++y)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        s_out[(32 * w + 16 * y + l15) * RK_LD + Tr<T>::acc_row(l4, r)] = outv[xp][y][r];
-    __syncthreads();
-    {
-      typedef RKRegs<T, 128> RR;
-      const int c = tid % RR::VPR, row = tid / RR::VPR;
-#pragma unroll
-      for (int q = 0; q < RR::NP; ++q) {
-        const int rr = row + RR::RPP * q;
-        if (rr < rows_valid)
-          *reinterpret_cast<vec_t*>(M + cm_off(p_pad, I0 + rr, J0 + 16 * xp + VE * c)) =
-              Tr<T>::lds_load(s_out + rr * RK_LD + VE * c);
-      }
-    }
-    if (64 * sb >= rows_valid) continue;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      T av[2], bv[4];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) av[a] = s_out[(64 * sb + 16 * t1[a] + l15) * RK_LD + 4 * kk + l4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) bv[b] = s_out[(64 * sb + 16 * b + l15) * RK_LD + 4 * kk + l4];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          if (b <= t1[a]) upd[a][b] = Tr<T>::mfma(av[a], bv[b], upd[a][b]);  // wave-uniform condition
-    }
-  }
-  // A[I',I'] -= L[I',J] L[I',J]^T on the sub-block's diagonal tile (owned by this workgroup alone)
-  if (64 * sb < rows_valid) {
-    const int d0 = I0 + 64 * sb;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (b > t1[a]) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * t1[a] + Tr<T>::acc_row(l4, r), col = 16 * b + l15;
-          if (col <= row) M[cm_off(p_pad, d0 + row, d0 + col)] -= upd[a][b][r];
-        }
-      }
-  }
-
-  // Tile 0 starts at block row J + 1: its first diagonal block has just received its last update,
-  // so this workgroup factors it right away (no separate launch, and the latency-bound sweep
-  // overlaps with the other workgroups' MFMA work).
-  if (tile == 0 && !(flags & 2)) {
-    __threadfence_block();
-    __syncthreads();  // the update above was written by waves 0 and 1; region A is free again
-    eliminate_block64<T>(M, p_pad, I0, Dinv + ((int64_t)mt * nblk + J + 1) * 4096,
-                         diag0 + (int64_t)mt * p_pad, piv_tol, info, reinterpret_cast<ElimScratch<T>*>(s_a), tid);
-  }
-}
-
-hipError_t launch_chol_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
-                             int J, int n_mats, int flags, int f32, hipStream_t st) {
-  const int nblk = p_pad / NB;
-  if (p_pad % NB != 0 || J < 0 || J >= nblk - 1 || n_mats < 1) return hipErrorInvalidValue;
-  const int rows_below = p_pad - (J + 1) * NB;
-  dim3 grid(n_mats, (rows_below + 127) / 128);
-  if (f32)
-    hipLaunchKernelGGL(chol_panel_kernel<float>, grid, dim3(256), 0, st, (float*)A, (float*)Dinv, diag0, piv_tol,
-                       info, p_pad, J, nblk, flags);
-  else
-    hipLaunchKernelGGL(chol_panel_kernel<double>, grid, dim3(256), 0, st, (double*)A, (double*)Dinv, diag0,
-                       piv_tol, info, p_pad, J, nblk, flags);
-  return hipGetLastError();
-}
-
-// =====================================================================================
-// strip:  V = L^-1 * RHS for one 128-column strip of the right-hand side, walking the
-// 64-row blocks top to bottom:  V[I] = L_II^-1 ( RHS[I] - sum_{K<I} L[I,K] V[K] ).
-//   tri  : RHS = L_t (Cholesky factor of the permuted test Gram), lower triangular, so a
-//          strip starts at its own diagonal block.
-//   rect : RHS = rows perm[i] of Ft (p x m, fp64), a plain row gather.
-// Strips are independent: no inter-workgroup traffic.
-// =====================================================================================
-template <typename T>
-__global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
-  typedef typename Tr<T>::acc_t acc_t;
-  typedef typename Tr<T>::vec_t vec_t;
-  constexpr int VE = Tr<T>::VE;
-  __shared__ __attribute__((aligned(16))) T s_rk[64 * RK_LD];
-  __shared__ __attribute__((aligned(16))) T s_kc[16 * KC_LD];
-  __shared__ __attribute__((aligned(16))) T s_dinv[64 * DI_LD];
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  // x = ordering (fastest in dispatch order), y = strip: in tri mode strip 0 is the longest, so
-  // the long workgroups start first and the short ones fill the tail
-  const int ord = blockIdx.x;
-  const int c0 = blockIdx.y * 128;
-  const int p = a.p, p_pad = a.p_pad, m_pad = a.m_pad;
-  const int nblk = p_pad / NB;
-  const int n_iblk = (p + NB - 1) / NB;
-  const int64_t ldv = ldv_of(m_pad);
-  const int64_t chunk = (int64_t)p_pad * 16;
-  const T* L = static_cast<const T*>(a.A) + (int64_t)ord * p_pad * p_pad;   // chunk-major
-  const T* Lt = a.tri ? static_cast<const T*>(a.rhs) + (int64_t)ord * p_pad * p_pad : nullptr;
-  const int32_t* perm = a.tri ? nullptr : a.perms + (int64_t)ord * p;
-  T* V = static_cast<T*>(a.V) + (int64_t)ord * v_rows_of(p) * ldv;
-  const T* Dv = static_cast<const T*>(a.Dinv) + (int64_t)ord * nblk * 4096;
-
-  const int ib0 = a.tri ? c0 / NB : 0;
-  const int kstart = a.tri ? c0 : 0;
-  if (a.tri) {
-    // rows above the strip's first diagonal block are structurally zero; later kernels read them
-    constexpr int VPR = 128 / VE;
-    for (int idx = tid; idx < ib0 * NB * VPR; idx += 256) {
-      const int row = idx / VPR, cv = idx % VPR;
-      *reinterpret_cast<vec_t*>(V + row * ldv + c0 + VE * cv) = Tr<T>::vzero();
-    }
-  }
-
-  for (int ib = ib0; ib < n_iblk; ++ib) {
-    const int I0 = ib * NB;
-    acc_t acc[4][2];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y) acc[x][y] = Tr<T>::zero();
-
-    const T* srcL = L + cm_off(p_pad, I0, kstart);
-    const T* srcV = V + kstart * ldv + c0;
-    const int nch = (I0 - kstart) / KCH;
-    RKRegs<T, 64> rl = {};
-    KCRegs<T> rv = {};
-    if (nch > 0) {
-      rk_load<T, 64>(rl, srcL, CM_LD, tid, 64);
-      kc_load<T>(rv, srcV, ldv, tid);
-    }
-    for (int c = 0; c < nch; ++c) {
-      __syncthreads();
-      rk_store<T, 64>(rl, s_rk, tid);
-      kc_store<T>(rv, s_kc, tid);
-      __syncthreads();
-      if (c + 1 < nch) {
-        rk_load<T, 64>(rl, srcL + (c + 1) * chunk, CM_LD, tid, 64);
-        kc_load<T>(rv, srcV + (c + 1) * KCH * ldv, ldv, tid);
-      }
-      // tri: V[k][c] = 0 for c > k, so columns c0+64.. (waves 2, 3) see only zeros while k < c0+64
-      if (a.tri && w >= 2 && c < 4 && !(a.flags & 1)) continue;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        T av[4], bv[2];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) av[x] = s_rk[(16 * x + l15) * RK_LD + 4 * kk + l4];
-#pragma unroll
-        for (int y = 0; y < 2; ++y) bv[y] = s_kc[(4 * kk + l4) * KC_LD + 32 * w + 16 * y + l15];
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-          for (int y = 0; y < 2; ++y) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
-      }
-    }
-
-    __syncthreads();  // s_dinv is still being read by slower waves of the previous block
-    load_block64<T>(s_dinv, Dv + (int64_t)ib * 4096, tid);
-
-    // C = RHS[I] - acc  (direct global reads: 16 lanes cover one contiguous row segment)
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = I0 + 16 * x + Tr<T>::acc_row(l4, r);
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-          const int c = c0 + 32 * w + 16 * y + l15;
-          T rv0 = (T)0;
-          if (a.tri) {
-            if (c < I0 + NB) rv0 = Lt[cm_off(p_pad, i, c)];
-          } else {
-            if (i < p) rv0 = (T)a.Ft[(int64_t)perm[i] * m_pad + c];
-          }
-          acc[x][y][r] = rv0 - acc[x][y][r];
-        }
-      }
-    __syncthreads();
-
-    acc_t outv[4][2];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y) outv[x][y] = Tr<T>::zero();
-#pragma unroll
-    for (int xp = 0; xp < 4; ++xp)
-#pragma unroll
-      for (int x = 0; x <= xp; ++x)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const T av = s_dinv[(16 * xp + l15) * DI_LD + 16 * x + Tr<T>::acc_row(l4, r)];
-#pragma unroll
-          for (int y = 0; y < 2; ++y) outv[xp][y] = Tr<T>::mfma(av, acc[x][y][r], outv[xp][y]);
-        }
-
-#pragma unroll
-    for (int xp = 0; xp < 4; ++xp)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = I0 + 16 * xp + Tr<T>::acc_row(l4, r);
-#pragma unroll
-        for (int y = 0; y < 2; ++y) V[i * ldv + c0 + 32 * w + 16 * y + l15] = outv[xp][y][r];
-      }
-    // the next block's k-loop reads these rows back (written by other waves of this workgroup)
-    __threadfence_block();
-    __syncthreads();
-  }
-}
-
 // copy the 64 x 64 block at (r0, c0) of a chunk-major matrix into LDS with stride DI_LD, 256 threads;
 // neg != 0 stores the negated block
 template <typename T, int NT = 256>
@@ -682,17 +184,26 @@ __device__ __forceinline__ void load_block64_cm(T* lds, const T* __restrict__ A,
 }
 
 // =====================================================================================
-// Two-level factorisation: panels of TWO block columns (128 wide).
+// Blocked Cholesky  G_pi = L L^T  of the per-ordering work matrices, panels of TWO 64-wide block columns
+// (128 wide), left-looking:
 //   chol_panel2, step Jo : for a 128-row tile I below the panel, one k-loop over the columns left of
 //        the panel accumulates  C = A[I, J:J+2] - sum_{K<J} L[I,K] L[J:J+2,K]^T  for both block
-//        columns at once (16 flop per operand byte instead of 10.7), then, on the accumulators,
+//        columns at once (16 flop per operand byte), then, on the accumulators,
 //            X1 = C1 L11^-T ;  C2 -= X1 L21^T ;  X2 = C2 L22^-T
-//        (transposed, as in the one-level kernel: the accumulators are the B operand), then the
-//        symmetric update of the tile's own 128 x 128 diagonal block while L[I, J:J+2] passes
-//        through LDS for its store.  Tile 0 -- the next panel's diagonal block -- then factors it.
+//        (transposed: the accumulators are the B operand of the next product).  Tile 0 -- the next
+//        panel's diagonal block -- then applies the whole row panel to its diagonal block and factors it.
 //   factor_diag128 : L11, L11^-1 by the carried-identity elimination; L21 = A21 L11^-T and
 //        A22 -= L21 L21^T on the matrix pipe; L22, L22^-1 by the elimination again.
-// Half as many dependent launches as the one-level scheme, two thirds of its operand traffic.
+//   X tiles (round 4, tri mode): V^T = L_t^T L^-T  (V = L^-1 L_t, the quantity the lift scan walks) is computed
+//        as EXTRA BLOCK ROWS of the training factorisation.  With B = L_t^T stacked under G_pi the panel step
+//            X[:, J] = ( B[:, J] - sum_{K<J} X[:, K] L[J, K]^T ) L[J, J]^-T
+//        is the tile body above, with three differences: the tile starts from -B[I', J] = -L_t[J, I']^T (read straight
+//        into accumulator layout: no transposition), its k-loop starts at the tile's own row block (X is upper
+//        triangular: X[I', K] = 0 for K < I'), and there is no diagonal block to update.  Tile (I', J) needs
+//        L_t[J, I'] (final after launch J - 1), L[J, 0:J) and Dinv_J (what the L tiles of launch J need): it runs in
+//        launch J, next to them, sharing the panel-row operand through the L2; launch p_pad/128 - 1 has X tiles only.
+//        This replaces the strip kernel (a workgroup walking a 128-column strip of V top-down, eight dependent solve
+//        epilogues in a row) in tri mode.
 // =====================================================================================
 // lower tiles (ti >= tj) of the 8 x 8 grid of 16 x 16 tiles of a 128 x 128 block, row by row; wave w owns 9 of them.
 // The (ti, tj) of tile t come out of two packed constants (3 bits an entry) with scalar shifts: as a table in
@@ -780,7 +291,10 @@ __device__ long long g_stamps[32];
 // Phase stamps of the panel kernel (tools/panel_probe.hip; compiled out of the library): 100 MHz wall clock at the
 // phase boundaries of a few workgroups spread over the grid, [workgroup slot][phase].
 #ifdef LSSPA_PANEL_STAMPS
-constexpr int PST_SLOTS = 64, PST_PHASES = 16;
+#ifndef LSSPA_PST_SLOTS
+#define LSSPA_PST_SLOTS 64
+#endif
+constexpr int PST_SLOTS = LSSPA_PST_SLOTS, PST_PHASES = 16;
 __device__ long long g_pstamps[PST_SLOTS * PST_PHASES];
 #define PSTAMP(i)                                                                                   \
   do {                                                                                              \
@@ -1094,15 +608,20 @@ __global__ __launch_bounds__(256, 2) void chol_diag2_kernel(T* __restrict__ A, T
                     diag0 + (int64_t)mt * p_pad, piv_tol, info, s_a, s_x, threadIdx.x);
 }
 
-// One 128 x 128 tile of panel step Jo of ONE matrix M (256 or 512 threads): the body shared by the one-launch-per-
-// panel-step kernel (chol_panel2_kernel: a workgroup per tile) and the whole-factorisation kernel
-// (chol_whole_kernel: a workgroup per matrix walks all its tiles).  Dm / diag0 are the matrix's own slices.
+// One 128 x 128 tile of panel step Jo (256 or 512 threads).  Two kinds, told apart by the workgroup-uniform `xt`:
+//   L tile  (xt == 0): rows I0 = J0 + 128 + 128 tile of the matrix M itself (MJ == M); tile 0 also updates and factors
+//                      the next diagonal block.
+//   X tile  (xt != 0): rows I0 = 128 tile of X = V^T, which lives in its own chunk-major buffer M; the panel rows, the
+//                      diagonal block's inverse (Dm) and L21 come from the ordering's TRAINING matrix MJ, the tile's
+//                      start from the factored TEST matrix Bt: -B[i][j] = -L_t[J0 + j][I0 + i].
+// Dm / diag0 are the slices of the matrix MJ.
 // s_a: >= 2 * 128 * RK_LD elements, s_b: >= 128 * RK_LD elements of LDS.
 template <typename T, int NT>
-__device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ Dm, const double* __restrict__ diag0,
+__device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restrict__ MJ, const T* __restrict__ Bt,
+                                            T* __restrict__ Dm, const double* __restrict__ diag0,
                                             double piv_tol, int32_t* __restrict__ info, const int p_pad, const int Jo,
-                                            const int tile, const int p_live, T* const s_a, T* const s_b,
-                                            const int tid) {
+                                            const int tile, const int xt, const int p_live, T* const s_a,
+                                            T* const s_b, const int tid) {
   typedef typename Tr<T>::acc_t acc_t;
   typedef typename Tr<T>::vec_t vec_t;
   constexpr int VE = Tr<T>::VE;
@@ -1111,10 +630,9 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
   constexpr int YT = RW / 16;          // 16-row accumulator tiles per wave and panel column block: 2 / 1
   constexpr int NU = (36 + NW - 1) / NW;   // diagonal-update tiles per wave: 9 / 5
   // Region A: the two 128 x 16 operand tiles of the main loop; afterwards the 64 x 64 blocks of the
-  // two-level solve and the elimination scratch.  Region B: output staging tile.
+  // two-level solve and the diagonal factorisation's block.  Region B: output staging tile.
   static_assert(2 * 128 * RK_LD >= 64 * DI_LD, "a 64 x 64 block must fit region A");
   static_assert(128 * RK_LD >= FB_SX_ELEMS, "the diagonal factorisation's side buffer must fit region B");
-  static_assert(sizeof(ElimScratch<T>) <= sizeof(T) * 64 * DI_LD, "elimination scratch must fit region A");
   T* const s_rkj = s_a;
   T* const s_rki = s_a + 128 * RK_LD;
   T* const s_dinv = s_a;
@@ -1123,12 +641,12 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
   const int lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int J0 = Jo * 128;
-  const int I0 = J0 + 128 + tile * 128;
+  const int I0 = xt ? tile * 128 : J0 + 128 + tile * 128;
   PSTAMP(0);
   // Rows at or beyond p_live (= p + 1 rounded up to 16) are identity padding: left of the diagonal they are exact
   // zeros before, during and after every update, so the 16-row accumulator tiles that consist of them only are
   // left out of every product -- the same bits with fewer instructions (p = 1000 pads to 1024: 1 tile in 64;
-  // p = 5000 to 5120: 7 in 320).
+  // p = 5000 to 5120: 7 in 320).  (X tiles: those rows of V^T belong to no feature; nobody reads them.)
   // Both counts are wave-uniform, and the compiler has to know it (the wave index comes out of threadIdx): a
   // condition it takes for divergent turns every product it guards into an exec-masked region of its own; as
   // scalars they are plain branches (measured: 4.08 -> 4.04 ms of panel time per C3 step).  A condition-free copy
@@ -1136,10 +654,15 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
   const int ws = __builtin_amdgcn_readfirstlane(w);
   const int ylive = min(YT, max(0, (p_live - (I0 + RW * ws) + 15) / 16));   // live 16-row tiles of this wave
 
-  const T* srcJ = M + cm_off(p_pad, J0, 0);
-  const T* srcI = M + cm_off(p_pad, I0, 0);
+  // k-loop range: an L tile sums over every column left of the panel; an X tile starts at its own row block
+  // (X[I', K] = 0 for K < I'), and inside that block wave ws's rows 32 ws .. are zero left of column 32 ws: its first
+  // 2 ws chunks add exact zeros and are left out (as the strip kernel did)
+  const int cb = xt ? I0 / KCH : 0;
+  const int nch = J0 / KCH - cb;
+  const int cskip = xt ? (RW / KCH) * ws : 0;
+  const T* srcJ = MJ + cm_off(p_pad, J0, KCH * cb);
+  const T* srcI = M + cm_off(p_pad, I0, KCH * cb);
   const int64_t chunk = (int64_t)p_pad * 16;
-  const int nch = J0 / KCH;
   RKRegs<T, 128, NT> rj = {}, ri = {};
   if (nch > 0) {
     rk_load_full<T, 128, NT>(rj, srcJ, CM_LD, tid);
@@ -1147,13 +670,30 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
   }
 
   // acc[x][y][r] <-> (panel column j = 16 x + acc_row(l4, r), tile row i = RW w + 16 y + l15); holds -C^T.
-  // (Round 3, measured and not kept: -A^T entering through the matrix pipe instead -- the tile's own eight chunks
-  // staged like the k-loop's operands and multiplied by -I, no transposition in front of the k-loop: 4.05 against
-  // 3.98 ms of panel time per C3 step in alternating processes on one box.)
-  // Each wave stages its own rows through its slice of the output buffer (coalesced reads, no
-  // workgroup barrier).
   acc_t acc[8][YT];
-  {
+  if (xt) {
+    // -B[i][j] = -L_t[J0 + j][I0 + i]: sixteen lanes read sixteen consecutive columns of one row of L_t (one 128-byte
+    // piece of a chunk): accumulator layout as it stands.  On the diagonal tile (I0 == J0) the entries above L_t's
+    // diagonal are not part of the factor (the upper right 64 x 64 block of a diagonal block is never written):
+    // unconditional loads, value selected afterwards.
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+#pragma unroll
+      for (int y = 0; y < YT; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = J0 + 16 * x + Tr<T>::acc_row(l4, r), col = I0 + RW * w + 16 * y + l15;
+          const T v = __builtin_nontemporal_load(Bt + cm_off(p_pad, row, col));
+          acc[x][y][r] = (row >= col) ? -v : (T)0;
+        }
+      if (x & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    // (Round 3, measured and not kept: -A^T entering through the matrix pipe instead -- the tile's own eight chunks
+    // staged like the k-loop's operands and multiplied by -I, no transposition in front of the k-loop: 4.05 against
+    // 3.98 ms of panel time per C3 step in alternating processes on one box.)
+    // Each wave stages its own rows through its slice of the output buffer (coalesced reads, no
+    // workgroup barrier).
     constexpr int VPR = 16 / VE;        // 16-byte vectors per 16-column row piece
     constexpr int RPI = 64 / VPR;       // rows per wave instruction: 8 (fp64) / 16 (fp32)
     constexpr int NQ = RW / RPI;        // passes over the wave's rows
@@ -1194,6 +734,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
       rk_load_full<T, 128, NT>(rj, srcJ + (c + 1) * chunk, CM_LD, tid);
       rk_load_full<T, 128, NT>(ri, srcI + (c + 1) * chunk, CM_LD, tid);
     }
+    if (c < cskip) continue;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       T av[8], bv[YT];
@@ -1246,7 +787,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
   block64_put<T, NT>(nb, s_dinv, tid);
   __syncthreads();
   PSTAMP(12);
-  block64_fetch_cm<T, NT>(nb, M, p_pad, J0 + NB, J0, tid);
+  block64_fetch_cm<T, NT>(nb, MJ, p_pad, J0 + NB, J0, tid);
   tri_mult(0);
   PSTAMP(13);
   __syncthreads();
@@ -1372,7 +913,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
       }
     }
   };
-  if (tile == 0)
+  if (tile == 0 && !xt)
   switch (ws) {     // scalar: the wave index
     case 0: diag_update(std::integral_constant<int, 0>()); break;
     case 1: diag_update(std::integral_constant<int, 1>()); break;
@@ -1388,7 +929,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
 
   // Tile 0 is the next panel's diagonal block and has just received its last update: factor it here,
   // the latency-bound sweep overlaps with the other workgroups' MFMA work.
-  if (tile == 0) {
+  if (tile == 0 && !xt) {
     __threadfence_block();
     __syncthreads();
     factor_diag128<T, NT>(M, p_pad, I0, Dm + (int64_t)(2 * (Jo + 1)) * 4096, diag0, piv_tol, info, s_a, s_b, tid);
@@ -1400,79 +941,78 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, T* __restrict__ D
 // for all 128 panel columns, i.e. 8 x YT accumulator tiles.
 // fp32, 256 threads: capped at 168 registers for a third workgroup per CU (as the fp32 strip kernel); fp64 needs all
 // 256 for its accumulators
+struct Panel2Args {
+  void* A;                 // [n_mats] chunk-major work matrices: training matrices first, then (tri) the test matrices
+  void* Dinv;              // [n_mats][nblk][64][64]
+  void* X;                 // [n_ord] chunk-major p_pad x p_pad, V^T (n_x > 0 only)
+  const double* diag0;
+  double piv_tol;
+  int32_t* info;
+  int p_pad, Jo, nblk, n_mats;
+  int n_ord;               // orderings = training matrices (X tiles: the test matrix of ordering o is matrix n_ord + o)
+  int n_lt;                // L tiles per matrix in this launch: p_pad / 128 - 1 - Jo (0 in the X-only last launch)
+  int n_x;                 // X tiles per ordering in this launch: Jo + 1, or 0 (rect mode / strip-kernel cross-check)
+  int grouped, p_live;
+};
+
 template <typename T, int NT>
-__global__ __launch_bounds__(NT, (sizeof(T) == 4 && NT == 256) ? 3 : NT / 128) void chol_panel2_kernel(T* __restrict__ A, T* __restrict__ Dinv,
-                                                                 const double* __restrict__ diag0,
-                                                                 double piv_tol, int32_t* __restrict__ info,
-                                                                 int p_pad, int Jo, int nblk, int n_mats,
-                                                                 int grouped, int p_live) {
+__global__ __launch_bounds__(NT, (sizeof(T) == 4 && NT == 256) ? 3 : NT / 128) void chol_panel2_kernel(Panel2Args a) {
   __shared__ __attribute__((aligned(16))) T s_a[2 * 128 * RK_LD];
   __shared__ __attribute__((aligned(16))) T s_b[128 * RK_LD];
-  // Dispatch order (1-D grid).  The tile-0 workgroups, which also factor the next diagonal block, come
-  // first, one per matrix.  The other tiles follow in groups of eight matrices: consecutive ids walk the
+  // Dispatch order (1-D grid).  The tile-0 workgroups, which also update and factor the next diagonal block, come
+  // first, one per matrix.  The other L tiles follow in groups of eight matrices: consecutive ids walk the
   // eight matrices (id % 8 = matrix % 8 = XCD, workgroups go round-robin over the XCDs), then the tiles,
   // so the tiles of one matrix run at about the same time on ONE XCD and share the panel-row operand
-  // L[J, 0:J0] through its L2 (worth ~1 %: the loop is not bound by that traffic).
-  int mt, tile;
+  // L[J, 0:J0] through its L2.  The X tiles come last, KIND BY KIND: tile 0 (the longest k-loop) of every ordering,
+  // then tile 1 of every ordering, ...  Workgroups of very different length must not alternate with a short period:
+  // the dispatcher hands workgroup n to XCD n % 8 and, inside the XCD, to its shader engines in turn, strictly in
+  // order -- a workgroup whose engine has no free slot holds up everything behind it.  With the eight X tiles of an
+  // ordering interleaved (period 64 = 8 XCDs x 8 kinds) each engine saw two kinds only, and the whole chip waited
+  // for the engine that held the long ones: 848 us for launch 7, its slots idle 40 % of the time
+  // (tools/xtile_probe.hip: tiles that ran 25 us were not replaced until 120 us).
+  const int n_mats = a.n_mats, n_ord = a.n_ord;
+  int mt, tile, xt = 0;
   {
     const int id = blockIdx.x;
-    if (id < n_mats || !grouped) {
-      mt = id % n_mats;
-      tile = id / n_mats;
-    } else {
-      const int n_tiles = gridDim.x / n_mats;
-      const int rem = id - n_mats, per = 8 * (n_tiles - 1);
-      const int g = rem / per, within = rem - g * per;
-      tile = 1 + within / 8;
-      mt = 8 * g + (within & 7);
+    const int n0 = a.n_lt > 0 ? n_mats : 0;
+    const int lt1 = a.n_lt > 0 ? a.n_lt - 1 : 0;      // L tiles of a matrix after its tile 0
+    const int n_l = n0 + n_mats * lt1;                // all L tiles
+    if (id < n0) {
+      mt = id;
+      tile = 0;
+    } else if (id < n_l) {
+      const int rem = id - n0;
+      if (a.grouped) {
+        const int per = 8 * lt1;
+        const int g = rem / per, within = rem - g * per;
+        tile = 1 + (within >> 3);
+        mt = 8 * g + (within & 7);
+      } else {
+        tile = 1 + rem / n_mats;
+        mt = rem % n_mats;
+      }
+    } else {            // X tile `tile` of ordering mt (= training matrix mt)
+      const int rem = id - n_l;
+      tile = rem / n_ord;
+      mt = rem - tile * n_ord;
+      xt = 1;
     }
   }
-  panel2_tile<T, NT>(A + (int64_t)mt * p_pad * p_pad, Dinv + (int64_t)mt * nblk * 4096, diag0 + (int64_t)mt * p_pad,
-                     piv_tol, info, p_pad, Jo, tile, p_live, s_a, s_b, threadIdx.x);
+  T* const A = static_cast<T*>(a.A);
+  const int64_t pp2 = (int64_t)a.p_pad * a.p_pad;
+  T* const MJ = A + (int64_t)mt * pp2;
+  T* const Dm = static_cast<T*>(a.Dinv) + (int64_t)mt * a.nblk * 4096;
+  const double* const d0 = a.diag0 + (int64_t)mt * a.p_pad;
+  if (xt)
+    panel2_tile<T, NT>(static_cast<T*>(a.X) + (int64_t)mt * pp2, MJ, A + (int64_t)(n_ord + mt) * pp2, Dm, d0,
+                       a.piv_tol, a.info, a.p_pad, a.Jo, tile, 1, a.p_live, s_a, s_b, threadIdx.x);
+  else
+    panel2_tile<T, NT>(MJ, MJ, MJ, Dm, d0, a.piv_tol, a.info, a.p_pad, a.Jo, tile, 0, a.p_live, s_a, s_b,
+                       threadIdx.x);
 }
 
-// The whole factorisation of one matrix by ONE workgroup (grid = matrices): the leading diagonal block, then panel
-// step by panel step every tile below it, in the order the one-launch-per-step scheme runs them -- the same
-// arithmetic on the same operands, hence the same bits (tested).  An experiment of round 3, kept behind developer
-// flag 8192: the idea was that without a launch boundary per panel step the two workgroups of a CU drift apart, so
-// that one's epilogue and diagonal factorisation run under the other's k-loop, with one tail instead of seven.
-// Measured at the C3 shape (512 matrices of 1024^2, fp64): 4.38 ms against 4.03 ms for diagonal launch + seven panel
-// launches.  The launches with several rounds of workgroups are out of step after their first round anyway; what
-// this form loses is the sharing of the panel-row operand L[J, 0:J0] among the tiles of a matrix that run side by side
-// on one XCD (here a workgroup re-reads it for every tile, from beyond the L2), and the tile body inlined into the
-// loop nest spills (67 registers; called out of line it loses the address-space and uniformity knowledge instead).
-// Memory order: everything a tile reads of L was written by this same workgroup, on this CU, through its L1.
-template <typename T>
-__global__ __launch_bounds__(256, 2) void chol_whole_kernel(T* __restrict__ A, T* __restrict__ Dinv,
-                                                            const double* __restrict__ diag0, double piv_tol,
-                                                            int32_t* __restrict__ info, int p_pad, int nblk,
-                                                            int p_live) {
-  __shared__ __attribute__((aligned(16))) T s_a[2 * 128 * RK_LD];
-  __shared__ __attribute__((aligned(16))) T s_b[128 * RK_LD];
-  const int mt = blockIdx.x;
-  T* const M = A + (int64_t)mt * p_pad * p_pad;
-  T* const Dm = Dinv + (int64_t)mt * nblk * 4096;
-  const double* const d0 = diag0 + (int64_t)mt * p_pad;
-  factor_diag128<T, 256>(M, p_pad, 0, Dm, d0, piv_tol, info, s_a, s_b, threadIdx.x);
-  const int n_panel = p_pad / 128 - 1;
-#pragma unroll 1
-  for (int Jo = 0; Jo < n_panel; ++Jo) {
-#pragma unroll 1
-    for (int tile = 0; tile < n_panel - Jo; ++tile) {
-      __threadfence_block();   // the previous tile's (and the factorisation's) stores, before this tile's loads
-      __syncthreads();         // ... and its LDS reads, before this tile's LDS writes
-      // nothing the tile body derives from these may be hoisted out of the loops (it would spill far more)
-      T* Mi = M;
-      T* Di = Dm;
-      const double* di = d0;
-      int pp = p_pad, pl = p_live, t = threadIdx.x;
-      asm volatile("" : "+s"(Mi), "+s"(Di), "+s"(di), "+s"(pp), "+s"(pl), "+v"(t));
-      panel2_tile<T, 256>(Mi, Di, di, piv_tol, info, pp, Jo, tile, pl, s_a, s_b, t);
-    }
-  }
-}
-
-// whole factorisation of n_mats matrices: one diagonal launch + (p_pad / 128 - 1) panel launches
+// whole factorisation of n_mats matrices: one diagonal launch + (p_pad / 128 - 1) panel launches (+ one more, X tiles
+// only, when V^T is computed alongside)
 hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
                              int n_mats, int f32, hipStream_t st) {
   if (p_pad % 128 != 0 || n_mats < 1) return hipErrorInvalidValue;
@@ -1487,43 +1027,52 @@ hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double pi
 }
 
 hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
-                              int Jo, int n_mats, int f32, hipStream_t st, int flags, int p_live) {
+                              int Jo, int n_mats, int f32, hipStream_t st, int flags, int p_live, void* X,
+                              int n_ord) {
   if (p_live <= 0 || p_live > p_pad || (flags & 2048)) p_live = p_pad;   // flag 2048: no padding-tile skipping
-  if (p_pad % 128 != 0 || Jo < 0 || Jo >= p_pad / 128 - 1 || n_mats < 1) return hipErrorInvalidValue;
-  const int nblk = p_pad / NB;
-  const int n_tiles = p_pad / 128 - 1 - Jo;
-  dim3 grid(n_mats * n_tiles);
-  const int grouped = (n_mats % 8 == 0 && n_tiles > 1 && !(flags & 64)) ? 1 : 0;
+  const int n_panel = p_pad / 128 - 1;
+  // with X tiles (X != null) the matrices are [n_ord training][n_ord test] and there is one more launch, Jo = n_panel
+  if (p_pad % 128 != 0 || Jo < 0 || n_mats < 1 || Jo > n_panel || (Jo == n_panel && !X)) return hipErrorInvalidValue;
+  if (X && (n_ord < 1 || n_mats != 2 * n_ord)) return hipErrorInvalidValue;
+  Panel2Args a;
+  a.A = A;
+  a.Dinv = Dinv;
+  a.X = X;
+  a.diag0 = diag0;
+  a.piv_tol = piv_tol;
+  a.info = info;
+  a.p_pad = p_pad;
+  a.Jo = Jo;
+  a.nblk = p_pad / NB;
+  a.n_mats = n_mats;
+  a.n_ord = X ? n_ord : n_mats;
+  a.n_lt = n_panel - Jo;
+  a.n_x = X ? Jo + 1 : 0;
+  a.p_live = p_live;
+  const int64_t total = (int64_t)n_mats * a.n_lt + (int64_t)a.n_ord * a.n_x;
+  if (total < 1 || total > 0x7fffffff) return hipErrorInvalidValue;
+  a.grouped = (n_mats % 8 == 0 && a.n_lt > 1 && !(flags & 64)) ? 1 : 0;
+  const dim3 grid((unsigned)total);
   // 256 threads: 512-thread workgroups (16 rows per wave, twice the waves per SIMD) were measured
   // slower in both precisions -- the epilogue is bound by its memory traffic, not by latency
   if (f32)
-    hipLaunchKernelGGL((chol_panel2_kernel<float, 256>), grid, dim3(256), 0, st, (float*)A, (float*)Dinv, diag0,
-                       piv_tol, info, p_pad, Jo, nblk, n_mats, grouped, p_live);
+    hipLaunchKernelGGL((chol_panel2_kernel<float, 256>), grid, dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((chol_panel2_kernel<double, 256>), grid, dim3(256), 0, st, (double*)A, (double*)Dinv,
-                       diag0, piv_tol, info, p_pad, Jo, nblk, n_mats, grouped, p_live);
-  return hipGetLastError();
-}
-
-hipError_t launch_chol2_whole(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
-                              int n_mats, int f32, hipStream_t st, int p_live) {
-  if (p_live <= 0 || p_live > p_pad) p_live = p_pad;
-  if (p_pad % 128 != 0 || p_pad < 128 || n_mats < 1) return hipErrorInvalidValue;
-  const int nblk = p_pad / NB;
-  if (f32)
-    hipLaunchKernelGGL(chol_whole_kernel<float>, dim3(n_mats), dim3(256), 0, st, (float*)A, (float*)Dinv, diag0,
-                       piv_tol, info, p_pad, nblk, p_live);
-  else
-    hipLaunchKernelGGL(chol_whole_kernel<double>, dim3(n_mats), dim3(256), 0, st, (double*)A, (double*)Dinv, diag0,
-                       piv_tol, info, p_pad, nblk, p_live);
+    hipLaunchKernelGGL((chol_panel2_kernel<double, 256>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
 // =====================================================================================
-// strip2: the same solve  V = L^-1 RHS  by 128-column strips, advancing 128 ROWS per step.
-// The k-loop of a step covers both 64-row halves with one pass over the V rows above them, which
-// halves the re-reads of V (the larger share of the kernel's traffic: 16 flop per operand byte
-// instead of 10.7).  The step ends with a two-level triangular solve on the accumulators:
+// strip2:  V = L^-1 * RHS  by 128-column strips of the right-hand side, advancing 128 ROWS per step, top to bottom:
+//     V[I] = L_II^-1 ( RHS[I] - sum_{K<I} L[I,K] V[K] ).
+//   rect : RHS = rows perm[i] of Ft (p x m, fp64), a plain row gather -- the shipped path for M < p (the test Gram
+//          matrix is singular there, no test Cholesky).
+//   tri  : RHS = L_t (Cholesky factor of the permuted test Gram), lower triangular, so a strip starts at its own
+//          diagonal block.  Since round 4 tri mode computes V^T inside the panel launches (X tiles above); this
+//          kernel is then the independent cross-check (developer flag 128).
+// Strips are independent: no inter-workgroup traffic.  The k-loop of a step covers both 64-row halves with one pass
+// over the V rows above them (16 flop per operand byte).  The step ends with a two-level triangular solve on the
+// accumulators:
 //     X1 = Dinv_i C1 ;  C2 -= L[i+1][i] X1 ;  X2 = Dinv_{i+1} C2
 // in which X1, still in registers, is the B operand of the middle product.
 // =====================================================================================
@@ -1752,26 +1301,12 @@ hipError_t launch_strip(const StripArgs& a_in, hipStream_t st) {
   if (a.tri && a.m_pad > a.p_pad + 127) return hipErrorInvalidValue;
   if (a.tri ? (a.rhs == nullptr) : (a.perms == nullptr || a.Ft == nullptr)) return hipErrorInvalidValue;
   dim3 grid(a.n_ord, a.m_pad / 128);
-  if (a.flags & 4) {   // A/B switch: the one-level kernel
-    if (a.f32)
-      hipLaunchKernelGGL(strip_kernel<float>, grid, dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL(strip_kernel<double>, grid, dim3(256), 0, st, a);
-  } else {
-    if (!(a.flags & 512)) {   // default: 128-column strips, 256 threads (flag: 256-column strips, 512 threads --
-                             // a third less L traffic, measured 5 % slower at p = 1000)
-      if (a.f32)
-        hipLaunchKernelGGL((strip2_kernel<float, 256>), grid, dim3(256), 0, st, a);
-      else
-        hipLaunchKernelGGL((strip2_kernel<double, 256>), grid, dim3(256), 0, st, a);
-    } else {
-      const dim3 wide(a.n_ord, (a.m_pad + 255) / 256);
-      if (a.f32)
-        hipLaunchKernelGGL((strip2_kernel<float, 512>), wide, dim3(512), 0, st, a);
-      else
-        hipLaunchKernelGGL((strip2_kernel<double, 512>), wide, dim3(512), 0, st, a);
-    }
-  }
+  // 128-column strips, 256 threads (256-column strips with 512 threads: a third less L traffic, measured 5 % slower at
+  // p = 1000 and 3 % faster at p = 5000 in fp32, rounds 1-2; dropped with the other unshipped variants in round 4)
+  if (a.f32)
+    hipLaunchKernelGGL((strip2_kernel<float, 256>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((strip2_kernel<double, 256>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -74,25 +74,20 @@ bool small_p_eligible(int p);
 size_t small_p_lds_bytes(int nb);
 hipError_t launch_small_p(const SmallArgs& a, hipStream_t st);
 
-// Blocked Cholesky.  diag0 / piv_tol: a pivot d counts as non-positive (LSSPA_INFO_NOT_PD) when
-// d <= piv_tol * diag0.  chol_diag factors diagonal block J stand-alone (only block 0 needs it);
-// panel step J computes L[I,J] for the tiles below and, unless flags & 2, its tile-0 workgroups
-// also factor diagonal block J + 1.
-hipError_t launch_chol_diag(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
-                            int J, int n_mats, int f32, hipStream_t st);
-// two-level scheme (128-wide panels, p_pad a multiple of 128): one diagonal launch, then Jo = 0 .. p_pad/128 - 2
+// Blocked Cholesky, 128-wide panels (p_pad a multiple of 128).  diag0 / piv_tol: a pivot d counts as non-positive
+// (LSSPA_INFO_NOT_PD) when d <= piv_tol * diag0.  One diagonal launch (block 0), then panel steps Jo = 0 ..
+// p_pad/128 - 2: step Jo computes L[I, Jo] for the tiles below and its tile-0 workgroups update and factor diagonal
+// block Jo + 1.
 hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
                              int n_mats, int f32, hipStream_t st);
 // p_live: rows at or beyond it are identity padding (p + 1 rounded up to 16; 0 = none known): their all-zero
-// accumulator tiles are left out of the products
+// accumulator tiles are left out of the products.
+// X != null (tri mode): the matrices are [n_ord training][n_ord test] and step Jo also computes block column Jo of
+// X = V^T = L_t^T L^-T ([n_ord] chunk-major p_pad x p_pad matrices, upper block triangle written) as extra tiles of
+// the training factorisation; there is then one more step, Jo = p_pad/128 - 1, with X tiles only.
 hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
-                              int Jo, int n_mats, int f32, hipStream_t st, int flags = 0, int p_live = 0);
-// the same factorisation in ONE launch: a workgroup per matrix runs the diagonal block and every panel tile of its
-// matrix (same results bit for bit); for batches with at least about two matrices per CU
-hipError_t launch_chol2_whole(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
-                              int n_mats, int f32, hipStream_t st, int p_live = 0);
-hipError_t launch_chol_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
-                             int J, int n_mats, int flags, int f32, hipStream_t st);
+                              int Jo, int n_mats, int f32, hipStream_t st, int flags = 0, int p_live = 0,
+                              void* X = nullptr, int n_ord = 0);
 
 struct StripArgs {
   const void* A;           // factored train matrices
@@ -113,7 +108,8 @@ struct LiftArgs {
   const void* A;           // factored train matrices (row p holds z)
   const void* At;          // tri: factored test matrices (row p holds y-tilde); rect: null
   const double* ytil;      // rect: [m_pad]
-  const void* V;
+  const void* V;           // vt == 0: V row-major [v_rows][m_pad + 32]; vt != 0: V^T chunk-major p_pad x p_pad (tri)
+  int vt = 0;
   const int32_t* perms;    // [n_ord][p]
   double* Ppart;           // [n_ord][m_pad/64][p_pad]
   double* lifts;           // [n_samples][p]

@@ -127,9 +127,9 @@ struct lsspa_ctx {
   bool general_path_once = false;   // set while the factors themselves are wanted (full_fit, get_factors, debug_factor)
   int fail_alloc_in = 0;   // test hook (lsspa_debug_fail_alloc): the n-th device allocation from now fails
 
-  // host seconds of the last reduction's parts (lsspa_reduce_timing): page-locking, streamed copies + Gram kernels,
-  // un-locking, finalize (scaling, Cholesky-side set-up of the statistics, sync)
-  double red_pin_s = 0.0, red_stream_s = 0.0, red_unpin_s = 0.0, red_finalize_s = 0.0;
+  // host seconds of the last reduction's parts (lsspa_reduce_timing): streamed copies + Gram kernels, finalize
+  // (scaling, Cholesky-side set-up of the statistics, sync)
+  double red_stream_s = 0.0, red_finalize_s = 0.0;
 
   // profiling
   bool prof_on = false;
@@ -383,12 +383,22 @@ int hist_append(lsspa_ctx* ctx, const double* src, int64_t rows, hipMemcpyKind k
   return LSSPA_OK;
 }
 
+// elements of one ordering's V buffer: V row-major (strip kernel) or, in tri mode, V^T as a chunk-major p_pad x p_pad
+// matrix (X tiles of the panel launches) -- room for either, so that developer flag 128 can switch between them
+size_t v_elems_per_ordering(const lsspa_ctx* ctx) {
+  const size_t rowmajor = (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad);
+  const size_t pp = ctx->p_pad;
+  return ctx->tri ? std::max(rowmajor, pp * pp) : rowmajor;
+}
+
+// tri mode computes V^T inside the panel launches; rect mode (and developer flag 128) uses the strip kernel
+static inline bool vt_path(const lsspa_ctx* ctx) { return ctx->tri && !(ctx->flags & 128); }
+
 size_t bytes_per_ordering(const lsspa_ctx* ctx) {
-  const size_t pp = ctx->p_pad, nblk = pp / NB, n_iblk = (ctx->p + NB - 1) / NB;
+  const size_t pp = ctx->p_pad, nblk = pp / NB;
   const size_t nm = ctx->tri ? 2 : 1;
-  (void)n_iblk;
   const size_t es = ctx->esz();
-  return nm * pp * pp * es + (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad) * es +
+  return nm * pp * pp * es + v_elems_per_ordering(ctx) * es +
          nm * nblk * 4096 * es + nm * pp * 8 +
          (size_t)(ctx->m_pad / 64) * pp * 8 + (size_t)ctx->p * 8;
 }
@@ -422,7 +432,7 @@ int ensure_workspace(lsspa_ctx* ctx, Lane& L, int want_ord, int want_samples) {
       const size_t nm = ctx->tri ? 2 : 1;
       const size_t es = ctx->esz();
       TRY(dev_alloc(ctx, L.A, nm * cap * pp * pp * es));
-      TRY(dev_alloc(ctx, L.V, (size_t)cap * (size_t)v_rows_of(ctx->p) * (size_t)ldv_of(ctx->m_pad) * es));
+      TRY(dev_alloc(ctx, L.V, (size_t)cap * v_elems_per_ordering(ctx) * es));
       TRY(dev_alloc(ctx, L.Dinv, nm * cap * nblk * 4096 * es));
       TRY(dev_alloc(ctx, L.diag0, nm * cap * pp));
       TRY(dev_alloc(ctx, L.Ppart, (size_t)cap * (ctx->m_pad / 64) * pp));
@@ -479,7 +489,8 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
   char* const A_s = L.A.ptr + (size_t)ord_off * n_src * pp2 * es;
   char* const Dinv_s = L.Dinv.ptr + (size_t)ord_off * n_src * nblk * 4096 * es;
   double* const diag0_s = L.diag0.ptr + (size_t)ord_off * n_src * p_pad;
-  char* const V_s = L.V.ptr + (size_t)ord_off * (size_t)v_rows_of(p) * (size_t)ldv_of(m_pad) * es;
+  char* const V_s = L.V.ptr + (size_t)ord_off * v_elems_per_ordering(ctx) * es;
+  const bool vt = vt_path(ctx);   // V^T by the panel launches' X tiles instead of the strip kernel
   double* const Ppart_s = L.Ppart.ptr + (size_t)ord_off * (m_pad / 64) * p_pad;
   const int32_t* const perms_s = L.perms_cur + (size_t)ord_off * p;
   const bool timed = (st == ctx->lane_stream(L));   // the profiling events live on the lane's main stream
@@ -536,56 +547,28 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
     ga.paired = (per_sample == 2 && !(ctx->flags & 256)) ? 1 : 0;   // stage_and_run lays pairs out back to back
     HIPCHK(launch_gather(ga, st));
   }
-  const bool fused = !(ctx->flags & 2);  // panel step J also factors diagonal block J + 1
   // a pivot below ~p ulps of its feature's own variance is numerically zero (collinear feature)
   const double piv_tol = 16.0 * (double)p * (ctx->f32 ? 1.1920929e-07 : 2.220446049250313e-16);
-  // Developer flag 8192: the whole factorisation in ONE launch, a workgroup per matrix (chol_whole_kernel).  Same bits;
-  // measured slower at the C3 shape (4.38 against 4.03 ms for 512 matrices, round 3) and therefore not the default.
-  const bool whole = !(ctx->flags & (8 | 2)) && (ctx->flags & 8192);
-  if (whole) {
-    ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_PANEL, st);
-    HIPCHK(launch_chol2_whole(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, n_mats, ctx->f32, st,
-                              round_up(p + 1, 16)));
-    if (L.mid_armed && timed) {
+  {
+    ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_DIAG, st);
+    HIPCHK(launch_chol2_diag(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, n_mats, ctx->f32, st));
+  }
+  // panel steps; with vt one more (X tiles only): step Jo also computes block column Jo of V^T
+  const int n_panel = p_pad / 128 - 1;
+  for (int Jo = 0; Jo < n_panel + (vt ? 1 : 0); ++Jo) {
+    {
+      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_PANEL, st);
+      HIPCHK(launch_chol2_panel(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, Jo, n_mats, ctx->f32, st,
+                                ctx->flags, round_up(p + 1, 16), vt ? V_s : nullptr, n_ord));
+    }
+    // two lanes: the other lane's next batch may start once this one is about half done
+    if (L.mid_armed && timed && Jo == n_panel / 2) {
       HIPCHK(hipEventRecord(L.ev_mid, st));
       L.mid_valid = true;
       L.mid_armed = false;
     }
   }
-  if (!whole && !(ctx->flags & 8)) {
-    {
-      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_DIAG, st);
-      HIPCHK(launch_chol2_diag(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, n_mats,
-                               ctx->f32, st));
-    }
-    const int n_panel = p_pad / 128 - 1;
-    for (int Jo = 0; Jo < n_panel; ++Jo) {
-      {
-        ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_PANEL, st);
-        HIPCHK(launch_chol2_panel(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, Jo,
-                                  n_mats, ctx->f32, st, ctx->flags, round_up(p + 1, 16)));
-      }
-      // two lanes: the other lane's next batch may start once this one is about half done
-      if (L.mid_armed && timed && Jo == n_panel / 2) {
-        HIPCHK(hipEventRecord(L.ev_mid, st));
-        L.mid_valid = true;
-        L.mid_armed = false;
-      }
-    }
-  }
-  for (int J = 0; J < nblk && !whole && (ctx->flags & 8); ++J) {   // A/B switch: the one-level scheme
-    if (J == 0 || !fused) {
-      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_DIAG, st);
-      HIPCHK(launch_chol_diag(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, J,
-                              n_mats, ctx->f32, st));
-    }
-    if (J + 1 < nblk) {
-      ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_PANEL, st);
-      HIPCHK(launch_chol_panel(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, J,
-                               n_mats, ctx->flags, ctx->f32, st));
-    }
-  }
-  {
+  if (!vt) {
     ProfScope ps(timed ? ctx : nullptr, LSSPA_K_STRIP, st);
     StripArgs sa;
     sa.A = A_s;
@@ -613,6 +596,7 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
     la.f32 = ctx->f32;
     la.ytil = ctx->tri ? nullptr : ctx->ytil.ptr;
     la.V = V_s;
+    la.vt = vt ? 1 : 0;
     la.perms = perms_s;
     la.Ppart = Ppart_s;
     la.lifts = L.lifts.ptr + (size_t)s_off * p;
@@ -779,6 +763,19 @@ int lift_launch(lsspa_ctx* ctx, const int32_t* perms, int B, int per, Lane** out
   return LSSPA_OK;
 }
 
+// accumulate: 0 = lift vectors only, 1 = fold into the pending buffer, 2 = fold and merge at once.  2 is a one-GPU
+// short cut: refused while a batch is pending (its moments are about another mean) and on a context whose
+// communicator spans several ranks (the merge would use per-rank statistics).  Checked BEFORE anything is enqueued.
+int check_accumulate(lsspa_ctx* ctx, int accumulate) {
+  if (accumulate < 0 || accumulate > 2) return ctx->fail(LSSPA_ERR_ARG, "accumulate must be 0, 1 or 2");
+  if (accumulate == 2 && ctx->pend_dirty)
+    return ctx->fail(LSSPA_ERR_STATE, "accumulate = 2 (fold and merge at once) with a batch pending: merge it first");
+  if (accumulate == 2 && ctx->comm && comm_world(ctx->comm) > 1)
+    return ctx->fail(LSSPA_ERR_STATE, "accumulate = 2 (fold and merge at once) on a context with a multi-rank "
+                                      "communicator: the moments must be all-reduced before the merge");
+  return LSSPA_OK;
+}
+
 // Fold `count` samples of a launched batch, from sample `first` on, into the pending statistics (accumulate) and /
 // or copy their lift vectors out -- on the context's stream, in order.  The parts of a batch are taken front to
 // back; the lane is given back with the last one.
@@ -788,10 +785,9 @@ int lift_collect(lsspa_ctx* ctx, Lane& L, int first, int count, double* lifts_ou
   if (count <= 0) count = L.B - first;
   if (first != L.taken || count < 1 || first + count > L.B)
     return ctx->fail(LSSPA_ERR_ARG, "parts of a launched batch are collected front to back, without gaps");
+  TRY(check_accumulate(ctx, accumulate));   // before the stream is touched: a refused call leaves the lane as it was
   const double* src = L.lifts.ptr + (size_t)first * p;
   if (ctx->n_lanes == 2 && first == 0) HIPCHK(hipStreamWaitEvent(ctx->stream, L.ev_done, 0));
-  if (accumulate == 2 && ctx->pend_dirty)
-    return ctx->fail(LSSPA_ERR_STATE, "accumulate = 2 (fold and merge at once) with a batch pending: merge it first");
   if (accumulate == 2 && stats_small_fusable(count, p)) {
     // single GPU, small p: moments and merge in ONE launch; the advanced mean and n land in the other halves of the
     // pairs, which then become the current ones
@@ -1053,68 +1049,12 @@ static int gram_side(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, in
   return rc;
 }
 
-// Pin, in place, the part of a caller's host array that is the array's ALONE: the whole pages strictly inside
-// [base, base + bytes).  The first and the last page of an unaligned block are shared with whatever the
-// allocator put next to it (NumPy hands out malloc blocks: X and y of one call may share a page; so may a block
-// of another thread), and a page lock is not ours to take on their behalf -- those few KB go through the runtime's
-// ordinary staged copy.  Not pinned at all: blocks under 8 MB (the staged copy is as fast), memory the runtime
-// already knows (hipHostMalloc'ed or registered by the caller: it is DMA-able as it stands, and unregistering it
-// here would pull it from under its owner).  Returns an empty span when nothing was pinned.
-struct PinnedSpan {
-  const char* lo = nullptr;
-  const char* hi = nullptr;
-};
-
-static PinnedSpan pin_interior(const void* base, size_t bytes) {
-  PinnedSpan sp;
-  constexpr size_t PIN_FROM = (size_t)8 << 20;
-  if (!base || bytes < PIN_FROM) return sp;
-  long pg = sysconf(_SC_PAGESIZE);
-  if (pg <= 0) pg = 4096;
-  const uintptr_t b = reinterpret_cast<uintptr_t>(base);
-  const uintptr_t lo = (b + (uintptr_t)pg - 1) / (uintptr_t)pg * (uintptr_t)pg;
-  const uintptr_t hi = (b + bytes) / (uintptr_t)pg * (uintptr_t)pg;
-  if (hi <= lo) return sp;
-  hipPointerAttribute_t at;
-  std::memset(&at, 0, sizeof at);
-  const hipError_t qa = hipPointerGetAttributes(&at, reinterpret_cast<const void*>(lo));
-  (void)hipGetLastError();
-  if (qa == hipSuccess && at.type != hipMemoryTypeUnregistered) return sp;   // the runtime knows it: leave it alone
-  const hipError_t e = hipHostRegister(reinterpret_cast<void*>(lo), hi - lo, hipHostRegisterDefault);
-  (void)hipGetLastError();
-  if (e != hipSuccess) return sp;   // refused (e.g. hipErrorHostMemoryAlreadyRegistered for a part of it): staged copies
-  sp.lo = reinterpret_cast<const char*>(lo);
-  sp.hi = reinterpret_cast<const char*>(hi);
-  return sp;
-}
-
-static void unpin(PinnedSpan& sp) {
-  if (sp.lo) (void)hipHostUnregister(const_cast<char*>(sp.lo));
-  (void)hipGetLastError();
-  sp.lo = sp.hi = nullptr;
-}
-
-// host -> device copy of [src, src + n) that crosses at most the two ends of a pinned span: the part inside the
-// span is one true DMA, the parts outside (under a page each) are the runtime's staged copies.  A single call
-// over the whole range would be refused: the range is not inside one registration.
-static hipError_t copy_h2d_split(char* dst, const char* src, size_t n, const PinnedSpan& sp, hipStream_t st) {
-  if (!sp.lo) return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st);
-  const char* const end = src + n;
-  const char* const a = std::min(end, std::max(src, sp.lo));   // first pinned byte of the range
-  const char* const b = std::max(a, std::min(end, sp.hi));     // one past its last pinned byte
-  hipError_t e = hipSuccess;
-  if (a > src) e = hipMemcpyAsync(dst, src, (size_t)(a - src), hipMemcpyHostToDevice, st);
-  if (e == hipSuccess && b > a) e = hipMemcpyAsync(dst + (a - src), a, (size_t)(b - a), hipMemcpyHostToDevice, st);
-  if (e == hipSuccess && end > b) e = hipMemcpyAsync(dst + (b - src), b, (size_t)(end - b), hipMemcpyHostToDevice, st);
-  return e;
-}
-
 // Gram of a HOST-resident [n][ld] matrix, streamed: the rows cross PCIe in chunks through two device
 // buffers on a copy stream while the previous chunk's Gram runs on the compute stream; the chunk
 // Grams accumulate in C in chunk order.  The copies read the caller's pageable memory through the runtime's ordinary
-// path.  Behind developer flag 4096 a dense X (ld == p) of 8 MB or more is pinned in place for the duration -- its
-// interior pages only, see pin_interior; y (1 / p of the bytes) and strided X (ld > p: the extent (n - 1) ld + p
-// ends inside somebody else's row) are never pinned.
+// path: the caller's pages are never page-locked (rounds 2-3 registered them in place; measured slower -- registering
+// 2 x 800 MB cost 14-21 ms to save about 10 ms of copy time -- and it was the one code path that touched memory it did
+// not own; removed in round 4).
 static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int64_t n, int64_t ld, int p,
                               int is_f32, double* C_out) {
   const size_t es = is_f32 ? 4 : 8;
@@ -1126,7 +1066,6 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
   void* dy[2] = {nullptr, nullptr};
   hipStream_t cs = nullptr;
   hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
-  PinnedSpan pin;
   C.ptr = C_out;
   int rc = dev_alloc(ctx, slabs, gram_workspace_bytes(p, n_split) / sizeof(double));
   hipError_t e = hipSuccess;
@@ -1140,16 +1079,11 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
     if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_NOMEM, "streamed reduction buffers", e);
   }
-  const auto t_pin0 = std::chrono::steady_clock::now();
+  const auto t_stream0 = std::chrono::steady_clock::now();
   auto seconds_since = [](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   };
   if (rc == LSSPA_OK) {
-    // Page-locking the caller's X is OFF by default (round 3, tools/host_reduce_probe.py at the C3 shape: registering
-    // 2 x 800 MB costs 14-21 ms and saves about 10 ms of copy time -- the runtime's own pageable path pins and DMAs
-    // chunk by chunk; 52-59 ms for the whole call without, 53-69 ms with, on two boxes).  Developer flag 4096 turns it on.
-    if (ld == p && (ctx->flags & 4096)) pin = pin_interior(X, (size_t)n * p * es);
-    ctx->red_pin_s += seconds_since(t_pin0);
     ProfScope ps(ctx, LSSPA_K_GRAM);
     int k = 0;
     for (int64_t r0 = 0; r0 < n && e == hipSuccess; r0 += rows, ++k) {
@@ -1159,7 +1093,7 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
       const char* src = static_cast<const char*>(X) + (size_t)r0 * ld * es;
       if (e == hipSuccess) {
         if (ld == p)
-          e = copy_h2d_split(static_cast<char*>(dX[b]), src, (size_t)nr * p * es, pin, cs);
+          e = hipMemcpyAsync(dX[b], src, (size_t)nr * p * es, hipMemcpyHostToDevice, cs);
         else
           e = hipMemcpy2DAsync(dX[b], (size_t)p * es, src, (size_t)ld * es, (size_t)p * es, (size_t)nr,
                                hipMemcpyHostToDevice, cs);
@@ -1188,7 +1122,7 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
     }
     if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "streamed gram", e);
   }
-  // Both streams are idle before the span is unpinned and the buffers go -- on the error paths too: every copy
+  // Both streams are idle before the buffers go -- on the error paths too: every copy
   // that reads the caller's pages was enqueued on cs, every kernel that reads dX / dy on the context's stream.
   hipError_t es1 = hipStreamSynchronize(ctx->stream);
   hipError_t es2 = hipSuccess;
@@ -1198,10 +1132,7 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
   }
   if (rc == LSSPA_OK && es1 != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "streamed gram sync", es1);
   if (rc == LSSPA_OK && es2 != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "streamed gram copy sync", es2);
-  ctx->red_stream_s += seconds_since(t_pin0);      // pin included; taken out again in lsspa_reduce_timing
-  const auto t_unpin0 = std::chrono::steady_clock::now();
-  unpin(pin);
-  ctx->red_unpin_s += seconds_since(t_unpin0);
+  ctx->red_stream_s += seconds_since(t_stream0);
   for (int b = 0; b < 2; ++b) {
     if (dX[b]) (void)hipFree(dX[b]);
     if (dy[b]) (void)hipFree(dy[b]);
@@ -1220,7 +1151,7 @@ static int reduce_rows(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, co
   const size_t es = dtype == LSSPA_F32 ? 4 : 8;
   const int is_f32 = dtype == LSSPA_F32;
   const size_t c_elems = (size_t)round_up(p + 1, 128) * round_up(p + 1, 128);
-  ctx->red_pin_s = ctx->red_stream_s = ctx->red_unpin_s = ctx->red_finalize_s = 0.0;
+  ctx->red_stream_s = ctx->red_finalize_s = 0.0;
   TRY(dev_alloc(ctx, ctx->Cred, 2 * c_elems));
   HIPCHK(hipMemsetAsync(ctx->Cred.ptr, 0, 2 * c_elems * 8, ctx->stream));
   auto side = [&](const void* X, const void* y, int64_t n, int64_t ld, bool train) -> int {
@@ -1325,9 +1256,9 @@ int lsspa_reduce(lsspa_ctx* ctx, const void* X_train, int64_t ld_train, const vo
 
 int lsspa_reduce_timing(const lsspa_ctx* ctx, double* seconds4) {
   if (!ctx || !seconds4) return LSSPA_ERR_ARG;
-  seconds4[0] = ctx->red_pin_s;
-  seconds4[1] = ctx->red_stream_s - ctx->red_pin_s;
-  seconds4[2] = ctx->red_unpin_s;
+  seconds4[0] = 0.0;
+  seconds4[1] = ctx->red_stream_s;
+  seconds4[2] = 0.0;
   seconds4[3] = ctx->red_finalize_s;
   return LSSPA_OK;
 }
@@ -1558,9 +1489,18 @@ int lsspa_lift_batch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t an
   // validate before anything is launched: a repeated index would make a permuted Gram singular
   if (!all_permutations(perms, B, p, ctx->perm_mark))
     return ctx->fail(LSSPA_ERR_ARG, "perms: a row is not a permutation of 0..p-1");
+  TRY(check_accumulate(ctx, accumulate));   // nothing is launched for a call that cannot be collected
   Lane* L = nullptr;
   TRY(lift_launch(ctx, perms, B, per, &L));
-  return lift_collect(ctx, *L, 0, B, lifts_out, accumulate);
+  const int rc = lift_collect(ctx, *L, 0, B, lifts_out, accumulate);
+  if (rc != LSSPA_OK && L->in_flight) {
+    // the caller has no ticket for this batch: give the lane back as lsspa_lift_discard would (the message of the
+    // failure stays in place)
+    if (ctx->n_lanes == 2 && L->taken > 0 && hipEventRecord(L->ev_consumed, ctx->stream) == hipSuccess)
+      L->consumed_valid = true;
+    L->in_flight = false;
+  }
+  return rc;
 } catch (...) {
   return abi_caught(ctx);
 }
@@ -2060,7 +2000,15 @@ int lsspa_debug_factor(lsspa_ctx* ctx, const int32_t* perm, double* L, double* L
   };
   if (L) TRY(unpack(0, L));
   if (Lt && ctx->tri) TRY(unpack(1, Lt));
-  if (V) {
+  if (V && vt_path(ctx)) {
+    // the panel launches leave V^T (chunk-major, upper block triangle written; rows at or beyond p belong to no feature)
+    const size_t rows = n_iblk * NB;
+    std::vector<double> tmp(pp * pp);
+    TRY(fetch_elems(ctx, ctx->lanes[0].V.ptr, 0, pp * pp, tmp.data()));
+    for (size_t r = 0; r < rows; ++r)
+      for (size_t c = 0; c < mp; ++c)
+        V[r * mp + c] = (c / 128 > r / 128 || c >= (size_t)ctx->p) ? 0.0 : tmp[cm_off((int)pp, (int)c, (int)r)];
+  } else if (V) {
     const size_t rows = n_iblk * NB;
     std::vector<double> tmp(rows * ldv);
     TRY(fetch_elems(ctx, ctx->lanes[0].V.ptr, 0, rows * ldv, tmp.data()));
@@ -2068,7 +2016,7 @@ int lsspa_debug_factor(lsspa_ctx* ctx, const int32_t* perm, double* L, double* L
     // device (strip2_kernel)
     for (size_t r = 0; r < rows; ++r)
       for (size_t c = 0; c < mp; ++c)
-        V[r * mp + c] = (ctx->tri && !(ctx->flags & 4) && r < (c / 128) * 128) ? 0.0 : tmp[r * ldv + c];
+        V[r * mp + c] = (ctx->tri && r < (c / 128) * 128) ? 0.0 : tmp[r * ldv + c];
   }
   return LSSPA_OK;
 } catch (...) {

@@ -210,7 +210,9 @@ class HipEngine:
     def _acc_mode(accumulate):
         """False / True / 2: nothing, into the pending buffer (all-reduce + merge() follow), or -- one GPU -- folded
         into the running statistics at once (no merge() call; include/lsspa.h)."""
-        return 2 if (accumulate is not True and accumulate == 2) else int(bool(accumulate))
+        if isinstance(accumulate, (bool, np.bool_)):
+            return int(accumulate)
+        return int(accumulate)      # integers go through as they are: the library refuses anything but 0, 1, 2
 
     def set_lanes(self, n: int):
         """1: batches run one after the other (default).  2: successive batches alternate between two workspaces on

@@ -609,14 +609,14 @@ def test_feature_count_beyond_64kb_of_gather_lds():
         eng.close()
 
 
-# ------------------------------------------------------------------ streamed reduction: page-locking of caller memory
-def test_streamed_reduction_pinning_corner_cases():
+# ------------------------------------------------------------------ streamed reduction: caller memory in awkward places
+def test_streamed_reduction_host_memory_corner_cases():
     """lsspa_reduce from host arrays, through the C ABI, in the three situations the round-2 review listed for the
     abort once seen in this path: (i) X and y carved out of ONE buffer so that they share pages, each >= 8 MB;
     (ii) arrays the caller has already page-locked; (iii) a strided X (ld > p) whose last row ends exactly at the end
     of a memory mapping, so that n * ld elements would reach past it.  Each must give the Gram matrices of the plain
-    call, and leave the caller's memory usable (still registered in (ii)).  Page-locking is behind developer flag 4096
-    (the default transport is the runtime's pageable path); the test turns it on."""
+    call, and leave the caller's memory usable (still registered in (ii)).  The library reads the caller's pages
+    through the runtime's ordinary copies only (the page-locking path of rounds 2-3 was removed in round 4)."""
     import ctypes as C
     import mmap
     from ls_spa import _native as N
@@ -634,7 +634,6 @@ def test_streamed_reduction_pinning_corner_cases():
         return eng.gram()
 
     try:
-        eng.set_flags(4096)               # page-locking on (off by default since round 3: it is the slower transport)
         # reference result: well-separated, aligned arrays
         Xa, Xe = rng.standard_normal((n, p)), rng.standard_normal((n, p))
         ya, ye = rng.standard_normal(n), rng.standard_normal(n)
@@ -685,11 +684,6 @@ def test_streamed_reduction_pinning_corner_cases():
             views.append(np.lib.stride_tricks.as_strided(flat, shape=(n, p), strides=(ld * 8, 8)))
         views[0][:], views[1][:] = Xa, Xe
         got = reduce_host(views[0], ya, views[1], ye, ld)
-        for a, b in zip(got, base):
-            np.testing.assert_array_equal(a, b)
-        # without page-locking (the default): the same bits, the pinning is transport only
-        eng.set_flags(0)
-        got = reduce_host(Xa1, ya1, Xe1, ye1, p)
         for a, b in zip(got, base):
             np.testing.assert_array_equal(a, b)
     finally:
