@@ -643,23 +643,32 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
   const int J0 = Jo * 128;
   const int I0 = xt ? tile * 128 : J0 + 128 + tile * 128;
   PSTAMP(0);
+  // Rows of a wave.  The tile's eight 16-row sub-tiles are dealt to the four waves as {w, 7 - w}: wave w owns rows
+  // rb[0] = 16 w .. and rb[1] = 16 (7 - w) .. (any assignment would do: rows are independent of each other from the
+  // tile's start to its store).  The pairing matters for the X tiles' first k-block, below.
+  static_assert(NW == 4 && YT == 2, "the row map is written for four waves of two 16-row sub-tiles");
+  const int ws = __builtin_amdgcn_readfirstlane(w);   // the wave index as the scalar it is
+  const int rb[2] = {16 * ws, 16 * (7 - ws)};
   // Rows at or beyond p_live (= p + 1 rounded up to 16) are identity padding: left of the diagonal they are exact
   // zeros before, during and after every update, so the 16-row accumulator tiles that consist of them only are
   // left out of every product -- the same bits with fewer instructions (p = 1000 pads to 1024: 1 tile in 64;
   // p = 5000 to 5120: 7 in 320).  (X tiles: those rows of V^T belong to no feature; nobody reads them.)
-  // Both counts are wave-uniform, and the compiler has to know it (the wave index comes out of threadIdx): a
+  // All of these are wave-uniform, and the compiler has to know it (the wave index comes out of threadIdx): a
   // condition it takes for divergent turns every product it guards into an exec-masked region of its own; as
   // scalars they are plain branches (measured: 4.08 -> 4.04 ms of panel time per C3 step).  A condition-free copy
   // of the k-loop for full tiles was measured too: no faster (it costs registers the epilogue then spills).
-  const int ws = __builtin_amdgcn_readfirstlane(w);
-  const int ylive = min(YT, max(0, (p_live - (I0 + RW * ws) + 15) / 16));   // live 16-row tiles of this wave
+  const bool live[2] = {I0 + rb[0] < p_live, I0 + rb[1] < p_live};
 
   // k-loop range: an L tile sums over every column left of the panel; an X tile starts at its own row block
-  // (X[I', K] = 0 for K < I'), and inside that block wave ws's rows 32 ws .. are zero left of column 32 ws: its first
-  // 2 ws chunks add exact zeros and are left out (as the strip kernel did)
+  // (X[I', K] = 0 for K < I').  Inside that first block X[I', I'] is upper triangular: sub-tile s (rows 16 s ..) is zero
+  // left of column 16 s, i.e. in the block's chunks c < s, and those products are left out.  With the sub-tiles dealt
+  // {w, 7 - w} every wave leaves out 7 of its 16 sub-tile-chunks: the block costs every wave -- and so the workgroup,
+  // whose waves meet at two barriers a chunk -- 9/16 of a full one.  (Contiguous rows per wave, as the strip kernel had
+  // them, let wave 3 skip six chunks of eight while wave 0 skipped none: the workgroup took the full time.)
   const int cb = xt ? I0 / KCH : 0;
   const int nch = J0 / KCH - cb;
-  const int cskip = xt ? (RW / KCH) * ws : 0;
+  constexpr int NEVER = 0x7fffffff;
+  const int cstart[2] = {live[0] ? (xt ? rb[0] / KCH : 0) : NEVER, live[1] ? (xt ? rb[1] / KCH : 0) : NEVER};
   const T* srcJ = MJ + cm_off(p_pad, J0, KCH * cb);
   const T* srcI = M + cm_off(p_pad, I0, KCH * cb);
   const int64_t chunk = (int64_t)p_pad * 16;
@@ -682,7 +691,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
       for (int y = 0; y < YT; ++y)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = J0 + 16 * x + Tr<T>::acc_row(l4, r), col = I0 + RW * w + 16 * y + l15;
+          const int row = J0 + 16 * x + Tr<T>::acc_row(l4, r), col = I0 + rb[y] + l15;
           const T v = __builtin_nontemporal_load(Bt + cm_off(p_pad, row, col));
           acc[x][y][r] = (row >= col) ? -v : (T)0;
         }
@@ -696,7 +705,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
     // workgroup barrier).
     constexpr int VPR = 16 / VE;        // 16-byte vectors per 16-column row piece
     constexpr int RPI = 64 / VPR;       // rows per wave instruction: 8 (fp64) / 16 (fp32)
-    constexpr int NQ = RW / RPI;        // passes over the wave's rows
+    constexpr int NQ = RW / RPI;        // passes over the wave's rows: NQ / 2 per sub-tile
     const int rr = lane / VPR, ch = lane % VPR;
 #pragma unroll
     for (int xh = 0; xh < 4; ++xh) {
@@ -706,18 +715,18 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
           t[xx][q] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(
-              M + cm_off(p_pad, I0 + RW * w + rr + RPI * q, J0 + 16 * (2 * xh + xx) + VE * ch)));
+              M + cm_off(p_pad, I0 + rb[q / (NQ / 2)] + rr + RPI * (q % (NQ / 2)), J0 + 16 * (2 * xh + xx) + VE * ch)));
 #pragma unroll
       for (int xx = 0; xx < 2; ++xx) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-          Tr<T>::lds_store(s_out + (RW * w + rr + RPI * q) * RK_LD + VE * ch, t[xx][q]);
+          Tr<T>::lds_store(s_out + (rb[q / (NQ / 2)] + rr + RPI * (q % (NQ / 2))) * RK_LD + VE * ch, t[xx][q]);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int y = 0; y < YT; ++y)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            acc[2 * xh + xx][y][r] = -s_out[(RW * w + 16 * y + l15) * RK_LD + Tr<T>::acc_row(l4, r)];
+            acc[2 * xh + xx][y][r] = -s_out[(rb[y] + l15) * RK_LD + Tr<T>::acc_row(l4, r)];
         __builtin_amdgcn_wave_barrier();
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -734,17 +743,16 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
       rk_load_full<T, 128, NT>(rj, srcJ + (c + 1) * chunk, CM_LD, tid);
       rk_load_full<T, 128, NT>(ri, srcI + (c + 1) * chunk, CM_LD, tid);
     }
-    if (c < cskip) continue;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       T av[8], bv[YT];
 #pragma unroll
       for (int x = 0; x < 8; ++x) av[x] = s_rkj[(16 * x + l15) * RK_LD + 4 * kk + l4];
 #pragma unroll
-      for (int y = 0; y < YT; ++y) bv[y] = s_rki[(RW * w + 16 * y + l15) * RK_LD + 4 * kk + l4];
+      for (int y = 0; y < YT; ++y) bv[y] = s_rki[(rb[y] + l15) * RK_LD + 4 * kk + l4];
 #pragma unroll
       for (int y = 0; y < YT; ++y)
-        if (y < ylive) {
+        if (c >= cstart[y]) {
 #pragma unroll
           for (int x = 0; x < 8; ++x) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
         }
@@ -759,7 +767,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
   auto tri_mult = [&](const int half) {
 #pragma unroll
     for (int y = 0; y < YT; ++y) {
-      if (y >= ylive) continue;   // padding rows: the accumulators are and stay zero
+      if (!live[y]) continue;   // padding rows: the accumulators are and stay zero
       acc_t t[4];
 #pragma unroll
       for (int xp = 0; xp < 4; ++xp) t[xp] = Tr<T>::zero();
@@ -815,6 +823,11 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
   tri_mult(1);
 
   PSTAMP(3);
+  // the wave's row bases once more, from a copy of the wave index the compiler cannot see through: otherwise the store
+  // loop's LDS addresses are computed ahead of the k-loop and carried -- spilled -- through it
+  int ws_e = ws;
+  asm volatile("" : "+s"(ws_e));
+  const int rb_e[2] = {16 * ws_e, 16 * (7 - ws_e)};
   // Store L[I, panel] through the output buffer, one 16-column chunk at a time (a contiguous 128 x 16
   // block in the chunk-major layout).
   typedef RKRegs<T, 128, NT> RR;
@@ -826,7 +839,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
     for (int y = 0; y < YT; ++y)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        s_out[(RW * w + 16 * y + l15) * RK_LD + Tr<T>::acc_row(l4, r)] = acc[xp][y][r];
+        s_out[(rb_e[y] + l15) * RK_LD + Tr<T>::acc_row(l4, r)] = acc[xp][y][r];
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < RR::NP; ++q) {
@@ -902,6 +915,10 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
       products(s_out);
     }
     PSTAMP(5);
+    // the block's addresses are formed again here, from a copy of p_pad the compiler cannot see through: kept from the
+    // initial loads above they are carried (five of them spilled) through the loop
+    int pp_e = p_pad;
+    asm volatile("" : "+s"(pp_e));
 #pragma unroll
     for (int q = 0; q < NU; ++q) {
       const int t = WS + NW * q;
@@ -909,7 +926,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * syrk_ti_c(t) + Tr<T>::acc_row(l4, r), col = 16 * syrk_tj_c(t) + l15;
-        if (col <= row) M[cm_off(p_pad, I0 + row, I0 + col)] = -upd[q][r];
+        if (col <= row) M[cm_off(pp_e, I0 + row, I0 + col)] = -upd[q][r];
       }
     }
   };
