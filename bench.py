@@ -17,7 +17,7 @@ samples = 256 orderings per step, fp64.  Other configs:  --p 100 --rows 10000 (C
 --p 5000 --rows 200000 --dtype f32 (C5: float32 data and per-ordering work, reg = 1e-2).
 
 A step = one batch through the whole per-batch path: ordering upload -> permuted gather -> blocked Cholesky ->
-strip solve -> lifts -> batch moments -> (all-reduce over the ranks: RCCL through the C ABI) -> merge.  The data
+V^T tiles inside the Cholesky's panel launches -> lifts -> batch moments -> (all-reduce over the ranks: RCCL through the C ABI) -> merge.  The data
 and its one-time Gram reduction are resident in HBM before the timed region; the reduction is timed and reported
 separately.  --scaling weak (default): every rank evaluates its own batch_size samples per step (global batch =
 N x batch_size).  --scaling strong: BASELINE config 4's semantics, the global batch of batch_size samples is dealt
@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--flags", type=int, default=0, help="developer switches of the engine (include/lsspa.h, lsspa_set_flags)")
     ap.add_argument("--no-probe", action="store_true", help="skip the strong-scaling probe (clean rocprof averages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 3 s sustained-rate region")
     ap.add_argument("--no-ttt", action="store_true", help="skip the time-to-tolerance runs")
     ap.add_argument("--data", choices=("gaussian", "correlated"), default="gaussian",
                     help="gaussian: BASELINE.md section 3 (default_rng(0)), the data the metric is quoted on; correlated: "
@@ -94,9 +95,16 @@ def launch_ranks(n, argv):
     while port + 64 > 65535:
         port = _free_port()
     procs = []
+    # LSSPA_BENCH_REHEARSE_WORLD=N (with --gpus N): the N ranks all open GPU 0 -- the real multi-rank code of this file
+    # (dealing, agreement on the transport, strong-scaling region, max / min over ranks, sharded time-to-tolerance legs)
+    # on a one-GPU box.  RCCL refuses several ranks on one device, so the process group is gloo and the engine's device
+    # buffers are staged through the host around the all-reduce (ls_spa._dist.TorchComm).
+    one_gpu = os.environ.get("LSSPA_BENCH_REHEARSE_WORLD") == str(n)
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LSSPA_BENCH_LAUNCHED="1")
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if one_gpu else str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LSSPA_BENCH_LAUNCHED="1")
+        if one_gpu:
+            env["LSSPA_BENCH_ONE_GPU"] = "1"
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
@@ -175,7 +183,7 @@ def correlated_data(p, rows, dtype):
     return tuple(np.ascontiguousarray(a, dtype=dt) for a in (Xa, Xe, ya, ye))
 
 
-def algorithmic_flops(kclass, p, n_ord, tri, launches_per_batch):
+def algorithmic_flops(kclass, p, n_ord, tri, launches_per_batch, vt=False):
     """Useful flops of one launch of a kernel class (element granularity, no padding, no
     redundant tile work), so that 'achieved' cannot be inflated by wasted arithmetic."""
     n_mats = n_ord * (2 if tri else 1)
@@ -183,7 +191,9 @@ def algorithmic_flops(kclass, p, n_ord, tri, launches_per_batch):
         per = p ** 3 / 3.0 if tri else float(p) ** 3
         return per * n_ord / launches_per_batch
     if kclass == "chol_panel":     # the whole Cholesky, p^3/3 per matrix: the panel launches also factor the
-        return (p ** 3 / 3.0) * n_mats / launches_per_batch   # diagonal blocks (all but block 0)
+        # diagonal blocks (all but block 0); vt (tri mode since round 4): they also compute V^T = L_t^T L^-T, p^3/3 per
+        # ordering -- SURVEY 8d's "~p^3 per ordering" in one kernel class
+        return ((p ** 3 / 3.0) * n_mats + ((p ** 3 / 3.0) * n_ord if vt else 0.0)) / launches_per_batch
     if kclass == "chol_diag":      # stand-alone launch: block 0 only (factor + inverse)
         return (64 ** 3 / 3.0 * 2) * n_mats / launches_per_batch
     if kclass == "small_p":        # fused small-p kernel: the whole per-ordering work, ~p^3
@@ -300,6 +310,10 @@ def main():
     # rehearse on a single GPU exactly what the N > 1 launch executes
     rehearse = world == 1 and os.environ.get("LSSPA_BENCH_REHEARSE_DIST") == "1"
     multi = world > 1 or rehearse
+    # several ranks on ONE GPU (the launcher's LSSPA_BENCH_REHEARSE_WORLD): gloo group, moments staged through the host
+    one_gpu = world > 1 and os.environ.get("LSSPA_BENCH_ONE_GPU") == "1"
+    coll_dev = torch.device("cpu") if one_gpu else dev      # where the contract's own small collectives live
+    fail_rank = os.environ.get("LSSPA_BENCH_FAIL_RANK")     # test hook: this rank dies after the warm-up steps
 
     p, rows, B = args.p, args.rows, args.batch_size
     reg = args.reg if args.reg is not None else (1e-2 if args.dtype == "f32" else 0.0)
@@ -324,13 +338,15 @@ def main():
             # path's all-reduce goes through the engine's own RCCL communicator on the engine's stream
             if rehearse:
                 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            elif one_gpu:
+                dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=dev)
-            warm = torch.zeros(1, device=dev)
+            warm = torch.zeros(1, device=coll_dev)
             dist.all_reduce(warm)
             torch.cuda.synchronize()
             native_ok = 0
-            if args.collective == "native":
+            if args.collective == "native" and not one_gpu:
                 try:
                     from ls_spa._rccl import NativeComm
                     comm = NativeComm.from_env(force_collective=rehearse)
@@ -340,7 +356,7 @@ def main():
                     sys.stderr.write(f"[bench] rank {rank}: native communicator failed ({exc})\n")
                 # the ranks agree on the outcome (the torch group is up): one rank on torch.distributed beside others on
                 # the engine's RCCL communicator would never meet them in a collective
-                flag = torch.tensor([native_ok], dtype=torch.int32, device=dev)
+                flag = torch.tensor([native_ok], dtype=torch.int32, device=coll_dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if int(flag.item()) == 0:
                     if native_ok and hasattr(comm, "close"):
@@ -351,10 +367,12 @@ def main():
                                          "torch.distributed\n")
                 else:
                     collective = "rccl via the C ABI (lsspa_stats_allreduce, engine stream)"
-            if args.collective == "torch" or comm is None:
+            if args.collective == "torch" or comm is None or one_gpu:
                 from ls_spa._dist import TorchComm
                 comm = TorchComm(force_collective=rehearse)
-                collective = "torch.distributed nccl (host-synchronised hand-off between the engine's and torch's stream)"
+                collective = ("torch.distributed gloo, device buffers staged through the host (several ranks rehearsed on "
+                              "one GPU: RCCL refuses that)" if one_gpu else
+                              "torch.distributed nccl (host-synchronised hand-off between the engine's and torch's stream)")
     finally:
         if multi:
             sys.stdout.flush()
@@ -467,6 +485,9 @@ def main():
         step.region(0, n_warm)
         for k in range(n_warm):
             step(k)
+        if fail_rank is not None and int(fail_rank) == rank:
+            sys.stderr.write(f"[bench] rank {rank}: LSSPA_BENCH_FAIL_RANK set, leaving with status 3\n")
+            os._exit(3)
         barrier()
         step.region(n_warm, n_total)
         t0 = time.perf_counter()
@@ -476,7 +497,7 @@ def main():
         mine = time.perf_counter() - t0
         hi = lo = mine
         if multi:
-            t = torch.tensor([mine, -mine], dtype=torch.float64, device=dev)
+            t = torch.tensor([mine, -mine], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             hi, lo = float(t[0].item()), -float(t[1].item())
         return mine, hi, lo
@@ -489,6 +510,58 @@ def main():
     eng.profile(False)
     _, elapsed, elapsed_min = timed_region(step, args.warmup, total_steps)
     n_seen, mean, _ = eng.stats(want_cov=False)
+    # sustained rate (orderings/s "sustained over the sampling loop"): the headline region is K steps --
+    # 0.13 s at C3 -- and the chip needs ~0.4 s of back-to-back launches to settle on the clock it holds under load.  The
+    # same step function over >= SUSTAIN_S seconds (the step count follows from the headline time, identical on every
+    # rank), after the headline region so that `value` keeps its definition; the orderings are the region's, cyclically.
+    # Rank 0 asks rocm-smi for clock and power about a second into the region (in a helper thread; None if it does not answer).
+    sustained = None
+    if not args.no_sustained:
+        SUSTAIN_S = 3.0
+        n_sus = max(args.steps, int(np.ceil(SUSTAIN_S / max(elapsed / args.steps, 1e-6))))
+        n_sus = -(-n_sus // D) * D          # whole look-ahead groups
+
+        class Cyclic:
+            """perms[k] for k beyond the generated steps: the timed region's orderings again"""
+            def __init__(self, base, lo, hi):
+                self.base, self.lo, self.n = base, lo, hi - lo
+
+            def __getitem__(self, k):
+                if isinstance(k, slice):
+                    return self.base[[self.lo + (i % self.n) for i in range(k.start, k.stop)]]
+                return self.base[self.lo + (k % self.n)]
+
+        smi = {}
+
+        def ask_smi():
+            import subprocess
+            time.sleep(1.0)
+            try:
+                r = subprocess.run(["rocm-smi", "-d", str(local), "--showclocks", "--showpower", "--json"],
+                                   capture_output=True, text=True, timeout=10)
+                card = next(iter(json.loads(r.stdout).values()))
+                for k, v in card.items():
+                    if "sclk" in k.lower() and "clock speed" in k.lower():
+                        smi["sclk_mhz"] = float(str(v).strip("()").lower().replace("mhz", ""))
+                    if "power" in k.lower() and "(w)" in k.lower():
+                        smi["power_w"] = float(v)
+            except Exception as exc:
+                smi["error"] = repr(exc)
+
+        import threading
+        th = threading.Thread(target=ask_smi, daemon=True) if rank == 0 else None
+        sus_step = Steps(Cyclic(my_perms, args.warmup, total_steps), B_rank, D)
+        barrier()
+        if th is not None:
+            th.start()
+        _, el_sus, el_sus_min = timed_region(sus_step, 0, n_sus)
+        if th is not None:
+            th.join(timeout=15)
+        sustained = {"steps": n_sus, "seconds": el_sus, "ms_per_step": 1e3 * el_sus / n_sus,
+                     "orderings_per_s": world * n_ord * n_sus / el_sus, "ms_per_step_min_rank": 1e3 * el_sus_min / n_sus,
+                     "sclk_mhz": smi.get("sclk_mhz"), "power_w": smi.get("power_w"), "rocm_smi_error": smi.get("error"),
+                     "note": "the same step function as the headline region over >= 3 s (max over ranks); clock and power "
+                             "as rocm-smi reports them about one second into the region"}
     # pass 2: the same K steps again with a HIP-event pair around every launch on the engine's
     # stream -> per-kernel durations for the roofline figures (one lane: each kernel alone on the GPU)
     eng.set_lanes(1)
@@ -561,7 +634,8 @@ def main():
         mfma_classes = [k for k in ("strip", "chol_panel", "chol_diag", "small_p") if k in per_class]
         dom = max(mfma_classes, key=lambda k: per_class[k]["ms_per_step"])
         lpb = per_class[dom]["launches_per_step"]
-        flops = algorithmic_flops(dom, p, n_ord, eng.tri, lpb)
+        vt = bool(eng.tri) and "strip" not in per_class      # V^T by the panel launches' X tiles (no strip launch)
+        flops = algorithmic_flops(dom, p, n_ord, eng.tri, lpb, vt)
         ach = flops / (per_class[dom]["avg_launch_ms"] * 1e-3) / 1e12
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -586,7 +660,8 @@ def main():
         out = {
             "metric": "orderings_per_sec", "value": value, "unit": "orderings/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic gaussian" if args.data == "gaussian" else "synthetic correlated",
             "config": {"workload": f"{label} p={p} N=M={rows} reg={reg:g} method=argsort batch_size={B} antithetical "
                                    f"(={n_ord} orderings/step/GPU) "
                                    f"{'fp64' if args.dtype == 'f64' else 'fp32 data and per-ordering work / fp64 accumulation'}",
@@ -604,6 +679,7 @@ def main():
             "host_data_generation_s": gen_s,
             "check": {"samples": int(n_seen), "sum_attribution": float(mean.sum())},
             "ms_per_step_min_rank": 1e3 * elapsed_min / args.steps,
+            "sustained": sustained,
             "timing_note": "value/ms_per_step: K steps without events; kernels/roofline: the same K steps "
                            "repeated with a HIP-event pair around every launch on the engine's stream",
         }
@@ -731,9 +807,9 @@ def main():
 
         breakdown_note = ("e2e_breakdown: host seconds of the faster of two calls -- engine_create (context, stream), setup "
                           "(communicator, precision), sampler_start (generator + QMC constructor handed to a helper thread), "
-                          "reduction_pin / reduction_copy_gram / reduction_unpin / reduction_finalize (page-lock of X's "
-                          "interior pages; chunked H2D over PCIe under the Gram kernels; un-lock; scaling and sync -- the library's "
-                          "own timers, lsspa_reduce_timing) and reduction_host (what is left of the phase: coercion of the arrays, "
+                          "reduction_copy_gram / reduction_finalize (chunked H2D over PCIe under the Gram kernels; scaling and "
+                          "sync -- the library's own timers, lsspa_reduce_timing; reduction_pin / reduction_unpin are 0 since "
+                          "round 4: nothing of the caller's is page-locked) and reduction_host (what is left of the phase: coercion of the arrays, "
                           "buffer allocation, the call), sampler (drawing orderings), sampling (upload + kernels + "
                           "statistics of the loop, incl. workspace allocation on the first batch), estimator (statistics "
                           "read-back + error estimate), final_fit (theta, r^2), teardown (free, destroy)")

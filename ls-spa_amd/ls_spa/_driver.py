@@ -422,7 +422,7 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
 
 def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_size=2 ** 8,
            tolerance=1e-2, seed=42, perms=None, antithetical=True, return_attribution_history=False, *,
-           method=None, num_batches=None, return_history=None, device=0, error_estimator="reference",
+           method=None, num_batches=None, return_history=None, device=0, error_estimator=None,
            precision="float64", row_sharded=False, checkpoint=None, comm=None, lookahead=1, _engine=None,
            _comm=None, _timings=None):
     """Estimates the Shapley attribution of the out-of-sample R^2 of a least-squares fit.
@@ -437,7 +437,14 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
     error_estimator:  'reference' (host, same generator call order as the reference),
         'lowrank' (same distribution, O(n p) instead of an O(p^3) factorisation, on the host) or
         'device' (the low-rank form on the GPU: the lift vectors never leave HBM; same numbers as
-        'lowrank' for the same seed up to summation order).
+        'lowrank' for the same seed up to summation order).  None (default) lets the method decide:
+        'reference' wherever the reference's code has a behaviour to mirror -- ``method`` None / 'random' / 'exact' and
+        every call with ``perms=``: there the estimator shares the generator with the ordering source and its
+        normal draws are observable in what is drawn next (ls_spa/ls_spa.py:168-175, :224) -- and 'device' for the
+        QMC methods 'argsort' / 'permutohedron', which the reference's code does not implement (only its README
+        names them): the estimator is then statistically the reference's (same 0.95-quantile definition of draws
+        with covariance C_unbiased / n, ls_spa/ls_spa.py:321-341) without its p x p factorisation on the host, which at
+        p = 5000 is 7 of the call's 9 seconds.
     precision:  'float64' (default, the reference's arithmetic) or 'float32' for the per-ordering
         factorisation work (about half the time; lifts agree to ~1e-5 on well-conditioned data;
         the Gram reduction, lift accumulation and statistics stay float64).
@@ -469,8 +476,10 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         return_attribution_history = bool(return_history)
     if num_batches is not None:
         max_samples = int(batch_size) * int(num_batches)
+    if error_estimator is None:
+        error_estimator = "device" if (perms is None and method in ("argsort", "permutohedron")) else "reference"
     if error_estimator not in ("reference", "lowrank", "device"):
-        raise ValueError("error_estimator must be 'reference', 'lowrank' or 'device'")
+        raise ValueError("error_estimator must be None, 'reference', 'lowrank' or 'device'")
 
     import time as _time
     tm = _timings if _timings is not None else {}   # bench.py's e2e_breakdown: host seconds per phase of this call
@@ -505,8 +514,8 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
             engine.load_data(X_train, X_test, y_train, y_test, reg)
         t0 = lap("reduction_h2d_gram", t0)
         if _timings is not None and hasattr(engine, "reduce_timing"):
-            # the library's own split of that phase: page-locking the caller's X, chunked copies + Gram kernels,
-            # un-locking, finalize; what is left of the phase is host-side coercion and the call itself
+            # the library's own split of that phase: chunked copies + Gram kernels, finalize (the page-locking parts
+            # are zero since round 4); what is left of the phase is host-side coercion and the call itself
             parts = engine.reduce_timing()
             whole = tm.pop("reduction_h2d_gram")
             tm["reduction_pin"], tm["reduction_copy_gram"] = parts["pin"], parts["h2d_gram"]

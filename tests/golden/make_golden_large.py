@@ -6,7 +6,11 @@ in the build container, arrays only, tests never import the reference).
 The raw data are not stored: the tests regenerate them from the seed with `large_problem` below (restated in
 tests/conftest.py), a plain default_rng stream.  Stored: the orderings, the reference's lift vector for each of them
 (`square_shapley`, ls_spa/ls_spa.py:256-287, on the reference's own `reduce_data` output, :290-318), theta and
-r_squared of the full fit, and -- at p = 1000 -- the attribution of the reference's driver on those orderings.
+r_squared of the full fit, and -- at p = 1000 -- the attribution of the reference's driver on those orderings together
+with its error estimates (error_history, overall_error, attribution_errors: ls_spa/ls_spa.py:222-236, :321-341 --
+statistical pins for the build's estimators, which draw other normals).
+
+    ... make_golden_large.py large_p1000      # regenerate one fixture only
 
   large_p1000.npz : p = 1000, N = M = 4000, seed 1000, 8 orderings          (~100 KB)
   large_p5000.npz : p = 5000, N = M = 6000, seed 5000, 1 ordering + reverse (~100 KB)
@@ -40,6 +44,8 @@ def save(name, **arrays):
 
 for name, seed, p, n, m, n_ord, reg in (("large_p1000", 1000, 1000, 4000, 4000, 8, 0.0),
                                         ("large_p5000", 5000, 5000, 6000, 6000, 1, 1e-2)):
+    if len(sys.argv) > 1 and name not in sys.argv[1:]:
+        continue
     t0 = time.time()
     d = large_problem(seed, p, n, m)
     red = ref.reduce_data(*d, reg)
@@ -56,6 +62,8 @@ for name, seed, p, n, m, n_ord, reg in (("large_p1000", 1000, 1000, 4000, 4000, 
                 y_norm_sq=np.float64(yn), y_test_head=d[3][:8], X_train_head=d[0][0, :8])
     if p == 1000:
         r = ref.ls_spa(*d, reg=reg, perms=orders, batch_size=4, tolerance=0.0)   # antithetical (the default)
-        pack.update(attribution=r.attribution, drv_theta=r.theta, drv_r_squared=np.float64(r.r_squared))
+        pack.update(attribution=r.attribution, drv_theta=r.theta, drv_r_squared=np.float64(r.r_squared),
+                    drv_error_history=np.asarray(r.error_history), drv_overall_error=np.float64(r.overall_error),
+                    drv_attribution_errors=np.asarray(r.attribution_errors), drv_batch_size=np.int64(4))
     save(name, **pack)
     print(f"  {name}: {time.time() - t0:.1f} s, sum(lift) - r2 = {lifts.sum(axis=1) - r2}")

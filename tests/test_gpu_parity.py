@@ -577,6 +577,18 @@ def test_large_p_against_reference_fixture(large_case, name):
         np.testing.assert_allclose(res.attribution, g["attribution"], rtol=0, atol=1e-10)
         np.testing.assert_allclose(res.theta, g["drv_theta"], rtol=1e-9, atol=1e-12)
         assert abs(res.r_squared - float(g["drv_r_squared"])) < 1e-11
+        # the reference driver's own error estimates on these eight samples (ls_spa/ls_spa.py:222-236, :321-341) as
+        # statistical pins for all three estimators: they draw other normals (the reference's Cholesky-or-SVD branch
+        # decides how many), the distribution is the same -- 0.95-quantiles of 1024 draws scatter by a few
+        # per cent
+        for est in ("reference", "lowrank", "device"):
+            r = ls_spa(*d, reg=reg, perms=g["orders"].astype(np.int64), batch_size=4, tolerance=0.0, error_estimator=est)
+            np.testing.assert_allclose(r.attribution, g["attribution"], rtol=0, atol=1e-10)
+            assert len(r.error_history) == len(g["drv_error_history"]) == 2
+            np.testing.assert_allclose(r.error_history, g["drv_error_history"], rtol=0.25)
+            assert r.overall_error == pytest.approx(float(g["drv_overall_error"]), rel=0.25)
+            ratio = r.attribution_errors / g["drv_attribution_errors"]
+            assert abs(np.median(ratio) - 1.0) < 0.1 and ratio.min() > 0.6 and ratio.max() < 1.6, (est, ratio.min(), ratio.max())
 
 
 def test_feature_count_beyond_64kb_of_gather_lds():

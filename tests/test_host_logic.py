@@ -124,6 +124,30 @@ def test_device_estimator_path_equals_lowrank(golden):
         pkg.ls_spa(*d, error_estimator="gpu", _engine=OracleEngine(), **kw)
 
 
+def test_default_estimator_fits_the_method(golden):
+    """error_estimator=None: the reference's estimator wherever the reference's code has a behaviour to mirror (its
+    shared generator makes the estimator's draws observable: ls_spa/ls_spa.py:168-175, :224) -- seed path, 'random',
+    any perms= -- and the device-side thin form for the QMC methods its code does not implement."""
+    from oracle_engine import OracleEngine
+    g = golden("p12")
+    d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+    base = dict(max_samples=48, batch_size=16, tolerance=0.0, seed=5)
+    for method in ("argsort", "permutohedron"):
+        eng = OracleEngine()
+        auto = pkg.ls_spa(*d, method=method, _engine=eng, **base)
+        assert eng.history_count() == 48                       # the device estimator keeps the lift vectors in the engine
+        dev = pkg.ls_spa(*d, method=method, error_estimator="device", _engine=OracleEngine(), **base)
+        np.testing.assert_array_equal(auto.error_history, dev.error_history)
+        np.testing.assert_array_equal(auto.attribution_errors, dev.attribution_errors)
+    for kw in (dict(base), dict(base, method="random"), dict(perms=g["perms64"][:48], batch_size=16, tolerance=0.0)):
+        eng = OracleEngine()
+        auto = pkg.ls_spa(*d, _engine=eng, **kw)
+        assert eng.history_count() == 0
+        ref = pkg.ls_spa(*d, error_estimator="reference", _engine=OracleEngine(), **kw)
+        np.testing.assert_array_equal(auto.error_history, ref.error_history)
+        np.testing.assert_array_equal(auto.attribution, ref.attribution)
+
+
 @pytest.mark.parametrize("method,estimator", [(None, "reference"), ("argsort", "lowrank"),
                                               ("permutohedron", "device"), ("random", "device")])
 def test_checkpoint_resume_continues_the_same_run(golden, tmp_path, method, estimator):
@@ -423,11 +447,17 @@ def test_lookahead_keeps_the_reference_order(golden):
     assert len(one.error_history) == len(three.error_history) == 2
     np.testing.assert_array_equal(three.attribution, one.attribution)
     assert e3.discarded == 1 and e3.launched == 1 and sum(e3.calls) == sum(e1.calls) == 32
-    # the group ends exactly at a check: the next group is launched before the rule is evaluated, then dropped
+    # the group ends exactly at a check.  Host-side estimator: the next group is launched before the rule is
+    # evaluated, then dropped.  Device-side estimator (the default of the QMC methods since round 4; its kernels
+    # would queue behind a new group): the next group is launched after the decision -- nothing wasted.
+    e2 = OracleEngine()
+    two = ls_spa(*d, _engine=e2, lookahead=2, error_estimator="reference", **kw)
+    np.testing.assert_array_equal(two.attribution, one.attribution)
+    assert e2.launched == 2 and e2.discarded == 1 and sum(e2.calls) == 32
     e2 = OracleEngine()
     two = ls_spa(*d, _engine=e2, lookahead=2, **kw)
     np.testing.assert_array_equal(two.attribution, one.attribution)
-    assert e2.launched == 2 and e2.discarded == 1 and sum(e2.calls) == 32
+    assert e2.launched == 1 and e2.discarded == 0 and sum(e2.calls) == 32
     # sources somebody else reads are not drawn ahead
     for kw in (dict(perms=iter(g["perms64"]), batch_size=16, tolerance=0.0),
                dict(max_samples=48, batch_size=16, tolerance=0.0, seed=3)):

@@ -8,7 +8,7 @@ cp $L/liblsspa_hip.so $L/keep.so
 for r in $(seq 1 ${AB_ROUNDS:-3}); do
   for v in old new; do
     cp $L/ab/$v.so $L/liblsspa_hip.so
-    timeout -k 10 300 python3 bench.py --steps 40 --warmup 5 --no-probe --no-ttt --no-cpu-baseline "$@" > $O/${v}_$r.json 2> $O/${v}_$r.err || (tail -20 $O/${v}_$r.err; cp $L/keep.so $L/liblsspa_hip.so; exit 1)
+    timeout -k 10 300 python3 bench.py --steps 40 --warmup 5 --no-probe --no-ttt --no-cpu-baseline --no-sustained "$@" > $O/${v}_$r.json 2> $O/${v}_$r.err || (tail -20 $O/${v}_$r.err; cp $L/keep.so $L/liblsspa_hip.so; exit 1)
     python3 - $v $r $O/${v}_$r.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[3]))
