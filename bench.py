@@ -818,6 +818,9 @@ def main():
             if got is not None:
                 legs["time_to_tolerance_e2e"] = dict(
                     got, h2d_included=True, tolerance=1e-2,
+                    default_error_estimator="device (what ls_spa(method='argsort') uses when error_estimator is not given: "
+                                            "the reference's code has no QMC method whose generator interleave could be "
+                                            "mirrored; 'reference' is the default of the seed / perms= paths)",
                     note="public ls_spa() on the host arrays of the timed region: engine creation, streamed reduction "
                          "over PCIe, sampling loop, estimator, final fit, teardown; " + breakdown_note)
         else:

@@ -52,9 +52,10 @@ int lsspa_synchronize(lsspa_ctx* ctx);
  * h = X_te^T y_te by one MFMA Gram pass each; when M < p the test rows themselves are
  * kept (transposed) as the test factor.  X pointers: row-major [rows][ld]; dtype applies to
  * X and y alike; location says whether the four pointers are host or device memory.
- * p is limited by the LDS of a CU (the gather stages one source row and the ordering: 12 B a feature of the padded
- * count, 160 KB): p <= 13567; a larger p is refused here with LSSPA_ERR_ARG and a message naming it (the reference
- * has no limit, ls_spa/ls_spa.py:163).
+ * p <= 32767 (32-bit element counts of one p x p work matrix); a larger p is refused here with LSSPA_ERR_ARG and a
+ * message naming it (the reference has no limit, ls_spa/ls_spa.py:163).  Up to p = 13567 the gather stages a whole
+ * source row and the ordering in the 160 KB of LDS of a CU; beyond that a segmented (slower) gather takes over, so that
+ * memory, not LDS, bounds the feature count.
  * Host arrays are never written and stay the caller's: they are read during the call only, through ordinary copies
  * (nothing of the caller's is ever page-locked: measured, the runtime's own pageable path is faster than registering
  * the arrays first).

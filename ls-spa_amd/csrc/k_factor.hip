@@ -117,11 +117,75 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
   }
 }
 
-// Largest feature count the per-ordering kernels take: the gather keeps one source row (8 B an entry in the fp64
-// path) and the ordering (4 B an entry) of p_pad entries in LDS, and a CU has 160 KB of it.
-int max_features() {
-  const int p_pad_max = (int)(LDS_BYTES_PER_CU / (sizeof(double) + sizeof(int32_t))) / 128 * 128;
-  return p_pad_max - 1;
+// The same gather for feature counts whose source row and ordering no longer fit the 160 KB of LDS of a CU
+// (12 B per padded feature: p > 13567).  The source row is staged in SEGMENTS of `seg` entries; for each segment the
+// workgroup walks the row's columns j <= i (the ordering is read from memory, coalesced) and writes the entries whose
+// source column lies in the segment.  Every output element is written exactly once, by element-wise stores: a slow
+// path (several passes over the columns per row) for shapes the fast kernel cannot take, so that p is bounded by HBM,
+// not by LDS (the reference has no limit, ls_spa/ls_spa.py:163).  Unpaired: every ordering is gathered on its own.
+template <typename T, typename ST>
+__global__ __launch_bounds__(256) void gather_seg_kernel(GatherArgs a, int seg) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  ST* rowbuf = reinterpret_cast<ST*>(smem_raw);                                  // [seg]
+  const int tid = threadIdx.x;
+  const int src = blockIdx.y / a.n_ord;
+  const int ord = blockIdx.y - src * a.n_ord;
+  const int mat = src * a.n_ord + ord;
+  const int i0 = blockIdx.x * GROWS;
+  const int p = a.p, p_pad = a.p_pad;
+  const int32_t* __restrict__ perm = a.perms + (int64_t)ord * p;
+  const ST* S;
+  if constexpr (sizeof(ST) == 8) S = reinterpret_cast<const ST*>(a.S[src]);
+  else S = reinterpret_cast<const ST*>(a.Sf[src]);
+  const double* svec = a.s[src];
+  T* out = static_cast<T*>(a.A) + (int64_t)mat * p_pad * p_pad;   // chunk-major, see tiles.h
+  double* d0 = a.diag0 + (int64_t)mat * p_pad;
+  for (int ii = 0; ii < GROWS; ++ii) {
+    const int i = i0 + ii;
+    if (i >= p_pad) break;
+    const int jend = min(((i + 1 + NB - 1) / NB) * NB, p_pad);  // zero-fill to the block edge
+    if (i < p) {
+      const int pi = perm[i];
+      const ST* srow = S + (int64_t)pi * a.ld_src;
+      for (int j = i + 1 + tid; j < jend; j += 256) out[cm_off(p_pad, i, j)] = (T)0;
+      for (int seg0 = 0; seg0 < p; seg0 += seg) {
+        const int n = min(seg, p - seg0);
+        __syncthreads();  // the previous segment's picks are done
+        for (int c = tid; c < n; c += 256) rowbuf[c] = srow[seg0 + c];
+        __syncthreads();
+        for (int j = tid; j <= i; j += 256) {
+          const int pj = perm[j] - seg0;
+          if (pj >= 0 && pj < n) out[cm_off(p_pad, i, j)] = (T)rowbuf[pj];
+        }
+      }
+      if (tid == 0) d0[i] = (double)srow[pi];
+    } else if (i == p) {
+      for (int j = tid; j < jend; j += 256)
+        out[cm_off(p_pad, i, j)] = (T)((j < p) ? svec[perm[j]] : (j == p ? a.aug[src] : 0.0));
+      if (tid == 0) d0[i] = a.aug[src];
+    } else {
+      for (int j = tid; j < jend; j += 256) out[cm_off(p_pad, i, j)] = (j == i) ? (T)1 : (T)0;
+      if (tid == 0) d0[i] = 1.0;
+    }
+  }
+}
+
+// Largest feature count the per-ordering kernels take.  The fast gather keeps one source row (8 B an entry in the fp64
+// path) and the ordering (4 B an entry) of p_pad entries in the 160 KB of LDS of a CU: p <= 13567; beyond that the
+// segmented gather above takes over, and what bounds p is memory -- and 32-bit element counts of one work matrix
+// (p_pad^2 < 2^31).
+int max_features() { return 32767; }
+
+template <typename T, typename ST>
+static hipError_t launch_gather_seg(const GatherArgs& a, hipStream_t st) {
+  static DynLdsGrant grant;   // one per instantiation
+  const int seg = (int)(128 * 1024 / sizeof(ST));
+  const size_t shmem = sizeof(ST) * (size_t)seg;
+  hipError_t e = grant.ensure(reinterpret_cast<const void*>(gather_seg_kernel<T, ST>), shmem);
+  if (e != hipSuccess) return e;
+  dim3 grid((a.p_pad + GROWS - 1) / GROWS, a.n_ord * a.n_src);
+  hipLaunchKernelGGL((gather_seg_kernel<T, ST>), grid, dim3(256), shmem, st, a, seg);
+  return hipGetLastError();
 }
 
 template <typename T, bool PAIRED, typename ST>
@@ -139,7 +203,11 @@ hipError_t launch_gather(const GatherArgs& a, hipStream_t st) {
     return hipErrorInvalidValue;
   const bool srcf = a.f32 && a.Sf[0] != nullptr && (a.n_src == 1 || a.Sf[1] != nullptr);
   const size_t shmem = (srcf ? sizeof(float) : sizeof(double)) * a.p_pad + sizeof(int32_t) * a.p_pad;
-  if (shmem > LDS_BYTES_PER_CU) return hipErrorInvalidValue;   // set_dims refuses such p (max_features)
+  if (shmem > LDS_BYTES_PER_CU) {   // the source row and the ordering do not fit a CU's LDS: segmented gather
+    if (srcf) return launch_gather_seg<float, float>(a, st);
+    if (a.f32) return launch_gather_seg<float, double>(a, st);
+    return launch_gather_seg<double, double>(a, st);
+  }
   dim3 grid((a.p_pad + GROWS - 1) / GROWS, (a.paired ? a.n_ord / 2 : a.n_ord) * a.n_src);
   // aug row reads sperm[j] for all j < p: the workgroup holding row p must have them all
   // (jmax = min(i0 + GROWS, p) = p there), so nothing else to arrange.

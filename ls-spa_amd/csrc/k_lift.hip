@@ -620,12 +620,15 @@ hipError_t launch_stats_merge(double* buf, double* state_n, double* mean, double
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(1024) void backsolve_kernel(const T* __restrict__ L, double* __restrict__ theta,
-                                                         int p, int p_pad) {
+                                                         int p, int p_pad, double* __restrict__ wg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* wv = reinterpret_cast<double*>(smem_raw);
+  // the running right-hand side: in LDS, or -- p beyond what LDS holds -- in the global workspace wg (one workgroup:
+  // its own writes are visible to it after a fence and a barrier)
+  double* wv = wg ? wg : reinterpret_cast<double*>(smem_raw);
   __shared__ double s_t;
   const int tid = threadIdx.x;
   for (int i = tid; i < p; i += 1024) wv[i] = (double)L[cm_off(p_pad, p, i)];
+  if (wg) __threadfence_block();
   __syncthreads();
   for (int j = p - 1; j >= 0; --j) {
     if (tid == 0) {
@@ -636,23 +639,30 @@ __global__ __launch_bounds__(1024) void backsolve_kernel(const T* __restrict__ L
     __syncthreads();
     const double t = s_t;
     for (int i = tid; i < j; i += 1024) wv[i] -= t * (double)L[cm_off(p_pad, j, i)];
+    if (wg) __threadfence_block();
     __syncthreads();
   }
 }
 
-hipError_t launch_backsolve(const void* A, double* theta, int p, int p_pad, int f32, hipStream_t st) {
+// wg: workspace of p doubles, used when p doubles do not fit a CU's LDS (may be null for smaller p)
+hipError_t launch_backsolve(const void* A, double* theta, int p, int p_pad, int f32, hipStream_t st, double* wg) {
   if (p < 1 || p_pad <= p) return hipErrorInvalidValue;
-  const size_t shmem = sizeof(double) * p;
-  if (shmem + 64 > LDS_BYTES_PER_CU) return hipErrorInvalidValue;   // set_dims refuses such p (max_features)
+  size_t shmem = sizeof(double) * p;
+  if (shmem + 64 > LDS_BYTES_PER_CU) {
+    if (!wg) return hipErrorInvalidValue;
+    shmem = 0;
+  } else {
+    wg = nullptr;
+  }
   static DynLdsGrant grant_f, grant_d;
   hipError_t e = f32 ? grant_f.ensure(reinterpret_cast<const void*>(backsolve_kernel<float>), shmem)
                      : grant_d.ensure(reinterpret_cast<const void*>(backsolve_kernel<double>), shmem);
   if (e != hipSuccess) return e;
   if (f32)
-    hipLaunchKernelGGL(backsolve_kernel<float>, dim3(1), dim3(1024), shmem, st, (const float*)A, theta, p, p_pad);
+    hipLaunchKernelGGL(backsolve_kernel<float>, dim3(1), dim3(1024), shmem, st, (const float*)A, theta, p, p_pad, wg);
   else
     hipLaunchKernelGGL(backsolve_kernel<double>, dim3(1), dim3(1024), shmem, st, (const double*)A, theta, p,
-                       p_pad);
+                       p_pad, wg);
   return hipGetLastError();
 }
 

@@ -50,7 +50,7 @@ struct GatherArgs {
                            // the source rows writes both matrices
 };
 hipError_t launch_gather(const GatherArgs& a, hipStream_t st);
-int max_features();   // largest p the per-ordering kernels take (LDS of the gather)
+int max_features();   // largest p the per-ordering kernels take (32-bit element counts of one work matrix)
 // dst[i] = (float)src[i]
 hipError_t launch_to_f32(const double* src, float* dst, int64_t count, hipStream_t st);
 
@@ -142,7 +142,9 @@ hipError_t launch_stats_pack(const double* buf, double* packed, int p, hipStream
 hipError_t launch_stats_unpack(const double* packed, double* buf, int p, hipStream_t st);
 
 // theta = L^-T z for the factor stored in A (identity ordering), single workgroup; theta is fp64
-hipError_t launch_backsolve(const void* A, double* theta, int p, int p_pad, int f32, hipStream_t st);
+// wg: workspace of p doubles for p beyond what a CU's LDS holds (may be null below that)
+hipError_t launch_backsolve(const void* A, double* theta, int p, int p_pad, int f32, hipStream_t st,
+                            double* wg = nullptr);
 
 // Gram contraction  C = Z^T Z, Z = [X | y]  (rows n, P1 = p + 1 columns), fp64 MFMA, split over rows
 struct GramArgs {

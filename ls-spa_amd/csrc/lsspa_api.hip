@@ -299,11 +299,12 @@ int set_dims(lsspa_ctx* ctx, int p, int m, int tri) {
   if (p < 1 || m < 1) return ctx->fail(LSSPA_ERR_ARG, "p and m must be positive");
   if (tri && m != p) return ctx->fail(LSSPA_ERR_ARG, "tri mode needs m == p");
   if (p > max_features()) {
-    // the reference has no limit (ls_spa/ls_spa.py:163); here the gather keeps a source row and the ordering in the
-    // 160 KB of LDS of a CU.  Refused now, by name, rather than at the first batch's launch.
+    // the reference has no limit (ls_spa/ls_spa.py:163); here one work matrix of p_pad^2 elements is indexed with 32
+    // bits in places.  Refused now, by name, rather than at the first batch's launch.  (Up to round 3 the limit was
+    // 13567: a source row and the ordering had to fit the LDS of a CU; the segmented gather lifted that.)
     char msg[160];
-    snprintf(msg, sizeof msg, "p = %d features exceeds the %d this engine supports (one source row and the ordering "
-             "must fit the 160 KB of LDS of a CU)", p, max_features());
+    snprintf(msg, sizeof msg, "p = %d features exceeds the %d this engine supports (32-bit element counts of one "
+             "p x p work matrix)", p, max_features());
     return ctx->fail(LSSPA_ERR_ARG, msg);
   }
   TRY(sync_all(ctx));  // buffers below may be re-allocated
@@ -1420,8 +1421,8 @@ int lsspa_full_fit(lsspa_ctx* ctx, double* theta, double* r_squared, int32_t* in
   if (info) *info = now;
   if (theta) {
     DevBuf<double> th;
-    TRY(dev_alloc(ctx, th, (size_t)p));
-    hipError_t e = launch_backsolve(ctx->lanes[0].A.ptr, th.ptr, p, ctx->p_pad, ctx->f32, ctx->stream);
+    TRY(dev_alloc(ctx, th, (size_t)2 * p));     // theta, and the running right-hand side when p exceeds the LDS
+    hipError_t e = launch_backsolve(ctx->lanes[0].A.ptr, th.ptr, p, ctx->p_pad, ctx->f32, ctx->stream, th.ptr + p);
     if (e == hipSuccess) e = hipMemcpyAsync(theta, th.ptr, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     dev_free(th);

@@ -33,6 +33,54 @@ from ._stats import error_estimates, error_estimates_lowrank
 
 _NO_CAP = 2 ** 100
 
+# ---- engines kept between calls ------------------------------------------------------------------------------------
+# ls_spa() needs a context on the GPU and, for large p, tens of GB of per-batch workspace (C5: 80 GB).  Creating and
+# releasing that on every call cost 2.3 of a C5 call's 2.9 seconds (profiles/r03_bench_c5.json: first_call_seconds
+# against 0.61 s of work).  One process per GPU is the deployment model and HBM is sized for it, so the engine of a
+# device -- context, stream, workspace -- stays alive between calls of one process and the next call of the same shape
+# finds its buffers in place (a different shape re-sizes them, as before).  ``release()`` frees everything at once;
+# LSSPA_ENGINE_CACHE=0 restores an engine per call.  A kept engine that is busy (another thread inside ls_spa on the same
+# device) is not shared: that call makes its own.  The reference keeps no state between calls either way: every
+# call resets the statistics, the history and the flags it touches.
+_engine_cache = {}
+
+
+def _acquire_engine(device):
+    """(engine, lock or None): a kept engine of this device if it is free, else a fresh one (lock None: caller closes it)."""
+    import threading
+    from ._engine import HipEngine
+    if os.environ.get("LSSPA_ENGINE_CACHE", "1") == "0":
+        return HipEngine(device), None
+    slot = _engine_cache.get(device)
+    if slot is None:
+        if not _engine_cache:
+            import atexit
+            atexit.register(release)
+        slot = _engine_cache[device] = {"engine": None, "lock": threading.Lock()}
+    if not slot["lock"].acquire(blocking=False):
+        return HipEngine(device), None
+    try:
+        if slot["engine"] is None or getattr(slot["engine"], "_h", None) is None:
+            slot["engine"] = HipEngine(device)
+        return slot["engine"], slot["lock"]
+    except BaseException:
+        slot["lock"].release()
+        raise
+
+
+def release(device=None):
+    """Close the engines ls_spa() keeps between calls (all of them, or one device's): frees their HBM."""
+    for dev, slot in list(_engine_cache.items()):
+        if device is not None and dev != device:
+            continue
+        if slot["lock"].acquire(blocking=False):
+            try:
+                if slot["engine"] is not None:
+                    slot["engine"].close()
+                slot["engine"] = None
+            finally:
+                slot["lock"].release()
+
 
 def _next_check(i, batch_size, max_samples):
     """Smallest index > i at which the reference evaluates the error estimate."""
@@ -490,12 +538,13 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
 
     comm = comm if comm is not None else _comm
     engine = _engine
-    owns = engine is None
+    owns = engine is None          # this call made (or borrowed) the engine: it also ends the communicator bound to it
+    kept = None                    # the lock of a borrowed, kept engine
     t0 = _time.perf_counter()
     if owns:
-        from ._engine import HipEngine
-        engine = HipEngine(device)
+        engine, kept = _acquire_engine(device)
     t0 = lap("engine_create", t0)
+    ok = False
     try:
         if comm is not None and hasattr(comm, "bind"):
             comm.bind(engine)      # RCCL communicator on this engine's GPU and stream (collective)
@@ -543,12 +592,21 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
                 pred = X_test.astype(np.float64) @ theta
                 r_squared = float((2.0 * (pred @ y_test) - pred @ pred) / yy)
         t0 = lap("final_fit", t0)
+        ok = True
     finally:
         t0 = _time.perf_counter()
         if owns:
-            if comm is not None and hasattr(comm, "close"):
-                comm.close()       # the communicator lives on the engine's context
-            engine.close()
+            try:
+                if comm is not None and hasattr(comm, "close"):
+                    comm.close()       # the communicator lives on the engine's context
+                if kept is None or not ok:
+                    engine.close()     # a kept engine an exception went through is not trusted with another call
+                else:
+                    engine.set_flags(0)
+                    engine.history_enable(0)
+            finally:
+                if kept is not None:
+                    kept.release()
         lap("teardown", t0)
     return ShapleyResults(attribution=attribution, theta=theta, overall_error=total_err,
                           attribution_errors=feat_err, r_squared=r_squared, error_history=err_hist,

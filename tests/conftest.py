@@ -22,6 +22,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of host BLAS beside the GPU work (still part of -m gpu)")
 
 
 @pytest.fixture(scope="session")

@@ -8,6 +8,7 @@ Stated fp64 tolerance: |lift_gpu - lift_ref| <= 1e-10 per ordering on benchmark-
 sample covariance is singular by construction, see test_oracle_golden.py).
 """
 import numpy as np
+import scipy.linalg as sla
 import pytest
 
 import lsspa_oracle as O
@@ -612,13 +613,49 @@ def test_feature_count_beyond_64kb_of_gather_lds():
         assert info == 0
         np.testing.assert_allclose(theta, np.linalg.lstsq(R, q, rcond=None)[0], rtol=1e-8, atol=1e-11)
         # beyond the supported count: refused at the reduction, with a message that names p
-        big = 13568
+        big = 32768
         z = np.zeros((big, big), dtype=np.float32)
         y = np.ones(big, dtype=np.float32)
         with pytest.raises(ValueError, match=f"p = {big} features exceeds"):
             eng.load_data(z, z, y, y, 0.0)
     finally:
         eng.close()
+
+
+@pytest.mark.slow
+def test_feature_count_beyond_the_lds_of_a_cu():
+    """p = 13700: a source row and the ordering (12 B a padded feature) no longer fit the 160 KB of LDS of a CU -- the
+    ceiling of rounds 1-3 (p <= 13567; the reference has none, ls_spa/ls_spa.py:163).  The segmented gather and the
+    back-substitution with its right-hand side in memory take over.  One ordering, fp32 per-ordering work, against
+    the oracle's QR-based lift on the same reduced problem (minutes of host BLAS: marked slow)."""
+    from ls_spa._engine import HipEngine
+    p, n = 13700, 27400
+    rng = np.random.default_rng(137)
+    Xa = rng.standard_normal((n, p), dtype=np.float32)
+    Xe = rng.standard_normal((n, p), dtype=np.float32)
+    w = (rng.standard_normal(p) / np.sqrt(p)).astype(np.float32)
+    ya = Xa @ w + rng.standard_normal(n, dtype=np.float32)
+    ye = Xe @ w + rng.standard_normal(n, dtype=np.float32)
+    perm = rng.permutation(p)
+    eng = HipEngine(0)
+    try:
+        eng.set_precision("float32")
+        eng.load_data(Xa, Xe, ya, ye, 1e-2)
+        assert eng.tri
+        got = eng.run_batch(perm[None, :].astype(np.int32), False, want_lifts=True, accumulate=False)[0]
+        theta, r2, info = eng.full_fit()
+        assert info == 0 and eng.info() == 0
+        G, g, H, h = eng.gram()           # the fp64 Gram reduction (pinned against numpy elsewhere) is the oracle's input
+        yy = eng.y_norm_sq
+    finally:
+        eng.close()
+    del Xa, Xe
+    assert abs(got.sum() - r2) < 1e-4      # every ordering's lifts sum to the full model's R^2
+    R, F = np.linalg.cholesky(G).T, np.linalg.cholesky(H).T
+    q, qt = sla.solve_triangular(R, g, trans="T"), sla.solve_triangular(F, h, trans="T")
+    want = O.ordering_lift(R, F, q, qt, yy, perm)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(theta, np.linalg.solve(G, g), rtol=2e-3, atol=2e-4)
 
 
 # ------------------------------------------------------------------ streamed reduction: caller memory in awkward places
