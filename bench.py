@@ -59,8 +59,10 @@ def parse():
                     help="steps whose orderings are launched as one GPU batch and then accumulated / all-reduced / merged "
                          "step by step (what ls_spa(lookahead=k) does); 0 = auto: 8 for p <= 126, 4 when a rank's step "
                          "has <= 32 samples, else 1")
-    ap.add_argument("--lanes", type=int, choices=(1, 2), default=1,
-                    help="batches in flight on the engine (lsspa_set_lanes): 2 = the next step's kernels run beside this one's")
+    ap.add_argument("--lanes", type=int, choices=(0, 1, 2), default=0,
+                    help="batches in flight on the engine (lsspa_set_lanes): 2 = the next step's kernels start when this "
+                         "step's are half way (two workspaces, two streams; statistics stay in batch order); 0 = auto: 2 on "
+                         "the general path (p > 126), 1 for the fused small-p kernel")
     ap.add_argument("--flags", type=int, default=0, help="developer switches of the engine (include/lsspa.h, lsspa_set_flags)")
     ap.add_argument("--no-probe", action="store_true", help="skip the strong-scaling probe (clean rocprof averages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -316,6 +318,8 @@ def main():
     fail_rank = os.environ.get("LSSPA_BENCH_FAIL_RANK")     # test hook: this rank dies after the warm-up steps
 
     p, rows, B = args.p, args.rows, args.batch_size
+    if args.lanes == 0:
+        args.lanes = 2 if p > 126 else 1
     reg = args.reg if args.reg is not None else (1e-2 if args.dtype == "f32" else 0.0)
     label = config_label(p, rows, args.dtype)
     if args.scaling == "strong" and B % world:

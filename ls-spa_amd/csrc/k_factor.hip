@@ -684,12 +684,13 @@ __global__ __launch_bounds__(256, 2) void chol_diag2_kernel(T* __restrict__ A, T
 //                      start from the factored TEST matrix Bt: -B[i][j] = -L_t[J0 + j][I0 + i].
 // Dm / diag0 are the slices of the matrix MJ.
 // s_a: >= 2 * 128 * RK_LD elements, s_b: >= 128 * RK_LD elements of LDS.
-template <typename T, int NT>
+template <typename T, int NT, bool XLAST = false>
 __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restrict__ MJ, const T* __restrict__ Bt,
                                             T* __restrict__ Dm, const double* __restrict__ diag0,
                                             double piv_tol, int32_t* __restrict__ info, const int p_pad, const int Jo,
-                                            const int tile, const int xt, const int p_live, T* const s_a,
+                                            const int tile, const int xt_arg, const int p_live, T* const s_a,
                                             T* const s_b, const int tid) {
+  const int xt = XLAST ? 1 : xt_arg;      // the last launch has X tiles only: the L-tile code drops out of its kernel
   typedef typename Tr<T>::acc_t acc_t;
   typedef typename Tr<T>::vec_t vec_t;
   constexpr int VE = Tr<T>::VE;
@@ -735,6 +736,12 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
   // them, let wave 3 skip six chunks of eight while wave 0 skipped none: the workgroup took the full time.)
   const int cb = xt ? I0 / KCH : 0;
   const int nch = J0 / KCH - cb;
+  // live 16-column tiles of the panel.  Only the X tiles of the LAST panel have fewer than eight (L tiles never sit in
+  // the last panel: it has no rows below it): columns j >= p_live of V^T belong to the augmented row and the identity
+  // padding, no lift reads them, and their accumulator tiles are left out of the k-loop.  XLAST is that launch's own
+  // instantiation of the kernel (X tiles only): the guard costs the other launches nothing -- in one kernel for both, the
+  // guarded copy of the loop cost the fp64 instance 288 B of scratch.
+  const int xlive = XLAST ? min(8, max(1, (p_live - J0 + 15) / 16)) : 8;
   constexpr int NEVER = 0x7fffffff;
   const int cstart[2] = {live[0] ? (xt ? rb[0] / KCH : 0) : NEVER, live[1] ? (xt ? rb[1] / KCH : 0) : NEVER};
   const T* srcJ = MJ + cm_off(p_pad, J0, KCH * cb);
@@ -822,7 +829,8 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
       for (int y = 0; y < YT; ++y)
         if (c >= cstart[y]) {
 #pragma unroll
-          for (int x = 0; x < 8; ++x) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
+          for (int x = 0; x < 8; ++x)
+            if (!XLAST || x < xlive) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
         }
     }
   }
@@ -1040,7 +1048,7 @@ struct Panel2Args {
   int grouped, p_live;
 };
 
-template <typename T, int NT>
+template <typename T, int NT, bool XLAST = false>
 __global__ __launch_bounds__(NT, (sizeof(T) == 4 && NT == 256) ? 3 : NT / 128) void chol_panel2_kernel(Panel2Args a) {
   __shared__ __attribute__((aligned(16))) T s_a[2 * 128 * RK_LD];
   __shared__ __attribute__((aligned(16))) T s_b[128 * RK_LD];
@@ -1088,12 +1096,12 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 4 && NT == 256) ? 3 : NT / 128) v
   T* const MJ = A + (int64_t)mt * pp2;
   T* const Dm = static_cast<T*>(a.Dinv) + (int64_t)mt * a.nblk * 4096;
   const double* const d0 = a.diag0 + (int64_t)mt * a.p_pad;
-  if (xt)
-    panel2_tile<T, NT>(static_cast<T*>(a.X) + (int64_t)mt * pp2, MJ, A + (int64_t)(n_ord + mt) * pp2, Dm, d0,
-                       a.piv_tol, a.info, a.p_pad, a.Jo, tile, 1, a.p_live, s_a, s_b, threadIdx.x);
+  if (XLAST || xt)
+    panel2_tile<T, NT, XLAST>(static_cast<T*>(a.X) + (int64_t)mt * pp2, MJ, A + (int64_t)(n_ord + mt) * pp2, Dm, d0,
+                              a.piv_tol, a.info, a.p_pad, a.Jo, tile, 1, a.p_live, s_a, s_b, threadIdx.x);
   else
-    panel2_tile<T, NT>(MJ, MJ, MJ, Dm, d0, a.piv_tol, a.info, a.p_pad, a.Jo, tile, 0, a.p_live, s_a, s_b,
-                       threadIdx.x);
+    panel2_tile<T, NT, false>(MJ, MJ, MJ, Dm, d0, a.piv_tol, a.info, a.p_pad, a.Jo, tile, 0, a.p_live, s_a, s_b,
+                              threadIdx.x);
 }
 
 // whole factorisation of n_mats matrices: one diagonal launch + (p_pad / 128 - 1) panel launches (+ one more, X tiles
@@ -1140,10 +1148,14 @@ hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double p
   const dim3 grid((unsigned)total);
   // 256 threads: 512-thread workgroups (16 rows per wave, twice the waves per SIMD) were measured
   // slower in both precisions -- the epilogue is bound by its memory traffic, not by latency
-  if (f32)
-    hipLaunchKernelGGL((chol_panel2_kernel<float, 256>), grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((chol_panel2_kernel<double, 256>), grid, dim3(256), 0, st, a);
+  const bool xlast = a.n_lt == 0 && p_live < p_pad - 15;     // X tiles only, and dead columns in the last panel
+  if (f32) {
+    if (xlast) hipLaunchKernelGGL((chol_panel2_kernel<float, 256, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((chol_panel2_kernel<float, 256, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (xlast) hipLaunchKernelGGL((chol_panel2_kernel<double, 256, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((chol_panel2_kernel<double, 256, false>), grid, dim3(256), 0, st, a);
+  }
   return hipGetLastError();
 }
 

@@ -367,6 +367,13 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
         per_rank = -(-int(batch_size) // comm.world)
         lookahead = max(1, min(8, 64 // max(per_rank, 1)))
     group = max(1, int(lookahead)) if (hasattr(engine, "launch_batch") and source.independent and not chunk_cap) else 1
+    # Two lanes (engine.lanes == 2, set by ls_spa() on the general path for the QMC samplers): successive groups run on
+    # two workspaces and two streams, the statistics on the context's own.  The next group is then launched as soon as
+    # the current one's last chunk is taken up -- BEFORE its statistics are read back: the read-back waits for the
+    # context's stream only, and the next group's kernels start when the current group's are half way (6.25 against
+    # 6.45 ms a step at the C3 shape).  A stop wastes at most that one group, which is discarded.
+    prefetch = (getattr(engine, "lanes", 1) == 2 and hasattr(engine, "launch_batch") and source.independent
+                and not chunk_cap)
     queue = []
 
     def refill(i_now):
@@ -389,7 +396,7 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
             if len(chunk) < want:
                 break
         ticket = None
-        if group > 1 and entries:
+        if (group > 1 or prefetch) and entries:
             mine_all = np.concatenate([e[1] for e in entries])
             if len(mine_all):
                 ticket = engine.launch_batch(mine_all, antithetical)
@@ -406,6 +413,8 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
             break
         chunk, mine, want, ticket, first = queue.pop(0)
         n_new = len(chunk)
+        if prefetch and not queue and ticket is not None and len(chunk) == want:
+            refill(i + n_new)      # the next group, on the other lane
         local = None
         if len(mine):
             if ticket is not None:
@@ -471,8 +480,8 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
 def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_size=2 ** 8,
            tolerance=1e-2, seed=42, perms=None, antithetical=True, return_attribution_history=False, *,
            method=None, num_batches=None, return_history=None, device=0, error_estimator=None,
-           precision="float64", row_sharded=False, checkpoint=None, comm=None, lookahead=1, _engine=None,
-           _comm=None, _timings=None):
+           precision="float64", row_sharded=False, checkpoint=None, comm=None, lookahead=1, lanes="auto",
+           _engine=None, _comm=None, _timings=None):
     """Estimates the Shapley attribution of the out-of-sample R^2 of a least-squares fit.
 
     Positional parameters, defaults and behaviour follow cvxgrp/ls-spa
@@ -503,6 +512,11 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         chunk by chunk in the reference's order and drops the chunks beyond a stop.  Same results; at most k
         chunks of wasted GPU work at the end of a run (none with error_estimator='device').  'auto': 1 when a rank's chunk has 64 samples or more, else as
         many chunks as make up 64 samples, eight at most.  Default 1 (every chunk its own launch).
+    lanes:  1, 2 or 'auto'.  2: successive chunk groups alternate between two workspaces on two HIP streams, the next
+        group's kernels starting when the current group's are half way, its orderings drawn and uploaded before the
+        current group's statistics are read back (QMC samplers only, as for lookahead; same results bit for bit; a
+        stop wastes at most one group of GPU work).  'auto': 2 for the QMC methods when p > 126 (the fused small-p
+        kernel gains nothing from it), else 1.
     comm:  several GPUs, one process each: the communicator every rank passes -- ``NativeComm.from_env()``
         (RCCL through the C ABI, no PyTorch) or ``TorchComm()`` (torch.distributed: RCCL, or gloo on CPU in
         the tests).  The orderings of every chunk are dealt round-robin over the ranks; the only data-path
@@ -552,6 +566,12 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
             engine.set_precision(precision)
         if lookahead != "auto" and int(lookahead) < 1:
             raise ValueError("lookahead must be >= 1 or 'auto'")
+        if lanes == "auto":
+            lanes = 2 if (perms is None and method in ("argsort", "permutohedron") and p > 126) else 1
+        if int(lanes) not in (1, 2):
+            raise ValueError("lanes must be 1, 2 or 'auto'")
+        if hasattr(engine, "set_lanes") and getattr(engine, "lanes", 1) != int(lanes):
+            engine.set_lanes(int(lanes))
         t0 = lap("setup", t0)
         prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
                                     antithetical=antithetical, method=method)
@@ -603,7 +623,7 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
                     engine.close()     # a kept engine an exception went through is not trusted with another call
                 else:
                     engine.set_flags(0)
-                    engine.history_enable(0)
+                    engine.history_enable(0)      # (the lanes stay as they are: the next call sets what it needs)
             finally:
                 if kept is not None:
                     kept.release()

@@ -622,6 +622,30 @@ def test_feature_count_beyond_64kb_of_gather_lds():
         eng.close()
 
 
+@pytest.mark.parametrize("estimator", ["reference", "device"])
+def test_two_lanes_in_the_driver_change_nothing(estimator):
+    """ls_spa(lanes=2): successive chunk groups on two workspaces and two streams, the next group launched before the
+    current one's statistics are read back.  Same kernels on the same orderings, statistics in chunk order on one
+    stream: every number of the one-lane run, bit for bit -- also when the stop rule drops a group launched ahead."""
+    d = O.gaussian_workload(150, 900, 800, seed=21)
+    kw = dict(reg=1e-3, method="argsort", seed=4, batch_size=16, max_samples=112, error_estimator=estimator)
+    one = ls_spa(*d, tolerance=0.0, lanes=1, **kw)
+    two = ls_spa(*d, tolerance=0.0, lanes=2, **kw)
+    auto = ls_spa(*d, tolerance=0.0, lookahead=3, **kw)        # lanes='auto' -> 2 at p = 150, groups of three chunks
+    for r in (two, auto):
+        np.testing.assert_array_equal(r.attribution, one.attribution)
+        np.testing.assert_array_equal(r.error_history, one.error_history)
+        np.testing.assert_array_equal(r.attribution_errors, one.attribution_errors)
+        assert r.r_squared == one.r_squared
+    assert len(one.error_history) == 8          # checks at 16 .. 96, at max_samples - 1 and the trailing one
+    tol = float(one.error_history[2]) * 1.0000001               # stops at the third check: a group in flight is dropped
+    if one.error_history[0] > tol and one.error_history[1] > tol:
+        a = ls_spa(*d, tolerance=tol, lanes=1, **kw)
+        b = ls_spa(*d, tolerance=tol, lanes=2, **kw)
+        assert len(a.error_history) == len(b.error_history) == 3
+        np.testing.assert_array_equal(a.attribution, b.attribution)
+
+
 @pytest.mark.slow
 def test_feature_count_beyond_the_lds_of_a_cu():
     """p = 13700: a source row and the ordering (12 B a padded feature) no longer fit the 160 KB of LDS of a CU -- the
