@@ -45,7 +45,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--p", type=int, default=1000)
     ap.add_argument("--rows", type=int, default=100000)
     ap.add_argument("--batch-size", type=int, default=128)
@@ -63,6 +63,10 @@ def parse():
                     help="batches in flight on the engine (lsspa_set_lanes): 2 = the next step's kernels start when this "
                          "step's are half way (two workspaces, two streams; statistics stay in batch order); 0 = auto: 2 on "
                          "the general path (p > 126), 1 for the fused small-p kernel")
+    ap.add_argument("--split", type=int, default=0,
+                    help="with two lanes: a step's batch goes to the engine as this many consecutive sub-batches (each its own "
+                         "launch sequence, alternating lanes): a shorter pipeline, so less fill / drain inside a K-step region; "
+                         "0 = auto")
     ap.add_argument("--flags", type=int, default=0, help="developer switches of the engine (include/lsspa.h, lsspa_set_flags)")
     ap.add_argument("--no-probe", action="store_true", help="skip the strong-scaling probe (clean rocprof averages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -449,8 +453,8 @@ def main():
         then folds its own b_rank lift vectors into the pending buffer, all-reduces and merges -- the reference's
         per-batch order, a fuller GPU.  Groups start at the first step of a region."""
 
-        def __init__(self, perms, b_rank, d):
-            self.perms, self.b_rank, self.d = perms, b_rank, d
+        def __init__(self, perms, b_rank, d, split=1):
+            self.perms, self.b_rank, self.d, self.split = perms, b_rank, d, split
             self.tickets, self.base, self.end = {}, 0, 0
 
         def region(self, k0, k1):
@@ -465,7 +469,11 @@ def main():
 
         def __call__(self, k):
             acc = True if multi else 2      # one rank: fold and merge at once (lsspa_lift_collect, accumulate = 2)
-            if self.d == 1:
+            if self.d == 1 and self.split > 1:
+                pk, h = self.perms[k], -(-self.b_rank // self.split)
+                for s0 in range(0, self.b_rank, h):
+                    eng.run_batch(pk[s0:s0 + h], True, want_lifts=False, accumulate=acc)
+            elif self.d == 1:
                 eng.run_batch(self.perms[k], True, want_lifts=False, accumulate=acc)
             else:
                 g, j = divmod(k - self.base, self.d)
@@ -506,7 +514,10 @@ def main():
             hi, lo = float(t[0].item()), -float(t[1].item())
         return mine, hi, lo
 
-    step = Steps(my_perms, B_rank, D)
+    # auto: two half-batches per step on the two lanes once a half still fills the chip (measured at C3, 20 steps: one
+    # launch sequence per step 6.37 ms, two 6.18, three 6.41, four 6.44; one lane 6.51)
+    SPLIT = args.split if args.split > 0 else (2 if (args.lanes == 2 and D == 1 and B_rank >= 64) else 1)
+    step = Steps(my_perms, B_rank, D, SPLIT)
 
     eng.set_lanes(args.lanes)
     # pass 1: the timed region proper (no events between the launches: an event record costs a
@@ -554,7 +565,7 @@ def main():
 
         import threading
         th = threading.Thread(target=ask_smi, daemon=True) if rank == 0 else None
-        sus_step = Steps(Cyclic(my_perms, args.warmup, total_steps), B_rank, D)
+        sus_step = Steps(Cyclic(my_perms, args.warmup, total_steps), B_rank, D, SPLIT)
         barrier()
         if th is not None:
             th.start()
@@ -672,6 +683,7 @@ def main():
                        "p": p, "N": rows, "M": rows, "reg": reg, "batch_size": B, "global_batch": B * world if
                        args.scaling == "weak" else B, "orderings_per_step_per_gpu": n_ord,
                        "path": "tri" if eng.tri else "rect", "collective": collective, "lanes": args.lanes, "lookahead": D,
+                       "launch_sequences_per_step": SPLIT,
                        "flags": args.flags,
                        "data_generator": ("BASELINE.md section 3: default_rng(0) on the host, moved to HBM before timing"
                                           if args.data == "gaussian" else
