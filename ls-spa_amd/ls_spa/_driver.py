@@ -135,7 +135,10 @@ def _min_norm_theta(G, g):
     return Q @ coef
 
 
-_CKPT_VERSION = 2
+# 3: the identity carries `history`, `precision` and `data`, the state `attribution_history` / `history_sum` (round 3);
+# a file of another version is refused by name instead of failing on a missing key.  With return_attribution_history the
+# whole n x p history is rewritten at every save (I/O quadratic in the run length): checkpoint long history runs sparsely.
+_CKPT_VERSION = 3
 
 
 def _ckpt_path(path, comm):

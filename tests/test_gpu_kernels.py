@@ -53,6 +53,15 @@ def test_gram_ragged_tiles_and_rows(engine, p, n, m, dt):
     Xa, Xe, ya, ye = (np.ascontiguousarray(a, dtype=dt) for a in (Xa, Xe, ya, ye))
     engine.load_data(Xa, Xe, ya, ye, 0.125)
     G, g, H, h = engine.gram()
+    # the other workgroup -> unit map (developer flag 65536: workgroup id = unit, no XCD-contiguous ranges) computes
+    # the same slabs: bit-identical Gram matrices
+    try:
+        engine.set_flags(65536)
+        engine.load_data(Xa, Xe, ya, ye, 0.125)
+        for a, b in zip(engine.gram(), (G, g, H, h)):
+            np.testing.assert_array_equal(a, b)
+    finally:
+        engine.set_flags(0)
     A64, E64, a64, e64 = (a.astype(np.float64) for a in (Xa, Xe, ya, ye))
     np.testing.assert_allclose(G, A64.T @ A64 / n + 0.125 * np.eye(p), rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(g, A64.T @ a64 / n, rtol=1e-12, atol=1e-12)

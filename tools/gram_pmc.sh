@@ -3,8 +3,8 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/gram_pmc; mkdir -p $O
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -o f -- python3 tools/gram_time.py c3 > $O/f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -o w -- python3 tools/gram_time.py c3 > $O/w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -o f -- python3 tools/gram_time.py ${GRAM_SHAPE:-c3} > $O/f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -o w -- python3 tools/gram_time.py ${GRAM_SHAPE:-c3} > $O/w.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 for tag, name in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
