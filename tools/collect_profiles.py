@@ -1,4 +1,4 @@
-"""Copy the artefacts of tools/r03_final.sh (python tools/collect_profiles.py r03) from gpurun_out/ (scratch) into profiles/ (tracked) and derive the
+"""Copy the artefacts of tools/r0N_final.sh (python tools/collect_profiles.py r04) from gpurun_out/ (scratch) into profiles/ (tracked) and derive the
 PMC traffic summaries.  Run in the build container after the gpurun call has merged its output."""
 import os
 import shutil
@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"      # round tag: gpurun_out/<tag>_final -> profiles/<tag>_*
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"      # round tag: gpurun_out/<tag>_final -> profiles/<tag>_*
 SRC = os.path.join(ROOT, "gpurun_out", f"{TAG}_final")
 DST = os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
@@ -18,8 +18,9 @@ def cp(src, dst):
 
 
 for name in ("bench_c3", "bench_c3_correlated", "bench_c2", "bench_c5", "bench_c3_f32", "bench_c3_rehearse",
-             "bench_c3_strong16_rehearse"):
-    cp(name + ".json", f"{TAG}_" + name + ".json")
+             "bench_c3_strong16_rehearse", "bench_c3_one_lane", "bench_c3_80steps", "bench_c3_two_ranks_one_gpu"):
+    if os.path.exists(os.path.join(SRC, name + ".json")):
+        cp(name + ".json", f"{TAG}_" + name + ".json")
 with open(os.path.join(DST, f"{TAG}_probes.log"), "w") as out:
     for title, f in (("tools/gram_time.py: the Gram reduction, both sides per line (C3: 2 x 1.003e11 flop; C5 per side as printed); "
                       "flags 0 = XCD-contiguous unit map, 65536 = natural map", "gram_time.log"),
@@ -27,7 +28,12 @@ with open(os.path.join(DST, f"{TAG}_probes.log"), "w") as out:
                       "the dispatches alternating between the two maps as in gram_time.py", "gram_pmc.log"),
                      ("tools/lat_probe.hip: dependent-chain latencies on the 16 x 16 elimination's critical path", "lat_probe.log"),
                      ("tools/small_probe.hip: phases of the fused small-p kernel (p = 100, 2048 orderings)", "small_probe.log"),
-                     ("tools/factor_probe.hip: phases of the 64 x 64 / 128 x 128 diagonal factorisations", "factor_probe.log")):
+                     ("tools/factor_probe.hip: phases of the 64 x 64 / 128 x 128 diagonal factorisations", "factor_probe.log"),
+                     ("tools/xtile_probe.hip: every 61st workgroup of the eight panel launches of a C3 step (L tiles, X tiles): "
+                      "start time in its launch and phase durations, us", "xtile_probe.log"),
+                     ("tools/host_reduce_probe.py: the streamed reduction from host arrays at the C3 shape", "host_reduce_probe.log")):
+        if not os.path.exists(os.path.join(SRC, f)):
+            continue
         out.write(f"## {title}\n" + "".join(l for l in open(os.path.join(SRC, f)) if "amdgpu.ids" not in l) + "\n")
 print(f"profiles/{TAG}_probes.log")
 if os.path.exists(os.path.join(SRC, "pmc_diag_summary.txt")):
@@ -35,12 +41,15 @@ if os.path.exists(os.path.join(SRC, "pmc_diag_summary.txt")):
     print(f"profiles/{TAG}_c3_pmc_diag.txt")
 # (config, p, batch, dtype, steps executed by the PMC runs = warm-up + timed + event pass)
 for cfg, p, b, dt, steps in (("c3", 1000, 128, "f64", 2 + 6 + 6), ("c5", 5000, 128, "f32", 1 + 3 + 3),
-                             ("c2", 100, 128, "f64", 8 + 16 + 16)):
+                             ("c2", 100, 128, "f64", 8 + 16 + 16)):   # (warm-up + timed + event pass; no sustained region: $P)
     if not os.path.exists(os.path.join(SRC, f"stats_{cfg}", f"{cfg}_kernel_stats.csv")):
         print(f"(no {cfg} artefacts in {SRC})")
         continue
     cp(f"stats_{cfg}/{cfg}_kernel_stats.csv", f"{TAG}_{cfg}_kernel_stats.csv")
     cp(f"stats_{cfg}.json", f"{TAG}_{cfg}_bench_under_rocprof.json")
+    if os.path.exists(os.path.join(SRC, f"stats_{cfg}l1", f"{cfg}l1_kernel_stats.csv")):     # the same command with --lanes 1
+        cp(f"stats_{cfg}l1/{cfg}l1_kernel_stats.csv", f"{TAG}_{cfg}_one_lane_kernel_stats.csv")
+        cp(f"stats_{cfg}l1.json", f"{TAG}_{cfg}_one_lane_bench_under_rocprof.json")
     cp(f"fetch_{cfg}/{cfg}_counter_collection.csv", f"{TAG}_{cfg}_pmc_fetch_size.csv")
     cp(f"write_{cfg}/{cfg}_counter_collection.csv", f"{TAG}_{cfg}_pmc_write_size.csv")
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"),
