@@ -281,6 +281,22 @@ def cpu_baseline(host, G, g, H, h, yy, p, reg, n_stop, n_checks, cov_at_stop, se
     return out
 
 
+def _keep_evidence():
+    """Any abnormal end of a rank (a fatal signal inside the HIP runtime or a kernel fault that aborts the process)
+    leaves a Python-level traceback of every thread in gpurun_out/bench_fault_rank<r>.log, beside whatever the
+    runtime printed on stderr (the advisor's round-3 finding: the one abort of round 2 left no evidence)."""
+    import faulthandler
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        fh = open(os.path.join(d, f"bench_fault_rank{os.environ.get('RANK', '0')}.log"), "w")
+        faulthandler.enable(file=fh, all_threads=True)
+        return fh
+    except Exception:
+        faulthandler.enable()
+        return None
+
+
 def main():
     args = parse()
     if (args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1
@@ -298,6 +314,7 @@ def main():
         if env["RANK"] == "0":
             print(json.dumps({"stub": True, "world": int(env["WORLD_SIZE"])}))
         return
+    _fault_log = _keep_evidence()     # (kept referenced: the handler writes to this file object)
     import torch
     import torch.distributed as dist
     from ls_spa import ls_spa
@@ -587,6 +604,20 @@ def main():
         step(k)
     barrier()
     prof = eng.profile_read()
+    # pass 3 (only when a step goes to the engine in several launch sequences): the same K steps once more as ONE launch
+    # sequence per step on one lane -- the dominant kernel at its full batch size, alone on the GPU.  This is the shape
+    # `rocprofv3 --stats -- python3 bench.py --lanes 1` shows (profiles/r0N_c3_one_lane_kernel_stats.csv): under the
+    # default command the profiler's averages mix the timed region's launches, which overlap across the two streams and
+    # are stretched by it, with this pass's.
+    prof_full = None
+    if SPLIT > 1:
+        eng.profile_reset()
+        full = Steps(my_perms, B_rank, D, 1)
+        full.region(args.warmup, total_steps)
+        for k in range(args.warmup, total_steps):
+            full(k)
+        barrier()
+        prof_full = eng.profile_read()
     eng.profile(False)
 
     # several ranks, weak line: the same K steps once more in BASELINE config 4's semantics -- the global batch of
@@ -667,11 +698,23 @@ def main():
         roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak_tf,
                     "unit": "TFLOP/s", "frac": ach / peak_tf, "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_flops_per_launch": flops, "avg_launch_ms": per_class[dom]["avg_launch_ms"],
+                    "launches_per_step": lpb,
                     "traffic_gbps": (traffic / (per_class[dom]["avg_launch_ms"] * 1e-3) / 1e9) if traffic else None,
                     "note": "peak = vendor fp64 (fp32) matrix figure; on random operands at the steady-state clock the "
                             "isolated k-loop of these kernels sustains ~60 TFLOP/s fp64 fed from HBM and ~67 fed from the "
                             "caches, the vendor library's GEMM 69-71 at 8192^3 and 59-67 batched at 1024^3 "
                             "(profiles/r02_kloop_ceiling.log)"}
+        if prof_full is not None and prof_full.get(dom, (0, 0))[1]:
+            ms_f, n_f = prof_full[dom]
+            lpb_f = n_f / args.steps
+            fl_f = algorithmic_flops(dom, p, n_ord, eng.tri, lpb_f, vt)
+            roofline["full_batch_one_lane"] = {
+                "avg_launch_ms": ms_f / n_f, "launches_per_step": lpb_f, "algorithmic_flops_per_launch": fl_f,
+                "achieved": fl_f / (ms_f / n_f * 1e-3) / 1e12, "frac": fl_f / (ms_f / n_f * 1e-3) / 1e12 / peak_tf,
+                "ms_per_step": ms_f / args.steps,
+                "note": "the same kernel with a step's batch as ONE launch sequence (what --lanes 1 runs and what rocprofv3 "
+                        "--stats of `bench.py --lanes 1` averages); the figures above are for the half-batch launches of "
+                        "the default pipeline, each alone on the GPU in the event pass"}
         out = {
             "metric": "orderings_per_sec", "value": value, "unit": "orderings/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -696,8 +739,9 @@ def main():
             "check": {"samples": int(n_seen), "sum_attribution": float(mean.sum())},
             "ms_per_step_min_rank": 1e3 * elapsed_min / args.steps,
             "sustained": sustained,
-            "timing_note": "value/ms_per_step: K steps without events; kernels/roofline: the same K steps "
-                           "repeated with a HIP-event pair around every launch on the engine's stream",
+            "timing_note": "value/ms_per_step: K steps without events (two lanes: launch sequences overlap across two "
+                           "streams); kernels/roofline: the same K steps repeated on ONE lane with a HIP-event pair around "
+                           "every launch on the engine's stream, i.e. each kernel alone on the GPU",
         }
         if "gather" in per_class:
             # 2 p^2 s bytes per ordering; a step's orderings may go in several launch sequences
@@ -716,11 +760,26 @@ def main():
         if probe is not None:
             probe["per_ordering_throughput_vs_full_step"] = probe["orderings_per_s"] / value
             out["strong_scaling_probe"] = probe
+        if "roofline_gather" in out and os.path.exists(pmc):
+            try:
+                for rec in json.load(open(pmc)).get("runs", []):
+                    if (rec.get("p"), rec.get("batch_size"), rec.get("dtype")) == (p, B_rank, args.dtype):
+                        g_tr = rec.get("hbm_bytes_per_launch", {}).get("gather")
+                        if g_tr:
+                            g_ms = per_class["gather"]["avg_launch_ms"]
+                            out["roofline_gather"].update(
+                                traffic=g_tr, physical_gbps=g_tr / (g_ms * 1e-3) / 1e9,
+                                physical_frac=g_tr / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                traffic_source="profiles/pmc_traffic.json (static; FETCH_SIZE x 2 + WRITE_SIZE of the last "
+                                               "profile refresh, not measured in this run)")
+            except Exception:
+                pass
         if "roofline_gather" in out:
             out["roofline_gather"]["note"] = (
                 "algorithmic bytes = SURVEY 8d's 2 p^2 s per ordering; by the PMC counters (profiles/*pmc_summary*) the kernel "
-                "moves fewer: the sources stay on chip and a pair shares a row -- at C3 3.56 GB per launch against 4.10 "
-                "algorithmic, i.e. the physical rate is 0.87 of the algorithmic one")
+                "moves fewer: the sources stay on chip and a pair shares a row -- at C3 3.58 GB per step against 4.10 "
+                "algorithmic, i.e. the physical rate (physical_frac, where the counters of this shape are on file) is 0.87 of "
+                "the algorithmic one")
         if multi:
             # did RCCL see N ranks: answered by RCCL (ncclCommCount through lsspa_comm_info), not by our bookkeeping
             rccl_world = None

@@ -20,6 +20,25 @@ for sub in ("ls-spa_amd", "oracle"):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _keep_evidence():
+    """A fatal signal in a GPU test (runtime abort, kernel fault) leaves the Python stacks of all threads in
+    gpurun_out/pytest_fault.log -- gpurun merges that directory back, so the next abort can be diagnosed from ONE run
+    (the suite is never looped to reproduce one)."""
+    import faulthandler
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        fh = open(os.path.join(d, "pytest_fault.log"), "w")
+        faulthandler.enable(file=fh, all_threads=True)
+        return fh
+    except Exception:
+        faulthandler.enable()
+        return None
+
+
+_FAULT_LOG = _keep_evidence()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: minutes of host BLAS beside the GPU work (still part of -m gpu)")
