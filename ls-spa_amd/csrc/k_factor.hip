@@ -494,10 +494,13 @@ __device__ __forceinline__ void factor_block64_core(T* __restrict__ M, int p_pad
   for (int kb = 0; kb < 4; ++kb) {
     T* const blk = s_t + (16 * kb) * DI_LD + 16 * kb;
     T* const inv = s_x + kb * 16 * XD_LD;
-    if (w == 0) {
+    if (w == (kb & 3)) {
       // the pivot chain is a sequence of DEPENDENT matrix instructions (two per pivot, a third of the pipe's time):
       // with priority over the co-resident workgroup's k-loop, which fills the pipe, each issues when it is ready
-      // instead of queueing behind independent work that can wait
+      // instead of queueing behind independent work that can wait.  The four chains of a 64 x 64 block go to the four
+      // waves in turn: the co-resident workgroup's waves meet at two barriers a chunk, so it runs at the pace of its
+      // slowest wave -- all four chains on wave 0 slowed ITS SIMD's neighbour, and with it the whole neighbour, four
+      // times as long as each SIMD's share does (6.40 -> 6.36 ms a C3 step; priority 0 instead of 3 here: no difference).
       __builtin_amdgcn_s_setprio(3);
       wave_factor16<T>(blk, inv, s_dd, __shfl(tol64, 16 * kb + (lane & 15)), lane, bad);
       __builtin_amdgcn_s_setprio(0);
@@ -559,7 +562,7 @@ __device__ __forceinline__ void factor_block64_core(T* __restrict__ M, int p_pad
     }
   }
   FSTAMP(14);
-  if (w == 0 && bad && lane == 0) atomicOr(&info[0], 1);
+  if (bad && lane == 0) atomicOr(&info[0], 1);
 }
 
 template <typename T, int NT>
