@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--no-probe", action="store_true", help="skip the strong-scaling probe (clean rocprof averages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 3 s sustained-rate region")
+    ap.add_argument("--no-full-pass", action="store_true",
+                    help="skip the third pass (full-batch launches on one lane): profiler runs, where every launch of a "
+                         "kernel should have the timed region's size")
     ap.add_argument("--no-ttt", action="store_true", help="skip the time-to-tolerance runs")
     ap.add_argument("--data", choices=("gaussian", "correlated"), default="gaussian",
                     help="gaussian: BASELINE.md section 3 (default_rng(0)), the data the metric is quoted on; correlated: "
@@ -610,7 +613,7 @@ def main():
     # default command the profiler's averages mix the timed region's launches, which overlap across the two streams and
     # are stretched by it, with this pass's.
     prof_full = None
-    if SPLIT > 1:
+    if SPLIT > 1 and not args.no_full_pass:
         eng.profile_reset()
         full = Steps(my_perms, B_rank, D, 1)
         full.region(args.warmup, total_steps)
@@ -690,6 +693,11 @@ def main():
                 for rec in json.load(open(pmc)).get("runs", []):
                     if (rec.get("p"), rec.get("batch_size"), rec.get("dtype")) == (p, B_rank, args.dtype):
                         traffic = rec.get("hbm_bytes_per_launch", {}).get(dom)
+                        # the counters were collected with the launch sizes of the default pipeline: per launch of THIS
+                        # run = per step there / launches per step here
+                        rec_lps = rec.get("launches_per_step", {}).get(dom)
+                        if traffic and rec_lps:
+                            traffic = traffic * rec_lps / lpb
                         traffic_src = ("profiles/pmc_traffic.json (static): FETCH_SIZE x 2 + WRITE_SIZE from separate "
                                        "rocprofv3 --pmc passes of bench.py, collected when the profiles were last refreshed "
                                        "-- NOT measured in this run")
@@ -765,6 +773,9 @@ def main():
                 for rec in json.load(open(pmc)).get("runs", []):
                     if (rec.get("p"), rec.get("batch_size"), rec.get("dtype")) == (p, B_rank, args.dtype):
                         g_tr = rec.get("hbm_bytes_per_launch", {}).get("gather")
+                        g_lps = rec.get("launches_per_step", {}).get("gather")
+                        if g_tr and g_lps:
+                            g_tr = g_tr * g_lps / max(per_class["gather"]["launches_per_step"], 1.0)
                         if g_tr:
                             g_ms = per_class["gather"]["avg_launch_ms"]
                             out["roofline_gather"].update(

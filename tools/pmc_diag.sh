@@ -2,7 +2,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmc_diag; rm -rf $O; mkdir -p $O
-P="--steps 3 --warmup 1 --no-probe --no-ttt --no-cpu-baseline"
+P="--steps 3 --warmup 1 --no-probe --no-ttt --no-cpu-baseline --no-sustained --no-full-pass --lanes 1"
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --output-format csv -d $O/a -o a -- python3 bench.py $P > $O/a.json 2> $O/a.err
 echo a done
 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $O/b -o b -- python3 bench.py $P > $O/b.json 2> $O/b.err

@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--steps", type=int, required=True, help="steps the profiled run executed (warm-up + timed + event pass)")
     args = ap.parse_args()
     fetch, write = load(args.fetch), load(args.write)
-    rows, per_class = [], {}
+    rows, per_class, per_class_lps = [], {}, {}
     for k in sorted(fetch, key=lambda k: -sum(fetch[k])):
         n = len(fetch[k])
         f_raw, w = sum(fetch[k]), sum(write.get(k, [0.0]))
@@ -59,6 +59,7 @@ def main():
         rows.append((k, n, f_raw, 2.0 * f_raw, w, total / n, 0.0 if k in ONE_TIME else total / args.steps))
         if k in CLASS_OF:
             per_class[CLASS_OF[k]] = total / n
+            per_class_lps[CLASS_OF[k]] = n / args.steps
     out_csv = os.path.join(ROOT, "profiles", f"{args.tag}_pmc_summary_{args.label}.csv")
     with open(out_csv, "w") as fh:
         fh.write("kernel,launches,FETCH_SIZE_bytes_raw,fetch_bytes_corrected_x2,WRITE_SIZE_bytes,"
@@ -78,6 +79,7 @@ def main():
                                   "--no-probe --no-ttt --no-cpu-baseline; tools/pmc_summary.py; FETCH_SIZE doubled "
                                   "(gfx950 16-B/lane correction); fabric-side bytes, Infinity-Cache hits included",
                         "hbm_bytes_per_launch": per_class,
+                        "launches_per_step": per_class_lps,
                         "bytes_per_step": sum(r[6] for r in rows)})
     json.dump(doc, open(path, "w"), indent=1)
     for r in rows:

@@ -3,7 +3,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04_final; mkdir -p $O
 PART=${1:-all}
-P="--no-probe --no-ttt --no-cpu-baseline --no-sustained"
+P="--no-probe --no-ttt --no-cpu-baseline --no-sustained --no-full-pass"
 if [ "$PART" = "all" ] || [ "$PART" = "a" ]; then
 python3 tools/gram_time.py > $O/gram_time.log 2>&1
 ./tools/bin/lat_probe > $O/lat_probe.log 2>&1
@@ -26,6 +26,8 @@ LSSPA_BENCH_REHEARSE_WORLD=2 python3 bench.py --gpus 2 --steps 20 --warmup 5 --n
 LSSPA_BENCH_REHEARSE_DIST=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c3_rehearse.json 2> $O/bench_c3_rehearse.err
 LSSPA_BENCH_REHEARSE_DIST=1 python3 bench.py --steps 40 --warmup 8 --batch-size 16 --scaling strong --no-cpu-baseline --no-ttt > $O/bench_c3_strong16_rehearse.json 2> $O/bench_c3_strong16_rehearse.err
 echo bench done
+fi
+if [ "$PART" = "all" ] || [ "$PART" = "a" ] || [ "$PART" = "s" ]; then
 # the same command under the profiler (program directly after --), without the legs that launch other shapes
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -o c3 -- python3 bench.py --steps 20 --warmup 5 $P > $O/stats_c3.json 2> $O/stats_c3.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3l1 -o c3l1 -- python3 bench.py --steps 20 --warmup 5 --lanes 1 $P > $O/stats_c3l1.json 2> $O/stats_c3l1.err
