@@ -915,7 +915,10 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
   asm volatile("" : "+s"(ws_e));
   const int rb_e[2] = {16 * ws_e, 16 * (7 - ws_e)};
   // Store L[I, panel] through the output buffer, one 16-column chunk at a time (a contiguous 128 x 16
-  // block in the chunk-major layout).
+  // block in the chunk-major layout).  (Round 4, measured and not kept: the accumulators stored straight to memory --
+  // an fp64 register is 32 contiguous bytes over four lanes, sixteen rows an instruction; no barrier, no LDS round
+  // trip, and 6.51 against 6.20 ms a C3 step: the 32-byte pieces cost the memory system more than sixteen barriers cost
+  // the tile.)
   typedef RKRegs<T, 128, NT> RR;
   const int sc = tid % RR::VPR, srow = tid / RR::VPR;
 #pragma unroll
