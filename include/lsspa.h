@@ -218,14 +218,15 @@ int lsspa_profile_get(lsspa_ctx* ctx, int32_t kernel_class, double* total_ms, in
 int lsspa_profile_reset(lsspa_ctx* ctx);
 
 /* developer switches for in-process A/B timing and cross-checks of kernel variants (0 = shipped configuration):
- *    32  two half-batches on two streams               64  plain (matrix, tile) dispatch order in the panel kernel
+ *    64  plain (matrix, tile) dispatch order in the panel kernel
  *   128  tri mode: V by the strip kernel (the shipped path of rect mode) instead of V^T by the panel launches' X tiles
  *   256  unpaired gather                             1024  general path also for small problems (p + 1 <= 128
  *  2048  no skipping of the all-padding 16 x 16 tiles       normally takes the fused one-workgroup kernel)
  * 16384  small problems: the LDS-resident kernel also where the register-resident one applies (p + 1 <= 112)
  * 65536  Gram kernel: workgroup id = unit (the units of a row slice spread over the XCDs instead of sharing one L2)
  * Every combination computes the same lifts (tests/test_gpu_kernels.py).  Rounds 1-3 carried more (one-level kernels,
- * whole-factorisation kernel, 256-column strips, page-locking of caller memory): measured slower, removed in round 4. */
+ * whole-factorisation kernel, 256-column strips, two half-batches on two streams of one lane, page-locking of caller
+ * memory): measured slower or superseded, removed in round 4. */
 int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);
 
 /* test hooks */

@@ -66,8 +66,6 @@ struct Lane {
   bool perms_used_valid[2] = {false, false};
   const int32_t* perms_cur = nullptr;              // device slot of the batch being launched
   // second stream for the two-slice schedule of a batch (developer flag 32)
-  hipStream_t side_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // two-lane hand-offs
   hipEvent_t ev_mid = nullptr, ev_done = nullptr, ev_consumed = nullptr, ev_main = nullptr;
   bool mid_valid = false, done_valid = false, consumed_valid = false;
@@ -289,7 +287,6 @@ int sync_all(lsspa_ctx* ctx) {
   for (Lane& L : ctx->lanes) {
     if (L.st) HIPCHK(hipStreamSynchronize(L.st));
     if (L.copy_stream) HIPCHK(hipStreamSynchronize(L.copy_stream));
-    if (L.side_stream) HIPCHK(hipStreamSynchronize(L.side_stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return LSSPA_OK;
@@ -641,27 +638,11 @@ int ensure_f32_sources(lsspa_ctx* ctx) {
   return mark_problem(ctx);
 }
 
-// Run gather -> factorisation -> strip -> lift for n_ord orderings already resident in perms_d.
-// lifts for sample s land in lifts_d[(s_off + s)][p].  With developer flag 32 a large batch is cut into
-// two slices on two streams (the launches of a slice depend on each other, so while one slice drains the
-// tail of a launch the other slice's workgroups take the idle CUs).
+// Run gather -> factorisation (with V^T) -> lift for n_ord orderings already resident in perms_d.
+// lifts for sample s land in lifts_d[(s_off + s)][p].  (Rounds 1-3 could cut a batch into two slices on two streams of
+// ONE lane, developer flag 32, +0.8 %; the two lanes of round 4 do that across batches and better -- removed.)
 int run_orderings(lsspa_ctx* ctx, Lane& L, int n_ord, int per_sample, int s_off) {
-  const hipStream_t st = ctx->lane_stream(L);
-  const int half = ((n_ord / 2) / per_sample) * per_sample;
-  // opt-in (developer flag 32): measured gain 0.8 % at p = 1000 -- not worth two launch shapes per kernel in the traces
-  if (ctx->prof_on || !(ctx->flags & 32) || half < 32) return run_slice(ctx, L, 0, n_ord, per_sample, s_off, st);
-  if (!L.side_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&L.side_stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
-  }
-  HIPCHK(hipEventRecord(L.ev_fork, st));          // the orderings are on the device
-  HIPCHK(hipStreamWaitEvent(L.side_stream, L.ev_fork, 0));
-  TRY(run_slice(ctx, L, 0, half, per_sample, s_off, st));
-  TRY(run_slice(ctx, L, half, n_ord - half, per_sample, s_off + half / per_sample, L.side_stream));
-  HIPCHK(hipEventRecord(L.ev_join, L.side_stream));
-  HIPCHK(hipStreamWaitEvent(st, L.ev_join, 0));
-  return LSSPA_OK;
+  return run_slice(ctx, L, 0, n_ord, per_sample, s_off, ctx->lane_stream(L));
 }
 
 // Stage `count` orderings (with their reverses when per_sample == 2) on lane L and run them.
@@ -947,11 +928,6 @@ int lsspa_destroy(lsspa_ctx* ctx) try {
     if (L.copy_stream) {
       (void)hipStreamDestroy(L.copy_stream);
       for (int b = 0; b < 2; ++b) (void)hipEventDestroy(L.perms_used[b]);
-    }
-    if (L.side_stream) {
-      (void)hipStreamDestroy(L.side_stream);
-      (void)hipEventDestroy(L.ev_fork);
-      (void)hipEventDestroy(L.ev_join);
     }
     if (L.ev_done) {
       (void)hipEventDestroy(L.ev_mid);
