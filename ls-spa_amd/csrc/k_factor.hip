@@ -687,6 +687,10 @@ __global__ __launch_bounds__(256, 2) void chol_diag2_kernel(T* __restrict__ A, T
 //                      start from the factored TEST matrix Bt: -B[i][j] = -L_t[J0 + j][I0 + i].
 // Dm / diag0 are the slices of the matrix MJ.
 // s_a: >= 2 * 128 * RK_LD elements, s_b: >= 128 * RK_LD elements of LDS.
+// Timing-only builds (developer: LSSPA_CXXFLAGS=-DLSSPA_T_NOINIT python ls-spa_amd/build.py --force --out ...,
+// tools/variants_bench.sh): LSSPA_T_NOINIT / NOKLOOP / NOLOADS / NOMFMA / NOSOLVE / NOSTORE / NOUPDATE / NOFACTOR compile
+// ONE phase of the tile out and leave the launch structure, the dispatch and every other phase as they are.  The results
+// of such a build are garbage; what it shows is what the phase costs the step.
 template <typename T, int NT, bool XLAST = false>
 __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restrict__ MJ, const T* __restrict__ Bt,
                                             T* __restrict__ Dm, const double* __restrict__ diag0,
@@ -765,7 +769,13 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
 
   // acc[x][y][r] <-> (panel column j = 16 x + acc_row(l4, r), tile row i = RW w + 16 y + l15); holds -C^T.
   acc_t acc[8][YT];
-  if (xt) {
+#ifdef LSSPA_T_NOINIT
+  constexpr bool T_INIT = false;
+  for (int x = 0; x < 8; ++x) for (int y = 0; y < YT; ++y) acc[x][y] = Tr<T>::zero();
+#else
+  constexpr bool T_INIT = true;
+#endif
+  if (xt && T_INIT) {
     // -B[i][j] = -L_t[J0 + j][I0 + i]: sixteen lanes read sixteen consecutive columns of one row of L_t (one 128-byte
     // piece of a chunk): accumulator layout as it stands.  On the diagonal tile (I0 == J0) the entries above L_t's
     // diagonal are not part of the factor (the upper right 64 x 64 block of a diagonal block is never written):
@@ -782,7 +792,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
         }
       if (x & 1) __builtin_amdgcn_sched_barrier(0);
     }
-  } else {
+  } else if (T_INIT) {
     // (Round 3, measured and not kept: -A^T entering through the matrix pipe instead -- the tile's own eight chunks
     // staged like the k-loop's operands and multiplied by -I, no transposition in front of the k-loop: 4.05 against
     // 3.98 ms of panel time per C3 step in alternating processes on one box.)
@@ -819,12 +829,20 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
   }
 
   PSTAMP(1);
+#ifdef LSSPA_T_NOKLOOP
+  for (int it = 0, c = c_first; it < 0; ++it, c += c_step) {
+#else
   for (int it = 0, c = c_first; it < nch; ++it, c += c_step) {
+#endif
     __syncthreads();
     rk_store<T, 128, NT>(rj, s_rkj, tid);
     rk_store<T, 128, NT>(ri, s_rki, tid);
     __syncthreads();
+#ifdef LSSPA_T_NOLOADS
+    if (false) {
+#else
     if (it + 1 < nch) {
+#endif
       rk_load_full<T, 128, NT>(rj, srcJ + (c + c_step) * chunk, CM_LD, tid);
       rk_load_full<T, 128, NT>(ri, srcI + (c + c_step) * chunk, CM_LD, tid);
     }
@@ -840,7 +858,11 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
         if (c >= cstart[y]) {
 #pragma unroll
           for (int x = 0; x < 8; ++x)
+#ifdef LSSPA_T_NOMFMA
+            if (!XLAST || x < xlive) acc[x][y][0] += av[x] * bv[y];
+#else
             if (!XLAST || x < xlive) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
+#endif
         }
     }
   }
@@ -875,6 +897,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
   // Each 64 x 64 operand block of the solve is fetched into registers one stage ahead and put into LDS when
   // the previous stage is done with the region.
   const T* Dg = Dm + (int64_t)(2 * Jo) * 4096;
+#ifndef LSSPA_T_NOSOLVE
   DenseBlock64Regs<T, NT> nb;
   block64_fetch<T, NT>(nb, Dg, tid);
   __syncthreads();  // every wave is done with the operand tiles that region A now loses
@@ -907,6 +930,10 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
   block64_put<T, NT>(nb, s_dinv, tid);
   __syncthreads();
   tri_mult(1);
+#else
+  (void)Dg; (void)tri_mult;
+  __syncthreads();
+#endif
 
   PSTAMP(3);
   // the wave's row bases once more, from a copy of the wave index the compiler cannot see through: otherwise the store
@@ -921,8 +948,17 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
   // the tile.)
   typedef RKRegs<T, 128, NT> RR;
   const int sc = tid % RR::VPR, srow = tid / RR::VPR;
+#ifdef LSSPA_T_NOSTORE
+  {
+    T sum = (T)0;
+    for (int x = 0; x < 8; ++x) for (int y = 0; y < YT; ++y) for (int r = 0; r < 4; ++r) sum += acc[x][y][r];
+    if (sum == (T)1.2345e-67) M[cm_off(p_pad, I0, J0)] = sum;
+  }
+  for (int xp = 0; xp < 0; ++xp) {
+#else
 #pragma unroll
   for (int xp = 0; xp < 8; ++xp) {
+#endif
     if (xp > 0) __syncthreads();
 #pragma unroll
     for (int y = 0; y < YT; ++y)
@@ -1019,7 +1055,11 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
       }
     }
   };
+#ifdef LSSPA_T_NOUPDATE
+  if (false)
+#else
   if (tile == 0 && !xt)
+#endif
   switch (ws) {     // scalar: the wave index
     case 0: diag_update(std::integral_constant<int, 0>()); break;
     case 1: diag_update(std::integral_constant<int, 1>()); break;
@@ -1035,7 +1075,11 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
 
   // Tile 0 is the next panel's diagonal block and has just received its last update: factor it here,
   // the latency-bound sweep overlaps with the other workgroups' MFMA work.
+#ifdef LSSPA_T_NOFACTOR
+  if (false) {
+#else
   if (tile == 0 && !xt) {
+#endif
     __threadfence_block();
     __syncthreads();
     factor_diag128<T, NT>(M, p_pad, I0, Dm + (int64_t)(2 * (Jo + 1)) * 4096, diag0, piv_tol, info, s_a, s_b, tid);

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512) void small_p_kernel(SmallArgs a) {
       } else {
         const int me = (w + 3 - fw) % 4 - 0;      // 0, 1, 2 among the three helpers
         if (kb == 0) HSTAMP(0);
-        int hs = 1;
+        [[maybe_unused]] int hs = 1;
         int To[4], Ao[4], Bo[4];
         int have = 0, tcount = 0;
         for (int ib = kb + 2; ib < nb; ++ib)       // row kb + 1 holds (kb+1, kb+1) only: the factoring wave's

@@ -8,7 +8,7 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 typedef int i16 __attribute__((ext_vector_type(16)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_i8_16(int* out, long long* cyc, int iters, int seed) {
+__global__ __launch_bounds__(512) void k_i8_16(int* out, long long* cyc, int iters, int seed) {
   i4 acc[8];
   for (int i = 0; i < 8; ++i) acc[i] = i4{0, 0, 0, 0};
   i4 a = {seed + (int)threadIdx.x, seed * 3, seed * 5, seed * 7}, b = {seed * 11, seed * 13, (int)threadIdx.x, seed};
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_i8_16(int* out, long long* cyc, int ite
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-__global__ __launch_bounds__(256) void k_i8_32(int* out, long long* cyc, int iters, int seed) {
+__global__ __launch_bounds__(512) void k_i8_32(int* out, long long* cyc, int iters, int seed) {
   i16 acc[4];
   for (int i = 0; i < 4; ++i)
     for (int e = 0; e < 16; ++e) acc[i][e] = 0;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_i8_32(int* out, long long* cyc, int ite
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-__global__ __launch_bounds__(256) void k_f64(double* out, long long* cyc, int iters, double a0, double b0) {
+__global__ __launch_bounds__(512) void k_f64(double* out, long long* cyc, int iters, double a0, double b0) {
   d4 acc[8];
   for (int i = 0; i < 8; ++i) acc[i] = d4{0, 0, 0, 0};
   double a = a0 + threadIdx.x * 1e-9, b = b0;
