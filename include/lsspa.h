@@ -34,6 +34,7 @@ extern "C" {
 
 /* info bit flags (lsspa_get_info) */
 #define LSSPA_INFO_NOT_PD 1 /* a non-positive pivot was met in a Cholesky step */
+#define LSSPA_INFO_SCAN_WAIT 4 /* an X tile gave up waiting for row p of its panel (fused lift scan): results invalid */
 
 typedef struct lsspa_ctx lsspa_ctx;
 
@@ -220,6 +221,7 @@ int lsspa_profile_reset(lsspa_ctx* ctx);
 /* developer switches for in-process A/B timing and cross-checks of kernel variants (0 = shipped configuration):
  *    64  plain (matrix, tile) dispatch order in the panel kernel
  *   128  tri mode: V by the strip kernel (the shipped path of rect mode) instead of V^T by the panel launches' X tiles
+ *   512  tri mode: the lift kernel reads V^T back and scans it, instead of the X tiles scanning their own blocks
  *   256  unpaired gather                             1024  general path also for small problems (p + 1 <= 128
  *  2048  no skipping of the all-padding 16 x 16 tiles       normally takes the fused one-workgroup kernel)
  * 16384  small problems: the LDS-resident kernel also where the register-resident one applies (p + 1 <= 112)

@@ -687,6 +687,18 @@ __global__ __launch_bounds__(256, 2) void chol_diag2_kernel(T* __restrict__ A, T
 //                      start from the factored TEST matrix Bt: -B[i][j] = -L_t[J0 + j][I0 + i].
 // Dm / diag0 are the slices of the matrix MJ.
 // s_a: >= 2 * 128 * RK_LD elements, s_b: >= 128 * RK_LD elements of LDS.
+// What an X tile needs to scan its own block of V^T for the lifts before it leaves the chip (fused lift scan, below);
+// for an L tile of the last block row: the flag it raises when row p of its panel (z, or y~ in a test matrix) is final.
+struct TileLift {
+  int32_t* raise;          // L tile of the last block row: &flags[matrix]; else null
+  const int32_t* fz;       // X tile: flag of the ordering's training matrix (z of this panel final)
+  const int32_t* fy;       // X tile: flag of the ordering's test matrix (y~ of this panel final; diagonal tile only)
+  double* run;             // [p_pad] running N of the ordering, carried from panel to panel
+  double* P;               // [blocks][p_pad] partial sums of the ordering, one row per row block of V^T
+  int p;                   // features
+  int mode;                // 0: no scan (the lift kernel reads V^T back); 1: scan; 2: scan, last panel's V^T not stored
+};
+
 // Timing-only builds (developer: LSSPA_CXXFLAGS=-DLSSPA_T_NOINIT python ls-spa_amd/build.py --force --out ...,
 // tools/variants_bench.sh): LSSPA_T_NOINIT / NOKLOOP / NOLOADS / NOMFMA / NOSOLVE / NOSTORE / NOUPDATE / NOFACTOR compile
 // ONE phase of the tile out and leave the launch structure, the dispatch and every other phase as they are.  The results
@@ -695,8 +707,8 @@ template <typename T, int NT, bool XLAST = false>
 __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restrict__ MJ, const T* __restrict__ Bt,
                                             T* __restrict__ Dm, const double* __restrict__ diag0,
                                             double piv_tol, int32_t* __restrict__ info, const int p_pad, const int Jo,
-                                            const int tile, const int xt_arg, const int p_live, T* const s_a,
-                                            T* const s_b, const int tid) {
+                                            const int tile, const int xt_arg, const int p_live, const TileLift& tl,
+                                            T* const s_a, T* const s_b, const int tid) {
   const int xt = XLAST ? 1 : xt_arg;      // the last launch has X tiles only: the L-tile code drops out of its kernel
   typedef typename Tr<T>::acc_t acc_t;
   typedef typename Tr<T>::vec_t vec_t;
@@ -869,6 +881,25 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
 
 
   PSTAMP(2);
+  // the wave's row bases once more, from a copy of the wave index the compiler cannot see through: otherwise the store
+  // loop's LDS addresses are computed ahead of the k-loop and carried -- spilled -- through it
+  int ws_e = ws;
+  asm volatile("" : "+s"(ws_e));
+  const int rb_e[2] = {16 * ws_e, 16 * (7 - ws_e)};
+  // the store's and the fused lift scan's bookkeeping (both described at the store, below)
+  constexpr int VPR16 = 16 / VE, RPI16 = 64 / VPR16;      // vectors per row piece; rows per wave instruction
+  constexpr int SE_LD = 17;
+  const bool scan = xt && tl.mode != 0;
+  double* const s_e = reinterpret_cast<double*>(s_a) + (tid >> 6) * (32 * SE_LD);      // [32][SE_LD] per wave: the terms e
+  double* const s_z = reinterpret_cast<double*>(s_a) + 4 * 32 * SE_LD;                  // [128] z of the panel
+  static_assert((4 * 32 * SE_LD + 128) * sizeof(double) <= 2 * 128 * RK_LD * sizeof(T), "scan tiles fit region A");
+  static_assert(16 * 128 * sizeof(double) <= 4 * 32 * SE_LD * sizeof(double), "the final sums fit the e tiles");
+  static_assert(YT == 2, "the scan takes a wave's 32 rows as lane >> 1");
+  // scan: lane -> row lane >> 1 of the wave's 32 (sub-tile (lane >> 5), its row (lane >> 1) & 15), half lane & 1 of the
+  // chunk's 16 columns; column sums: lane -> column l15 of the chunk over the rows 8 l4 .. 8 l4 + 7
+  const int sy = lane >> 5, si = (lane >> 1) & 15, sh = lane & 1;
+  double run_c = 0.0, yt_c = 0.0, z_mine = 0.0;
+  double psum[8] = {};
   // two-level solve on the accumulators (they hold -C^T):
   //   X1^T = L11^-1 C1^T ;  -C2^T += L21 X1^T ;  X2^T = L22^-1 C2^T
   // acc[4 h + xp][y] <- -sum_{x <= xp} D[xp][x] acc[4 h + x][y], one column tile at a time (in place)
@@ -926,28 +957,103 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
     __builtin_amdgcn_sched_barrier(0);
   }
   PSTAMP(14);
+  if (scan) {
+    // the flag is polled, and the three vectors are fetched into registers, in front of the solve's last stage: its
+    // matrix instructions hide the two memory round trips (the flag has been up for a long time by now: the training
+    // matrices' L tiles are the first half of the grid's L tiles, the X tiles come after all of them)
+    if (!XLAST && J0 + 128 < p_pad) {      // (the last launch has no L tiles: its row p came out of the launch before)
+      if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(tl.fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= Jo ||
+               (I0 == J0 && __hip_atomic_load(tl.fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= Jo)) {
+          __builtin_amdgcn_s_sleep(32);
+          if (++spins > (1 << 16)) {
+            atomicOr(&info[0], 4);
+            break;
+          }
+        }
+      }
+    }
+  }
   __syncthreads();
   block64_put<T, NT>(nb, s_dinv, tid);
   __syncthreads();
+  if (scan) {
+    const int p = tl.p;
+    if (tid < 128) {
+      const int j = J0 + tid;
+      z_mine = (j < p) ? (double)__hip_atomic_load(MJ + cm_off(p_pad, p, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       : 0.0;
+    }
+    const int c = I0 + rb_e[sy] + si;
+    yt_c = (c < p) ? (double)__hip_atomic_load(Bt + cm_off(p_pad, p, c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                   : 0.0;
+    run_c = (I0 == J0) ? 0.0 : tl.run[c];
+  }
   tri_mult(1);
 #else
   (void)Dg; (void)tri_mult;
+  if (scan) {
+    // the flag is polled, and the three vectors are fetched into registers, in front of the solve's last stage: its
+    // matrix instructions hide the two memory round trips (the flag has been up for a long time by now: the training
+    // matrices' L tiles are the first half of the grid's L tiles, the X tiles come after all of them)
+    if (!XLAST && J0 + 128 < p_pad) {      // (the last launch has no L tiles: its row p came out of the launch before)
+      if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(tl.fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= Jo ||
+               (I0 == J0 && __hip_atomic_load(tl.fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= Jo)) {
+          __builtin_amdgcn_s_sleep(32);
+          if (++spins > (1 << 16)) {
+            atomicOr(&info[0], 4);
+            break;
+          }
+        }
+      }
+    }
+  }
   __syncthreads();
+  if (scan) {
+    const int p = tl.p;
+    if (tid < 128) {
+      const int j = J0 + tid;
+      z_mine = (j < p) ? (double)__hip_atomic_load(MJ + cm_off(p_pad, p, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       : 0.0;
+    }
+    const int c = I0 + rb_e[sy] + si;
+    yt_c = (c < p) ? (double)__hip_atomic_load(Bt + cm_off(p_pad, p, c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                   : 0.0;
+    run_c = (I0 == J0) ? 0.0 : tl.run[c];
+  }
 #endif
 
-  PSTAMP(3);
-  // the wave's row bases once more, from a copy of the wave index the compiler cannot see through: otherwise the store
-  // loop's LDS addresses are computed ahead of the k-loop and carried -- spilled -- through it
-  int ws_e = ws;
-  asm volatile("" : "+s"(ws_e));
-  const int rb_e[2] = {16 * ws_e, 16 * (7 - ws_e)};
   // Store L[I, panel] through the output buffer, one 16-column chunk at a time (a contiguous 128 x 16
   // block in the chunk-major layout).  (Round 4, measured and not kept: the accumulators stored straight to memory --
   // an fp64 register is 32 contiguous bytes over four lanes, sixteen rows an instruction; no barrier, no LDS round
   // trip, and 6.51 against 6.20 ms a C3 step: the 32-byte pieces cost the memory system more than sixteen barriers cost
   // the tile.)
-  typedef RKRegs<T, 128, NT> RR;
-  const int sc = tid % RR::VPR, srow = tid / RR::VPR;
+  // Every wave turns its own two 16 x 16 sub-tiles round in its own rows of the buffer: in the chunk-major layout a
+  // sub-tile is one contiguous 2 KB block (fp32: 1 KB), so the wave's own lanes store it in full lines and the store
+  // needs no workgroup barrier.  (As a change of its own -- workgroup-wide staging with two barriers a chunk before --
+  // it left the step where it was, 6.16-6.21 against 6.19-6.21 ms: the store costs its bytes, not its barriers.)
+  //
+  // FUSED LIFT SCAN (X tiles, tl.mode != 0).  The lifts need, for every row c of V^T (a column of V, "test space") and
+  // the columns j in ordering position, the running sum N_{j-1}[c] = sum_{k<j} z_k V^T[c][k] and the terms
+  //     e = V^T[c][j] (2 (y~_c - N_{j-1}[c]) - z_j V^T[c][j]),        lift_j = z_j sum_c e / |y_test|^2
+  // (k_lift.hip).  A separate kernel used to read all of V^T back for this (1.2 GB and 0.23 ms a C3 step).  Here the
+  // tile does it for its own 128 x 128 block while the block passes through LDS on its way out: the 16 columns of a
+  // chunk are scanned by four lanes a row (a 4-lane prefix), the row sums of e are reduced over the wave's rows through
+  // a small LDS tile, and N is carried from panel to panel in tl.run (tile (I', J) runs in launch J, tile (I', J + 1) in
+  // the next).  z of THIS panel is row p of the training matrix's L tile (last block row, J) and y~ of a diagonal tile's
+  // rows is row p of the test matrix's: both are written by workgroups of the SAME launch.  Those are dispatched before
+  // every X tile (the grid is L tiles first, and each XCD hands out its workgroups in order), they depend on nothing, and
+  // they raise a flag when their tile is stored; the X tile waits for it here, after its own k-loop and solve, i.e. in
+  // practice never (a wait that outlasts ~60 ms sets info bit 2 and goes on: no hang).  The last launch needs no flag.
+  PSTAMP(3);
+  if (scan) {
+    __syncthreads();      // every wave is done with the solve's blocks in region A
+    if (tid < 128) s_z[tid] = z_mine;
+    __syncthreads();
+  }
 #ifdef LSSPA_T_NOSTORE
   {
     T sum = (T)0;
@@ -959,19 +1065,85 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
 #pragma unroll
   for (int xp = 0; xp < 8; ++xp) {
 #endif
-    if (xp > 0) __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int y = 0; y < YT; ++y)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         s_out[(rb_e[y] + l15) * RK_LD + Tr<T>::acc_row(l4, r)] = acc[xp][y][r];
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    if (!(XLAST && tl.mode == 2)) {
 #pragma unroll
-    for (int q = 0; q < RR::NP; ++q) {
-      const int rr = srow + RR::RPP * q;
-      *reinterpret_cast<vec_t*>(M + cm_off(p_pad, I0 + rr, J0 + 16 * xp + VE * sc)) =
-          Tr<T>::lds_load(s_out + rr * RK_LD + VE * sc);
+      for (int y = 0; y < YT; ++y)
+#pragma unroll
+        for (int h = 0; h < 16 / RPI16; ++h) {
+          const int rr = rb_e[y] + RPI16 * h + lane / VPR16, cv = VE * (lane % VPR16);
+          T* const dst = M + cm_off(p_pad, I0 + rr, J0 + 16 * xp + cv);
+          const vec_t val = Tr<T>::lds_load(s_out + rr * RK_LD + cv);
+          if (tl.raise != nullptr && I0 + rr == tl.p) {
+            // row p of an L tile (z, or y~ in a test matrix): X tiles of THIS launch read it -- written through (sc1)
+#pragma unroll
+            for (int e = 0; e < VE; ++e)
+              __hip_atomic_store(dst + e, val[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            *reinterpret_cast<vec_t*>(dst) = val;
+          }
+        }
     }
+    if (scan) {
+      const int p = tl.p;
+      const int c = I0 + rb_e[sy] + si;
+      double v[8], t[8];
+      double tot = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int jl = 16 * xp + 8 * sh + q;
+        const double raw = (double)s_out[(rb_e[sy] + si) * RK_LD + 8 * sh + q];
+        v[q] = (J0 + jl < p && c < p) ? raw : 0.0;
+        t[q] = s_z[jl] * v[q];
+        tot += t[q];
+      }
+      // the other half of the row (the neighbouring lane): the second half starts behind the first one's total
+      const double other = __shfl_xor(tot, 1, 64);
+      double before = run_c + (sh ? other : 0.0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        s_e[(lane >> 1) * SE_LD + 8 * sh + q] = v[q] * (2.0 * (yt_c - before) - t[q]);
+        before += t[q];
+      }
+      run_c += tot + other;
+      __builtin_amdgcn_wave_barrier();
+      // column l15 of the chunk over eight of the wave's rows; the four row groups and the four waves meet at the end
+      double sum = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) sum += s_e[(8 * l4 + rr) * SE_LD + l15];
+      psum[xp] = sum;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (scan) {
+    if (sh == 0) tl.run[I0 + rb_e[sy] + si] = run_c;
+    __syncthreads();      // every wave is done with its e tile: the region takes the 16 partial sums of each column
+    double* const s_f = reinterpret_cast<double*>(s_a);      // [4 waves x 4 row groups][128]
+#pragma unroll
+    for (int xp = 0; xp < 8; ++xp) s_f[((tid >> 6) * 4 + l4) * 128 + 16 * xp + l15] = psum[xp];
+    __syncthreads();
+    if (tid < 128) {
+      double sum = 0.0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) sum += s_f[g * 128 + tid];
+      tl.P[(int64_t)(I0 / 128) * p_pad + J0 + tid] = sum;
+    }
+  }
+  // row p of this panel is final (z in a training matrix, y~ in a test matrix): tell the X tiles of this launch
+  // (the hand-off needs no fence -- an agent-scope fence writes back or invalidates a whole L2: with one in every tile the
+  // step took 7.8 instead of 6.2 ms --: the 128 values are stored and loaded with sc1 accesses, which go through to
+  // memory and past the reader's L1, every storing wave waits for its stores, and one lane raises the flag behind a
+  // workgroup barrier; the reader polls with sc1 loads and reads after a barrier of its own)
+  if (!xt && tl.raise != nullptr && I0 + 128 == p_pad) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(tl.raise, Jo + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 
   PSTAMP(4);
@@ -1103,6 +1275,11 @@ struct Panel2Args {
   int n_lt;                // L tiles per matrix in this launch: p_pad / 128 - 1 - Jo (0 in the X-only last launch)
   int n_x;                 // X tiles per ordering in this launch: Jo + 1, or 0 (rect mode / strip-kernel cross-check)
   int grouped, p_live;
+  int32_t* flags;          // [n_mats] fused lift scan: panels whose row p is final, per matrix (zeroed before launch 0)
+  double* run;             // [n_ord][p_pad] running N of the scan
+  double* Ppart;           // [n_ord][pstride] partial sums, row block I' at [I' * p_pad]
+  int64_t pstride;
+  int p, lift;             // features; 0: no fused scan, 1: scan, 2: scan and the last panel's V^T is not stored
 };
 
 template <typename T, int NT, bool XLAST = false>
@@ -1153,12 +1330,24 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 4 && NT == 256) ? 3 : NT / 128) v
   T* const MJ = A + (int64_t)mt * pp2;
   T* const Dm = static_cast<T*>(a.Dinv) + (int64_t)mt * a.nblk * 4096;
   const double* const d0 = a.diag0 + (int64_t)mt * a.p_pad;
-  if (XLAST || xt)
+  TileLift tl;
+  tl.p = a.p;
+  tl.mode = a.lift;
+  if (XLAST || xt) {
+    tl.raise = nullptr;
+    tl.fz = a.flags + mt;
+    tl.fy = a.flags + n_ord + mt;
+    tl.run = a.run + (int64_t)mt * a.p_pad;
+    tl.P = a.Ppart + (int64_t)mt * a.pstride;
     panel2_tile<T, NT, XLAST>(static_cast<T*>(a.X) + (int64_t)mt * pp2, MJ, A + (int64_t)(n_ord + mt) * pp2, Dm, d0,
-                              a.piv_tol, a.info, a.p_pad, a.Jo, tile, 1, a.p_live, s_a, s_b, threadIdx.x);
-  else
-    panel2_tile<T, NT, false>(MJ, MJ, MJ, Dm, d0, a.piv_tol, a.info, a.p_pad, a.Jo, tile, 0, a.p_live, s_a, s_b,
+                              a.piv_tol, a.info, a.p_pad, a.Jo, tile, 1, a.p_live, tl, s_a, s_b, threadIdx.x);
+  } else {
+    tl.raise = a.lift ? a.flags + mt : nullptr;
+    tl.fz = tl.fy = nullptr;
+    tl.run = tl.P = nullptr;
+    panel2_tile<T, NT, false>(MJ, MJ, MJ, Dm, d0, a.piv_tol, a.info, a.p_pad, a.Jo, tile, 0, a.p_live, tl, s_a, s_b,
                               threadIdx.x);
+  }
 }
 
 // whole factorisation of n_mats matrices: one diagonal launch + (p_pad / 128 - 1) panel launches (+ one more, X tiles
@@ -1178,7 +1367,7 @@ hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double pi
 
 hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
                               int Jo, int n_mats, int f32, hipStream_t st, int flags, int p_live, void* X,
-                              int n_ord) {
+                              int n_ord, const PanelLift* pl) {
   if (p_live <= 0 || p_live > p_pad || (flags & 2048)) p_live = p_pad;   // flag 2048: no padding-tile skipping
   const int n_panel = p_pad / 128 - 1;
   // with X tiles (X != null) the matrices are [n_ord training][n_ord test] and there is one more launch, Jo = n_panel
@@ -1199,6 +1388,22 @@ hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double p
   a.n_lt = n_panel - Jo;
   a.n_x = X ? Jo + 1 : 0;
   a.p_live = p_live;
+  a.flags = nullptr;
+  a.run = a.Ppart = nullptr;
+  a.pstride = 0;
+  a.p = 0;
+  a.lift = 0;
+  if (pl && pl->mode) {
+    if (!X || !pl->flags || !pl->run || !pl->Ppart || pl->p < 1 || pl->p >= p_pad ||
+        pl->pstride < (int64_t)(p_pad / 128) * p_pad)
+      return hipErrorInvalidValue;
+    a.flags = pl->flags;
+    a.run = pl->run;
+    a.Ppart = pl->Ppart;
+    a.pstride = pl->pstride;
+    a.p = pl->p;
+    a.lift = pl->mode;
+  }
   const int64_t total = (int64_t)n_mats * a.n_lt + (int64_t)a.n_ord * a.n_x;
   if (total < 1 || total > 0x7fffffff) return hipErrorInvalidValue;
   a.grouped = (n_mats % 8 == 0 && a.n_lt > 1 && !(flags & 64)) ? 1 : 0;

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void lift_finish_kernel(LiftArgs a) {
     const double* Pp = a.Ppart + (int64_t)ord * nstrips * p_pad;
     for (int j = threadIdx.x; j < p; j += 256) {
       double s = 0.0;
-      for (int t = 0; t < nstrips; ++t) s += Pp[(int64_t)t * p_pad + j];
+      const int nt = a.fused ? j / 128 + 1 : nstrips;
+      for (int t = 0; t < nt; ++t) s += Pp[(int64_t)t * p_pad + j];
       const double val = (double)Lm[cm_off(p_pad, p, j)] * s * wgt;
       const int f = perm[j];
       if (k == 0)
@@ -146,7 +147,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void lift_finish_paired_kernel(LiftArgs a) {
   const int sample = blockIdx.x;
   const int j = blockIdx.y * 256 + threadIdx.x;
-  const int nstrips = a.m_pad / 64;
+  const int nstrips = a.m_pad / 64;      // rows of Ppart per ordering (fused: only the first j / 128 + 1 are written)
   const int p = a.p, p_pad = a.p_pad;
   if (j >= p) return;
   const double wgt = 0.5 / a.y_norm_sq;
@@ -157,9 +158,14 @@ __global__ __launch_bounds__(256) void lift_finish_paired_kernel(LiftArgs a) {
   const double* P0 = a.Ppart + (int64_t)ord * nstrips * p_pad;
   const double* P1 = P0 + (int64_t)nstrips * p_pad;
   double s0 = 0.0, s1 = 0.0;
-  for (int t = 0; t < nstrips; ++t) {
-    s0 += P0[(int64_t)t * p_pad + j];
-    s1 += P1[(int64_t)t * p_pad + j2];
+  if (a.fused) {      // row block I' of V^T has entries in the columns j >= 128 I' only
+    for (int t = 0; t <= j / 128; ++t) s0 += P0[(int64_t)t * p_pad + j];
+    for (int t = 0; t <= j2 / 128; ++t) s1 += P1[(int64_t)t * p_pad + j2];
+  } else {
+    for (int t = 0; t < nstrips; ++t) {
+      s0 += P0[(int64_t)t * p_pad + j];
+      s1 += P1[(int64_t)t * p_pad + j2];
+    }
   }
   const double v0 = (double)L0[cm_off(p_pad, p, j)] * s0 * wgt;
   const double v1 = (double)L1[cm_off(p_pad, p, j2)] * s1 * wgt;
@@ -171,7 +177,9 @@ hipError_t launch_lift(const LiftArgs& a, hipStream_t st) {
       (a.per_sample != 1 && a.per_sample != 2) || a.n_ord % a.per_sample != 0 || !(a.y_norm_sq > 0.0))
     return hipErrorInvalidValue;
   const dim3 g1(a.n_ord, (a.m_pad / 64 + 3) / 4), g2(a.n_ord / a.per_sample);
-  if (a.vt) {
+  if (a.vt && a.fused) {      // the X tiles of the panel launches have scanned V^T themselves: only the finish is left
+    if (!a.tri || a.m_pad > a.p_pad || a.m_pad / 64 < a.p_pad / 128) return hipErrorInvalidValue;
+  } else if (a.vt) {
     if (!a.tri || a.m_pad > a.p_pad) return hipErrorInvalidValue;
     if (a.f32)
       hipLaunchKernelGGL((lift_partial_kernel<float, true>), g1, dim3(256), 0, st, a);

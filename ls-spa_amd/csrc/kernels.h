@@ -85,9 +85,20 @@ hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double pi
 // X != null (tri mode): the matrices are [n_ord training][n_ord test] and step Jo also computes block column Jo of
 // X = V^T = L_t^T L^-T ([n_ord] chunk-major p_pad x p_pad matrices, upper block triangle written) as extra tiles of
 // the training factorisation; there is then one more step, Jo = p_pad/128 - 1, with X tiles only.
+// pl (with X tiles): the lift scan of V^T is done by the X tiles themselves, block by block, before the block leaves
+// the chip -- the lift kernel's pass over V^T falls away (launch_lift with fused = 1 only finishes).  flags must be
+// zero before launch 0 of a batch; mode 2 also leaves the last panel's V^T unstored (nobody reads it then).
+struct PanelLift {
+  int32_t* flags;          // [n_mats]
+  double* run;             // [n_ord][p_pad]
+  double* Ppart;           // [n_ord][pstride], row block I' of V^T at [I' * p_pad]
+  int64_t pstride;
+  int p;                   // features
+  int mode;                // 0 off, 1 scan, 2 scan + last panel of V^T not stored
+};
 hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
                               int Jo, int n_mats, int f32, hipStream_t st, int flags = 0, int p_live = 0,
-                              void* X = nullptr, int n_ord = 0);
+                              void* X = nullptr, int n_ord = 0, const PanelLift* pl = nullptr);
 
 struct StripArgs {
   const void* A;           // factored train matrices
@@ -117,6 +128,7 @@ struct LiftArgs {
   int p, p_pad, m_pad, n_ord, per_sample, tri;  // per_sample = 1 or 2 orderings per sample
   int f32;
   int paired;              // per_sample == 2 and ordering 2 s + 1 is ordering 2 s reversed
+  int fused = 0;           // vt: Ppart already holds the X tiles' own sums, one row per 128-row block of V^T (PanelLift)
 };
 hipError_t launch_lift(const LiftArgs& a, hipStream_t st);
 

@@ -51,6 +51,8 @@ struct Lane {
   int cap_samples = 0;               // samples the lifts buffer can hold
   DevBuf<char> A, V, Dinv;           // raw bytes: esz() per element
   DevBuf<double> Ppart, lifts, diag0;
+  DevBuf<double> run;                // [cap_ord][p_pad] running sums of the fused lift scan (tri mode)
+  DevBuf<int32_t> row_flags;         // [2 cap_ord] "row p of panel J is final" per work matrix (fused lift scan)
   DevBuf<int32_t> perms_d;
   // pinned staging of the orderings: two buffers in turn, each guarded by the event of its last
   // H2D copy, so the host can prepare batch k+1 while the GPU still runs batch k (no stream sync)
@@ -273,6 +275,8 @@ void free_lane_workspace(Lane& L) {
   dev_free(L.Dinv);
   dev_free(L.diag0);
   dev_free(L.Ppart);
+  dev_free(L.run);
+  dev_free(L.row_flags);
   dev_free(L.perms_d);
   dev_free(L.lifts);
 }
@@ -391,6 +395,8 @@ size_t v_elems_per_ordering(const lsspa_ctx* ctx) {
 
 // tri mode computes V^T inside the panel launches; rect mode (and developer flag 128) uses the strip kernel
 static inline bool vt_path(const lsspa_ctx* ctx) { return ctx->tri && !(ctx->flags & 128); }
+// the X tiles scan their own blocks of V^T for the lifts (developer flag 512: the lift kernel reads V^T back instead)
+static inline bool fused_scan(const lsspa_ctx* ctx) { return vt_path(ctx) && !(ctx->flags & 512); }
 
 size_t bytes_per_ordering(const lsspa_ctx* ctx) {
   const size_t pp = ctx->p_pad, nblk = pp / NB;
@@ -434,6 +440,10 @@ int ensure_workspace(lsspa_ctx* ctx, Lane& L, int want_ord, int want_samples) {
       TRY(dev_alloc(ctx, L.Dinv, nm * cap * nblk * 4096 * es));
       TRY(dev_alloc(ctx, L.diag0, nm * cap * pp));
       TRY(dev_alloc(ctx, L.Ppart, (size_t)cap * (ctx->m_pad / 64) * pp));
+      if (ctx->tri) {
+        TRY(dev_alloc(ctx, L.run, (size_t)cap * pp));
+        TRY(dev_alloc(ctx, L.row_flags, (size_t)2 * cap));
+      }
       TRY(dev_alloc(ctx, L.perms_d, (size_t)2 * cap * ctx->p));
       L.cap_ord = cap;
     }
@@ -553,11 +563,23 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
   }
   // panel steps; with vt one more (X tiles only): step Jo also computes block column Jo of V^T
   const int n_panel = p_pad / 128 - 1;
+  PanelLift pl;
+  pl.mode = 0;
+  if (fused_scan(ctx)) {
+    pl.flags = L.row_flags.ptr + (size_t)ord_off * n_src;
+    pl.run = L.run.ptr + (size_t)ord_off * p_pad;
+    pl.Ppart = Ppart_s;
+    pl.pstride = (int64_t)(m_pad / 64) * p_pad;
+    pl.p = p;
+    // the factors themselves are wanted (debug_factor reads V^T back): keep the last panel's stores
+    pl.mode = ctx->general_path_once ? 1 : 2;
+    HIPCHK(hipMemsetAsync(pl.flags, 0, sizeof(int32_t) * n_mats, st));
+  }
   for (int Jo = 0; Jo < n_panel + (vt ? 1 : 0); ++Jo) {
     {
       ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_PANEL, st);
       HIPCHK(launch_chol2_panel(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, Jo, n_mats, ctx->f32, st,
-                                ctx->flags, round_up(p + 1, 16), vt ? V_s : nullptr, n_ord));
+                                ctx->flags, round_up(p + 1, 16), vt ? V_s : nullptr, n_ord, pl.mode ? &pl : nullptr));
     }
     // two lanes: the other lane's next batch may start once this one is about half done
     // (the hand-over point scanned at the C3 shape, round 4, eight launches: after launch 0 / 1 / 2 / 3 / 4 / 5 / 6 / 7 ->
@@ -599,6 +621,7 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
     la.ytil = ctx->tri ? nullptr : ctx->ytil.ptr;
     la.V = V_s;
     la.vt = vt ? 1 : 0;
+    la.fused = pl.mode ? 1 : 0;
     la.perms = perms_s;
     la.Ppart = Ppart_s;
     la.lifts = L.lifts.ptr + (size_t)s_off * p;

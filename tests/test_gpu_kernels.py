@@ -277,7 +277,9 @@ def test_vt_tiles_agree_with_the_strip_kernel(p, n, m, prec):
     """Two independent computations of V = L^-1 L_t live in the library: as extra block rows of the training
     factorisation inside the panel launches (V^T, the shipped tri-mode path since round 4) and by the strip kernel
     (developer flag 128; the shipped path of rect mode).  Same factors in, same lifts to round-off -- and both meet
-    the oracle; the paired / unpaired gather (flag 256) and the plain dispatch order (flag 64) likewise."""
+    the oracle; the paired / unpaired gather (flag 256) and the plain dispatch order (flag 64) likewise.  The lift scan
+    itself has two forms as well: fused into the X tiles (shipped) and as a kernel of its own over the stored V^T
+    (flag 512)."""
     from ls_spa._engine import HipEngine
     Xa, Xe, ya, ye = problem(13, p, n, m)
     rng = np.random.default_rng(8)
@@ -289,7 +291,8 @@ def test_vt_tiles_agree_with_the_strip_kernel(p, n, m, prec):
         eng.load_data(Xa, Xe, ya, ye, 1e-3)
         eng.set_flags(1024)            # 1024: the general path also where the fused small-p kernel would run
         base = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
-        for flags in (128, 256, 64, 128 | 256 | 64):
+        # 512: the lift kernel reads V^T back and scans it (the X tiles scan their own blocks otherwise)
+        for flags in (128, 256, 64, 512, 512 | 256, 128 | 256 | 64):
             eng.set_flags(flags | 1024)
             other = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
             np.testing.assert_allclose(other, base, rtol=0, atol=5e-13 if f64 else 2e-5)
