@@ -586,7 +586,10 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
     // 6.32 / 6.33 / 6.29 / 6.25 / 6.32 / 6.39 / 6.40 / 6.48 ms per step, one lane 6.44-6.52)
     // (with two half-batches per step on the two lanes, 20 steps: after launch 1 / 2 / 3 / 4 / 5 -> 6.24 / 6.22 / 6.19 /
     // 6.28 / 6.38 ms)
-    if (L.mid_armed && timed && Jo == std::max(0, (n_panel + (vt ? 1 : 0)) / 2 - 1)) {
+    static const int handover_env = [] { const char* e = getenv("LSSPA_HANDOVER"); return e ? atoi(e) : -1; }();
+    const int handover = handover_env >= 0 ? std::min(handover_env, n_panel + (vt ? 1 : 0) - 1)
+                                           : std::max(0, (n_panel + (vt ? 1 : 0)) / 2 - 1);
+    if (L.mid_armed && timed && Jo == handover) {
       HIPCHK(hipEventRecord(L.ev_mid, st));
       L.mid_valid = true;
       L.mid_armed = false;

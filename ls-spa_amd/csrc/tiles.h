@@ -154,6 +154,17 @@ __device__ __forceinline__ void rk_load_full(RKRegs<T, R, NT>& r, const T* __res
     r.v[q] = *reinterpret_cast<const typename Tr<T>::vec_t*>(src + (int64_t)(row + RR::RPP * q) * ld + Tr<T>::VE * c);
 }
 
+// the same with the streaming hint (an operand no other workgroup reads at this time)
+template <typename T, int R, int NT = 256>
+__device__ __forceinline__ void rk_load_full_nt(RKRegs<T, R, NT>& r, const T* __restrict__ src, int64_t ld, int tid) {
+  typedef RKRegs<T, R, NT> RR;
+  const int c = tid % RR::VPR, row = tid / RR::VPR;
+#pragma unroll
+  for (int q = 0; q < RR::NP; ++q)
+    r.v[q] = __builtin_nontemporal_load(
+        reinterpret_cast<const typename Tr<T>::vec_t*>(src + (int64_t)(row + RR::RPP * q) * ld + Tr<T>::VE * c));
+}
+
 template <typename T, int R, int NT = 256>
 __device__ __forceinline__ void rk_store(const RKRegs<T, R, NT>& r, T* lds, int tid) {
   typedef RKRegs<T, R, NT> RR;
