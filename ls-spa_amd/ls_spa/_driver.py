@@ -28,6 +28,7 @@ import warnings
 import numpy as np
 
 from . import _samplers as S
+from ._native import LSSPANativeError
 from ._results import ShapleyResults, validate_data
 from ._stats import error_estimates, error_estimates_lowrank
 
@@ -611,11 +612,14 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
             lookahead=lookahead, timings=tm)
         t0 = _time.perf_counter()
         theta, r_squared, info = engine.full_fit()
-        if info or engine.info():
+        if (info | engine.info()) & 4:      # LSSPA_INFO_SCAN_WAIT: a hand-over inside a panel launch timed out
+            raise LSSPANativeError("the fused lift scan gave up waiting for a row of its panel: the lift vectors of this "
+                                   "run are not valid (engine fault; the lift kernel of its own is developer flag 512)")
+        if (info | engine.info()) & 1:
             warnings.warn("a permuted Gram matrix was not numerically positive definite; the attribution "
                           "of collinear features is not meaningful (the reference's is not either)",
                           RuntimeWarning, stacklevel=2)
-        if info:
+        if info & 1:
             G, g, _, _ = engine.gram()
             theta = _min_norm_theta(G, g)
             yy = engine.y_norm_sq
