@@ -744,7 +744,9 @@ def main():
             "kernels": per_class,
             "reduction_ms": reduce_ms, "reduction_ms_warm_call": reduce_warm_ms,
             "host_data_generation_s": gen_s,
-            "check": {"samples": int(n_seen), "sum_attribution": float(mean.sum())},
+            # engine_info: LSSPA_INFO_* bits raised by any launch of this process so far (1: a pivot was not positive,
+            # 4: a hand-over inside a panel launch timed out) -- 0 on the benchmark data
+            "check": {"samples": int(n_seen), "sum_attribution": float(mean.sum()), "engine_info": int(eng.info())},
             "ms_per_step_min_rank": 1e3 * elapsed_min / args.steps,
             "sustained": sustained,
             "timing_note": "value/ms_per_step: K steps without events (two lanes: launch sequences overlap across two "

@@ -226,7 +226,9 @@ int lsspa_profile_reset(lsspa_ctx* ctx);
  *  2048  no skipping of the all-padding 16 x 16 tiles       normally takes the fused one-workgroup kernel)
  * 16384  small problems: the LDS-resident kernel also where the register-resident one applies (p + 1 <= 112)
  * 65536  Gram kernel: workgroup id = unit (the units of a row slice spread over the XCDs instead of sharing one L2)
- * Every combination computes the same lifts (tests/test_gpu_kernels.py).  Rounds 1-3 carried more (one-level kernels,
+ * Every combination computes the same lifts (tests/test_gpu_kernels.py).  Environment, read once per process:
+ * LSSPA_HANDOVER=k moves the point at which the second lane's next launch sequence may start to "after panel launch k"
+ * (default: the middle one; a scan knob, tools/handover_scan.sh).  Rounds 1-3 carried more (one-level kernels,
  * whole-factorisation kernel, 256-column strips, two half-batches on two streams of one lane, page-locking of caller
  * memory): measured slower or superseded, removed in round 4. */
 int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);
