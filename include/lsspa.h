@@ -224,6 +224,8 @@ int lsspa_profile_reset(lsspa_ctx* ctx);
  *   512  tri mode: the lift kernel reads V^T back and scans it, instead of the X tiles scanning their own blocks
  *   256  unpaired gather                             1024  general path also for small problems (p + 1 <= 128
  *  2048  no skipping of the all-padding 16 x 16 tiles       normally takes the fused one-workgroup kernel)
+ *  4096  fault injection: the L tiles never raise the flag the fused lift scan waits for -- every X tile runs into the
+ *        scan's time-out (~0.1 s a launch), LSSPA_INFO_SCAN_WAIT is set, nothing hangs (tests/test_gpu_kernels.py)
  * 16384  small problems: the LDS-resident kernel also where the register-resident one applies (p + 1 <= 112)
  * 65536  Gram kernel: workgroup id = unit (the units of a row slice spread over the XCDs instead of sharing one L2)
  * Every combination computes the same lifts (tests/test_gpu_kernels.py).  Environment, read once per process:

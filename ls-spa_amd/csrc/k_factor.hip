@@ -1282,6 +1282,7 @@ struct Panel2Args {
   double* Ppart;           // [n_ord][pstride] partial sums, row block I' at [I' * p_pad]
   int64_t pstride;
   int p, lift;             // features; 0: no fused scan, 1: scan, 2: scan and the last panel's V^T is not stored
+  int mute;                // fault injection (developer flag 4096): the row flags are never raised
 };
 
 template <typename T, int NT, bool XLAST = false>
@@ -1344,7 +1345,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 4 && NT == 256) ? 3 : NT / 128) v
     panel2_tile<T, NT, XLAST>(static_cast<T*>(a.X) + (int64_t)mt * pp2, MJ, A + (int64_t)(n_ord + mt) * pp2, Dm, d0,
                               a.piv_tol, a.info, a.p_pad, a.Jo, tile, 1, a.p_live, tl, s_a, s_b, threadIdx.x);
   } else {
-    tl.raise = a.lift ? a.flags + mt : nullptr;
+    tl.raise = (a.lift && !a.mute) ? a.flags + mt : nullptr;
     tl.fz = tl.fy = nullptr;
     tl.run = tl.P = nullptr;
     panel2_tile<T, NT, false>(MJ, MJ, MJ, Dm, d0, a.piv_tol, a.info, a.p_pad, a.Jo, tile, 0, a.p_live, tl, s_a, s_b,
@@ -1406,6 +1407,7 @@ hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double p
     a.p = pl->p;
     a.lift = pl->mode;
   }
+  a.mute = (flags & 4096) ? 1 : 0;
   const int64_t total = (int64_t)n_mats * a.n_lt + (int64_t)a.n_ord * a.n_x;
   if (total < 1 || total > 0x7fffffff) return hipErrorInvalidValue;
   a.grouped = (n_mats % 8 == 0 && a.n_lt > 1 && !(flags & 64)) ? 1 : 0;

@@ -313,6 +313,37 @@ def test_vt_tiles_agree_with_the_strip_kernel(p, n, m, prec):
         np.testing.assert_allclose(base, want, rtol=0, atol=1e-11 if f64 else 1e-4)
 
 
+def test_a_hand_over_that_never_comes_times_out_and_is_reported():
+    """The fused lift scan waits, inside a panel launch, for row p of its panel from another workgroup of the same
+    launch.  That wait must end whatever happens: with the flags muted (developer flag 4096) every X tile of the first two
+    launches runs into the time-out, the launches finish, LSSPA_INFO_SCAN_WAIT (4) is set -- and the engine is fine
+    afterwards."""
+    import time
+    from ls_spa._engine import HipEngine
+    p, n, m = 257, 900, 700
+    Xa, Xe, ya, ye = problem(23, p, n, m)
+    rng = np.random.default_rng(3)
+    perms = np.array([rng.permutation(p) for _ in range(2)])
+    eng = HipEngine(0)
+    try:
+        eng.load_data(Xa, Xe, ya, ye, 1e-3)
+        good = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        assert eng.info() == 0
+        eng.set_flags(4096)
+        t0 = time.perf_counter()
+        eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        waited = time.perf_counter() - t0
+        assert eng.info() & 4
+        assert waited < 20.0
+        eng.set_flags(0)
+        eng.load_data(Xa, Xe, ya, ye, 1e-3)      # (loading a problem clears the info word)
+        again = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        assert eng.info() == 0
+        np.testing.assert_array_equal(again, good)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("p,n,m,prec", [(257, 900, 700, "float64"), (257, 900, 700, "float32"), (130, 500, 40, "float64"),
                                         (1000, 3000, 2500, "float64")])
 def test_padding_tiles_are_skipped_without_a_trace(p, n, m, prec):
