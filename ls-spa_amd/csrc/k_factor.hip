@@ -490,23 +490,55 @@ __device__ __forceinline__ void factor_block64_core(T* __restrict__ M, int p_pad
   const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave index as the scalar it is
   T* const s_dd = s_x + 4 * 16 * XD_LD;
   int bad = 0;
+  // Block step kb: (1) the 16 x 16 pivot chain of diagonal tile kb on ONE wave; (2) the panel tiles L[ib][kb] and the
+  // inverse tiles X[kb][jb]; (3) the trailing tiles.  LOOK-AHEAD (round 4): (3) of step kb - 1 and (1) of step kb run side
+  // by side -- the wave that has the chain updates diagonal tile (kb, kb) alone and starts at once, the other three waves
+  // share the remaining trailing tiles meanwhile (8 / 6 / 3 of them: three rounds / two / one, as the four waves had
+  // before): the 128 x 128 factorisation 52.4 -> 49.5 us alone on its CU, the diagonal launch 0.103 -> 0.096 ms.
+  // The pivot chain is a sequence of DEPENDENT matrix instructions (two per pivot, a third of the pipe's time): with
+  // priority over the co-resident workgroup's k-loop, which fills the pipe, each issues when it is ready instead of
+  // queueing behind independent work that can wait.  The four chains of a 64 x 64 block go to the four waves in turn:
+  // the co-resident workgroup's waves meet at two barriers a chunk, so it runs at the pace of its slowest wave -- all
+  // four chains on wave 0 slowed ITS SIMD's neighbour, and with it the whole neighbour, four times as long as each
+  // SIMD's share does (6.40 -> 6.36 ms a C3 step; priority 0 instead of 3 here: no difference).
 #pragma unroll 1
   for (int kb = 0; kb < 4; ++kb) {
-    T* const blk = s_t + (16 * kb) * DI_LD + 16 * kb;
-    T* const inv = s_x + kb * 16 * XD_LD;
-    if (w == (kb & 3)) {
-      // the pivot chain is a sequence of DEPENDENT matrix instructions (two per pivot, a third of the pipe's time):
-      // with priority over the co-resident workgroup's k-loop, which fills the pipe, each issues when it is ready
-      // instead of queueing behind independent work that can wait.  The four chains of a 64 x 64 block go to the four
-      // waves in turn: the co-resident workgroup's waves meet at two barriers a chunk, so it runs at the pace of its
-      // slowest wave -- all four chains on wave 0 slowed ITS SIMD's neighbour, and with it the whole neighbour, four
-      // times as long as each SIMD's share does (6.40 -> 6.36 ms a C3 step; priority 0 instead of 3 here: no difference).
+    const int wc = kb & 3;                   // this step's chain wave
+    if (w == wc) {
+      if (kb > 0) {                          // T[kb][kb] -= L[kb][kb-1] L[kb][kb-1]^T: the one trailing tile the chain needs
+        const T* const lkk = s_t + (16 * kb) * DI_LD + 16 * (kb - 1);
+        tile16_mma<T>(lkk, DI_LD, lkk, DI_LD, true, s_t + (16 * kb) * DI_LD + 16 * kb, DI_LD, true, (T)-1, lane);
+        __builtin_amdgcn_wave_barrier();
+      }
       __builtin_amdgcn_s_setprio(3);
-      wave_factor16<T>(blk, inv, s_dd, __shfl(tol64, 16 * kb + (lane & 15)), lane, bad);
+      wave_factor16<T>(s_t + (16 * kb) * DI_LD + 16 * kb, s_x + kb * 16 * XD_LD, s_dd,
+                       __shfl(tol64, 16 * kb + (lane & 15)), lane, bad);
       __builtin_amdgcn_s_setprio(0);
+    } else if (kb > 0) {
+      // (3) of step kp = kb - 1 without its tile (kb, kb): trailing tiles (ib >= jb > kp) and Y tiles (ib > kp, jb <= kp)
+      const int kp = kb - 1;
+      const T* const invp = s_x + kp * 16 * XD_LD;
+      const int wr = (w - wc - 1) & 3;       // 0, 1, 2 among the three helpers
+      int t = 0;
+      for (int ib = kp + 1; ib < 4; ++ib) {
+        const T* lik = s_t + (16 * ib) * DI_LD + 16 * kp;
+        for (int jb = kp + 1; jb <= ib; ++jb) {
+          if (ib == kb) continue;            // (kb, kb): the chain's wave has it
+          if ((t++ % 3) == wr)               // T[ib][jb] -= L[ib][kp] * L[jb][kp]^T
+            tile16_mma<T>(lik, DI_LD, s_t + (16 * jb) * DI_LD + 16 * kp, DI_LD, true,
+                          s_t + (16 * ib) * DI_LD + 16 * jb, DI_LD, true, (T)-1, lane);
+        }
+        for (int jb = 0; jb <= kp; ++jb)
+          if ((t++ % 3) == wr) {             // Y[ib][jb] -= L[ib][kp] * X[kp][jb]
+            const T* xb = (jb == kp) ? invp : s_t + (16 * jb) * DI_LD + 16 * kp;
+            tile16_mma<T>(lik, DI_LD, xb, (jb == kp) ? XD_LD : DI_LD, false,
+                          s_t + (16 * jb) * DI_LD + 16 * ib, DI_LD, true, (T)-1, lane);
+          }
+      }
     }
     __syncthreads();
     FSTAMP(2 + 3 * kb);
+    T* const inv = s_x + kb * 16 * XD_LD;
     // (2): 3 - kb panel tiles and kb inverse tiles: three tiles in all, one per wave
     if (w < 3) {
       if (w < 3 - kb) {
@@ -521,26 +553,6 @@ __device__ __forceinline__ void factor_block64_core(T* __restrict__ M, int p_pad
     }
     __syncthreads();
     FSTAMP(3 + 3 * kb);
-    if (kb == 3) break;
-    // (3): trailing tiles (ib >= jb > kb) and Y tiles (ib > kb, jb <= kb), dealt round-robin to the four waves
-    {
-      int t = 0;
-      for (int ib = kb + 1; ib < 4; ++ib) {
-        const T* lik = s_t + (16 * ib) * DI_LD + 16 * kb;
-        for (int jb = kb + 1; jb <= ib; ++jb, ++t)
-          if ((t & 3) == w)                  // T[ib][jb] -= L[ib][kb] * L[jb][kb]^T
-            tile16_mma<T>(lik, DI_LD, s_t + (16 * jb) * DI_LD + 16 * kb, DI_LD, true,
-                          s_t + (16 * ib) * DI_LD + 16 * jb, DI_LD, true, (T)-1, lane);
-        for (int jb = 0; jb <= kb; ++jb, ++t)
-          if ((t & 3) == w) {                // Y[ib][jb] -= L[ib][kb] * X[kb][jb]
-            const T* xb = (jb == kb) ? inv : s_t + (16 * jb) * DI_LD + 16 * kb;
-            tile16_mma<T>(lik, DI_LD, xb, (jb == kb) ? XD_LD : DI_LD, false,
-                          s_t + (16 * jb) * DI_LD + 16 * ib, DI_LD, true, (T)-1, lane);
-          }
-      }
-    }
-    __syncthreads();
-    FSTAMP(4 + 3 * kb);
   }
   // store L (lower) and its inverse (lower; off-diagonal blocks from the upper block positions), 16-byte vectors
   {
