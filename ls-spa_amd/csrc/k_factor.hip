@@ -682,10 +682,14 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void chol_diag2_kernel(T* __restrict__ A, T* __restrict__ Dinv,
                                                             const double* __restrict__ diag0, double piv_tol,
                                                             int32_t* __restrict__ info, int p_pad, int Jo,
-                                                            int nblk) {
+                                                            int nblk, int32_t* __restrict__ row_flags) {
   __shared__ __attribute__((aligned(16))) T s_a[64 * DI_LD];
   __shared__ __attribute__((aligned(16))) T s_x[FB_SX_ELEMS];
   const int mt = blockIdx.x;
+  // the fused lift scan's "row p of panel J is final" word of this matrix starts the batch at zero (a memset of its own
+  // between this launch and the first panel launch took 120-160 us of the lane's time in the two-lane pipeline: a fill
+  // kernel queues for slots like any other)
+  if (row_flags != nullptr && threadIdx.x == 0) row_flags[mt] = 0;
   T* M = A + (int64_t)mt * p_pad * p_pad;
   factor_diag128<T>(M, p_pad, Jo * 128, Dinv + ((int64_t)mt * nblk + 2 * Jo) * 4096,
                     diag0 + (int64_t)mt * p_pad, piv_tol, info, s_a, s_x, threadIdx.x);
@@ -1368,15 +1372,15 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 4 && NT == 256) ? 3 : NT / 128) v
 // whole factorisation of n_mats matrices: one diagonal launch + (p_pad / 128 - 1) panel launches (+ one more, X tiles
 // only, when V^T is computed alongside)
 hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
-                             int n_mats, int f32, hipStream_t st) {
+                             int n_mats, int f32, hipStream_t st, int32_t* row_flags) {
   if (p_pad % 128 != 0 || n_mats < 1) return hipErrorInvalidValue;
   const int nblk = p_pad / NB;
   if (f32)
     hipLaunchKernelGGL(chol_diag2_kernel<float>, dim3(n_mats), dim3(256), 0, st, (float*)A, (float*)Dinv, diag0,
-                       piv_tol, info, p_pad, 0, nblk);
+                       piv_tol, info, p_pad, 0, nblk, row_flags);
   else
     hipLaunchKernelGGL(chol_diag2_kernel<double>, dim3(n_mats), dim3(256), 0, st, (double*)A, (double*)Dinv,
-                       diag0, piv_tol, info, p_pad, 0, nblk);
+                       diag0, piv_tol, info, p_pad, 0, nblk, row_flags);
   return hipGetLastError();
 }
 

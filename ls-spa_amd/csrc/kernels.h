@@ -79,7 +79,8 @@ hipError_t launch_small_p(const SmallArgs& a, hipStream_t st);
 // p_pad/128 - 2: step Jo computes L[I, Jo] for the tiles below and its tile-0 workgroups update and factor diagonal
 // block Jo + 1.
 hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
-                             int n_mats, int f32, hipStream_t st);
+                             int n_mats, int f32, hipStream_t st,
+                             int32_t* row_flags = nullptr);
 // p_live: rows at or beyond it are identity padding (p + 1 rounded up to 16; 0 = none known): their all-zero
 // accumulator tiles are left out of the products.
 // X != null (tri mode): the matrices are [n_ord training][n_ord test] and step Jo also computes block column Jo of

@@ -559,7 +559,9 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
   const double piv_tol = 16.0 * (double)p * (ctx->f32 ? 1.1920929e-07 : 2.220446049250313e-16);
   {
     ProfScope ps(timed ? ctx : nullptr, LSSPA_K_CHOL_DIAG, st);
-    HIPCHK(launch_chol2_diag(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, n_mats, ctx->f32, st));
+    // (the diagonal launch also zeroes the fused lift scan's row flags of its matrices)
+    HIPCHK(launch_chol2_diag(A_s, Dinv_s, diag0_s, piv_tol, ctx->info_d.ptr, p_pad, n_mats, ctx->f32, st,
+                             fused_scan(ctx) ? L.row_flags.ptr + (size_t)ord_off * n_src : nullptr));
   }
   // panel steps; with vt one more (X tiles only): step Jo also computes block column Jo of V^T
   const int n_panel = p_pad / 128 - 1;
@@ -573,7 +575,6 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
     pl.p = p;
     // the factors themselves are wanted (debug_factor reads V^T back): keep the last panel's stores
     pl.mode = ctx->general_path_once ? 1 : 2;
-    HIPCHK(hipMemsetAsync(pl.flags, 0, sizeof(int32_t) * n_mats, st));
   }
   for (int Jo = 0; Jo < n_panel + (vt ? 1 : 0); ++Jo) {
     {
