@@ -4,10 +4,10 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/variants; mkdir -p $O
 L=ls-spa_amd/lib
 cp $L/liblsspa_hip.so $L/keep.so
-for r in 1 2; do
+for r in 1; do
 for v in ${VARIANTS:-BASE}; do
   cp $L/var/$v.so $L/liblsspa_hip.so
-  for lanes in 2; do
+  for lanes in 2 1; do
     timeout -k 10 200 python3 bench.py --steps 40 --warmup 5 --no-probe --no-ttt --no-cpu-baseline --no-sustained --no-full-pass --lanes $lanes > $O/${v}_l$lanes.json 2> $O/${v}_l$lanes.err || { tail -5 $O/${v}_l$lanes.err; cp $L/keep.so $L/liblsspa_hip.so; exit 1; }
     python3 - $v $lanes $O/${v}_l$lanes.json <<'PY'
 import json, sys
