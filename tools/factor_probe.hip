@@ -62,8 +62,11 @@ int main() {
       if (mode == 1 && rep == 1) {
         long long g[32];
         (void)hipMemcpyFromSymbol(g, HIP_SYMBOL(lsspa::g_stamps), sizeof g);
-        const char* nm[15] = {"start", "load", "f0", "p0", "t0", "f1", "p1", "t1", "f2", "p2", "t2", "f3", "p3", "-", "store"};
-        for (int i = 1; i < 15; ++i) if (i != 13) printf("  %-6s %+6.2f us\n", nm[i], (g[i] - g[i == 14 ? 12 : i - 1]) * 0.01);
+        // stamps of factor_block64_core: 2 + 3 kb after [pivot chain kb beside the trailing products of step kb - 1],
+        // 3 + 3 kb after the panel / inverse tiles of step kb
+        const int idx[11] = {0, 1, 2, 3, 5, 6, 8, 9, 11, 12, 14};
+        const char* nm[11] = {"start", "load", "f0", "p0", "t0+f1", "p1", "t1+f2", "p2", "t2+f3", "p3", "store"};
+        for (int i = 1; i < 11; ++i) printf("  %-6s %+6.2f us\n", nm[i], (g[idx[i]] - g[idx[i - 1]]) * 0.01);
       }
     }
   return 0;
