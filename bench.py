@@ -830,7 +830,12 @@ def main():
             legs[name] = {"error": repr(exc)}
             return None
 
-    if not args.no_ttt:
+    # several ranks: the legs below are off unless asked for (LSSPA_BENCH_TTT_MULTI=1; the rehearsal test asks) -- what a
+    # scaling run is for is the throughput line, and a leg that stalls in a collective would cost it
+    ttt_on = not args.no_ttt and (world == 1 or os.environ.get("LSSPA_BENCH_TTT_MULTI") == "1")
+    if not args.no_ttt and not ttt_on:
+        legs["time_to_tolerance"] = {"skipped": "several ranks: LSSPA_BENCH_TTT_MULTI=1 runs the sharded time-to-tolerance legs"}
+    if ttt_on:
         # the legs below run whole batches on ONE lane; the timed region (two lanes, half-batches) left the lane's
         # workspace at half that size -- grown here, untimed, as any second call of a process finds it (the cold start
         # of a process is what time_to_tolerance_e2e measures)
@@ -941,8 +946,8 @@ def main():
             got = guarded("time_to_tolerance_correlated", correlated_leg)
             if got is not None:
                 legs["time_to_tolerance_correlated"] = got
-        if out is not None:
-            out.update(legs)
+    if out is not None:
+        out.update(legs)
 
     if out is not None and world == 1 and not args.no_cpu_baseline:
         G, g, H, h = eng.gram()

@@ -33,7 +33,7 @@ def test_two_ranks_of_bench_py_on_one_gpu():
     assert len(lines1) == 1
     d1 = json.loads(lines1[0])
 
-    two = _bench(2, {"LSSPA_BENCH_REHEARSE_WORLD": "2"})
+    two = _bench(2, {"LSSPA_BENCH_REHEARSE_WORLD": "2", "LSSPA_BENCH_TTT_MULTI": "1"})
     assert two.returncode == 0, two.stderr[-3000:]
     lines2 = [ln for ln in two.stdout.splitlines() if ln.strip()]
     assert len(lines2) == 1, two.stdout[-2000:]            # exactly one JSON line: rank 0's

@@ -22,7 +22,7 @@ python3 bench.py --steps 5 --warmup 2 --p 5000 --rows 200000 --dtype f32 > $O/be
 python3 bench.py --steps 20 --warmup 5 --dtype f32 --reg 0 --no-cpu-baseline > $O/bench_c3_f32.json 2> $O/bench_c3_f32.err
 python3 bench.py --steps 20 --warmup 5 --lanes 1 --no-cpu-baseline --no-ttt --no-probe > $O/bench_c3_one_lane.json 2> $O/bench_c3_one_lane.err
 python3 bench.py --steps 80 --warmup 5 --no-cpu-baseline --no-ttt --no-probe > $O/bench_c3_80steps.json 2> $O/bench_c3_80steps.err
-LSSPA_BENCH_REHEARSE_WORLD=2 python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c3_two_ranks_one_gpu.json 2> $O/bench_c3_two_ranks_one_gpu.err
+LSSPA_BENCH_TTT_MULTI=1 LSSPA_BENCH_REHEARSE_WORLD=2 python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c3_two_ranks_one_gpu.json 2> $O/bench_c3_two_ranks_one_gpu.err
 LSSPA_BENCH_REHEARSE_DIST=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c3_rehearse.json 2> $O/bench_c3_rehearse.err
 LSSPA_BENCH_REHEARSE_DIST=1 python3 bench.py --steps 40 --warmup 8 --batch-size 16 --scaling strong --no-cpu-baseline --no-ttt > $O/bench_c3_strong16_rehearse.json 2> $O/bench_c3_strong16_rehearse.err
 echo bench done
