@@ -993,6 +993,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
       }
     }
   }
+  PSTAMP(15);
   __syncthreads();
   block64_put<T, NT>(nb, s_dinv, tid);
   __syncthreads();
@@ -1113,10 +1114,16 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
       const int c = I0 + rb_e[sy] + si;
       double v[8], t[8];
       double tot = 0.0;
+      // (16-byte reads, all of them before the first select: a guarded element read becomes a branch with a full wait
+      // behind it, and eight of them a chain of eight LDS round trips -- 11-24 us a tile instead of 2-5 for the store)
+      vec_t rawv[8 / VE];
+#pragma unroll
+      for (int q = 0; q < 8 / VE; ++q) rawv[q] = Tr<T>::lds_load(s_out + (rb_e[sy] + si) * RK_LD + 8 * sh + VE * q);
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int jl = 16 * xp + 8 * sh + q;
-        const double raw = (double)s_out[(rb_e[sy] + si) * RK_LD + 8 * sh + q];
+        const double raw = (double)rawv[q / VE][q % VE];
         v[q] = (J0 + jl < p && c < p) ? raw : 0.0;
         t[q] = s_z[jl] * v[q];
         tot += t[q];

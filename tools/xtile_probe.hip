@@ -30,19 +30,26 @@ int main(int argc, char** argv) {
   (void)hipMalloc(&A, (size_t)n_mats * p_pad * p_pad * 8); (void)hipMalloc(&Dinv, (size_t)n_mats * nblk * 4096 * 8);
   (void)hipMalloc(&X, (size_t)n_ord * p_pad * p_pad * 8);
   (void)hipMalloc(&diag0, (size_t)n_mats * p_pad * 8); (void)hipMalloc(&info, 64); (void)hipMemset(info, 0, 64);
+  // the fused lift scan of the X tiles (argv[3] = 0 switches it off): row flags, running sums, partial sums
+  const int scan_mode = argc > 3 ? atoi(argv[3]) : 2;
+  int32_t* rflags; double *run, *Ppart;
+  (void)hipMalloc(&rflags, (size_t)n_mats * 4); (void)hipMalloc(&run, (size_t)n_ord * p_pad * 8);
+  (void)hipMalloc(&Ppart, (size_t)n_ord * 16 * p_pad * 8);
+  PanelLift pl = {rflags, run, Ppart, (int64_t)16 * p_pad, 1000, scan_mode};
   std::vector<double> d0((size_t)n_mats * p_pad, 2.0);
   (void)hipMemcpy(diag0, d0.data(), d0.size() * 8, hipMemcpyHostToDevice);
   const int n_panel = p_pad / 128 - 1;
   for (int rep = 0; rep < 3; ++rep) {
     hipLaunchKernelGGL(fill_spd, dim3(8192), dim3(256), 0, 0, A, p_pad, n_mats);
-    (void)launch_chol2_diag(A, Dinv, diag0, 1e-13, info, p_pad, n_mats, 0, 0);
+    (void)launch_chol2_diag(A, Dinv, diag0, 1e-13, info, p_pad, n_mats, 0, 0, rflags);
     (void)hipDeviceSynchronize();
     for (int Jo = 0; Jo <= n_panel; ++Jo) {
       std::vector<long long> zero(PST_SLOTS * PST_PHASES, 0);
       (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pstamps), zero.data(), zero.size() * 8);
       hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
       (void)hipEventRecord(e0);
-      hipError_t le = launch_chol2_panel(A, Dinv, diag0, 1e-13, info, p_pad, Jo, n_mats, 0, 0, flags, p_live, X, n_ord);
+      hipError_t le = launch_chol2_panel(A, Dinv, diag0, 1e-13, info, p_pad, Jo, n_mats, 0, 0, flags, p_live, X, n_ord,
+                                           scan_mode ? &pl : nullptr);
       (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
       if (le != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(le)); return 1; }
       float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -77,6 +84,7 @@ int main(int argc, char** argv) {
                (t[0] - first) * 0.01, (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01,
                (t[(kind[0] == 't') ? 7 : 6] - t[0]) * 0.01);
         if (kind[0] == 't') printf("  (update %5.1f  factor %5.1f)", (t[6] - t[4]) * 0.01, (t[7] - t[6]) * 0.01);
+        if (kind[0] == 'X' && scan_mode) printf("  (waited for row p: %4.2f; store incl. scan)", (t[15] - t[14]) * 0.01);
         printf("\n");
       }
     }
