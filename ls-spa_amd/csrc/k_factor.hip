@@ -916,7 +916,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
   // scan: lane -> row lane >> 1 of the wave's 32 (sub-tile (lane >> 5), its row (lane >> 1) & 15), half lane & 1 of the
   // chunk's 16 columns; column sums: lane -> column l15 of the chunk over the rows 8 l4 .. 8 l4 + 7
   const int sy = lane >> 5, si = (lane >> 1) & 15, sh = lane & 1;
-  double run_c = 0.0, yt_c = 0.0, z_mine = 0.0;
+  double run_c = 0.0, yt_c = 0.0, z_mine = 0.0, d_run = 0.0;
   double psum[8] = {};
   // two-level solve on the accumulators (they hold -C^T):
   //   X1^T = L11^-1 C1^T ;  -C2^T += L21 X1^T ;  X2^T = L22^-1 C2^T
@@ -1008,6 +1008,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
     yt_c = (c < p) ? (double)__hip_atomic_load(Bt + cm_off(p_pad, p, c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                    : 0.0;
     run_c = (I0 == J0) ? 0.0 : tl.run[c];
+    d_run = 2.0 * (yt_c - run_c);
   }
   tri_mult(1);
 #else
@@ -1042,6 +1043,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
     yt_c = (c < p) ? (double)__hip_atomic_load(Bt + cm_off(p_pad, p, c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                    : 0.0;
     run_c = (I0 == J0) ? 0.0 : tl.run[c];
+    d_run = 2.0 * (yt_c - run_c);
   }
 #endif
 
@@ -1112,10 +1114,13 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
     if (scan) {
       const int p = tl.p;
       const int c = I0 + rb_e[sy] + si;
-      double v[8], t[8];
-      double tot = 0.0;
+      // Few fp64 VECTOR instructions: beside a workgroup in its k-loop every one of them waits for the matrix pipe it
+      // shares with that wave's matrix instructions -- 265 cycles an instruction beside a pure stream of them, 8.5 alone
+      // (tools/mfma_cap_probe.hip).  d_run = 2 (y~ - N) is what is carried; with the lane's inclusive partial sums pi of
+      // t = z v the term of column q is  e = v (d0 - (pi[q-1] + pi[q])).
+      double v[8], pi[8];
       // (16-byte reads, all of them before the first select: a guarded element read becomes a branch with a full wait
-      // behind it, and eight of them a chain of eight LDS round trips -- 11-24 us a tile instead of 2-5 for the store)
+      // behind it, and eight of them a chain of eight LDS round trips)
       vec_t rawv[8 / VE];
 #pragma unroll
       for (int q = 0; q < 8 / VE; ++q) rawv[q] = Tr<T>::lds_load(s_out + (rb_e[sy] + si) * RK_LD + 8 * sh + VE * q);
@@ -1125,18 +1130,16 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
         const int jl = 16 * xp + 8 * sh + q;
         const double raw = (double)rawv[q / VE][q % VE];
         v[q] = (J0 + jl < p && c < p) ? raw : 0.0;
-        t[q] = s_z[jl] * v[q];
-        tot += t[q];
+        const double t = s_z[jl] * v[q];
+        pi[q] = q ? pi[q - 1] + t : t;
       }
       // the other half of the row (the neighbouring lane): the second half starts behind the first one's total
-      const double other = __shfl_xor(tot, 1, 64);
-      double before = run_c + (sh ? other : 0.0);
+      const double other = __shfl_xor(pi[7], 1, 64);
+      const double d0 = sh ? fma(-2.0, other, d_run) : d_run;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        s_e[(lane >> 1) * SE_LD + 8 * sh + q] = v[q] * (2.0 * (yt_c - before) - t[q]);
-        before += t[q];
-      }
-      run_c += tot + other;
+      for (int q = 0; q < 8; ++q)
+        s_e[(lane >> 1) * SE_LD + 8 * sh + q] = v[q] * (d0 - (q ? pi[q - 1] + pi[q] : pi[0]));
+      d_run = fma(-2.0, pi[7] + other, d_run);
       __builtin_amdgcn_wave_barrier();
       // column l15 of the chunk over eight of the wave's rows; the four row groups and the four waves meet at the end
       double sum = 0.0;
@@ -1147,7 +1150,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
     }
   }
   if (scan) {
-    if (sh == 0) tl.run[I0 + rb_e[sy] + si] = run_c;
+    if (sh == 0) tl.run[I0 + rb_e[sy] + si] = fma(-0.5, d_run, yt_c);      // N = y~ - d_run / 2
     __syncthreads();      // every wave is done with its e tile: the region takes the 16 partial sums of each column
     double* const s_f = reinterpret_cast<double*>(s_a);      // [4 waves x 4 row groups][128]
 #pragma unroll

@@ -78,6 +78,59 @@ static void run_rand(int grid, int block, int iters, double* out, long long* cyc
          cs / grid / n_inst, cmax / n_inst);
 }
 
+// What vector fp64 arithmetic costs beside matrix fp64 arithmetic on the SAME SIMD: workgroups of eight waves, waves 0-3
+// (one per SIMD) run the matrix loop (or idle, mode 0), waves 4-7 a loop of v_fma_f64 -- eight independent chains
+// (ILP 8) or one dependent chain (ILP 1) -- and report their own cycles per instruction.
+template <int ILP>
+__global__ __launch_bounds__(512) void k_beside(double* out, long long* cyc, int iters, int matrix_on, double a0) {
+  const int w = threadIdx.x >> 6;
+  if (w < 4) {
+    if (!matrix_on) return;
+    d4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = d4{0, 0, 0, 0};
+    const double a = a0 + threadIdx.x * 1e-9, b = 1e-9 + threadIdx.x * 3e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    return;
+  }
+  double x[8];
+  for (int i = 0; i < 8; ++i) x[i] = a0 + i + threadIdx.x * 1e-9;
+  const double m = 0.999999999, c = 1e-12;
+  // the vector waves run a quarter as many groups: they should end well inside the matrix waves' run
+  const long long t0 = clock64();
+  for (int it = 0; it < iters / 4; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (ILP == 8) x[i] = fma(x[i], m, c);
+      else x[0] = fma(x[0], m, c);
+    }
+  }
+  const long long t1 = clock64();
+  double s = 0;
+  for (int i = 0; i < 8; ++i) s += x[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0 && w == 4) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int ILP>
+static void run_beside(int grid, int iters, int matrix_on, double* out, long long* cyc) {
+  hipLaunchKernelGGL(k_beside<ILP>, dim3(grid), dim3(512), 0, 0, out, cyc, iters, matrix_on, 1.0000001);
+  (void)hipDeviceSynchronize();
+  hipLaunchKernelGGL(k_beside<ILP>, dim3(grid), dim3(512), 0, 0, out, cyc, iters, matrix_on, 1.0000001);
+  (void)hipDeviceSynchronize();
+  std::vector<long long> c(grid);
+  (void)hipMemcpy(c.data(), cyc, grid * 8, hipMemcpyDeviceToHost);
+  double cs = 0;
+  for (int i = 0; i < grid; ++i) cs += c[i];
+  printf("v_fma_f64, %s, beside %s: %6.1f cycles per instruction of a wave\n", ILP == 8 ? "eight independent chains" : "one dependent chain",
+         matrix_on ? "a wave of fp64 matrix instructions on its SIMD" : "nothing", cs / grid / ((double)(iters / 4) * 8));
+}
+
 template <int GAP>
 static void run(int grid, int block, int iters, double* out, long long* cyc, long long* wall) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -114,6 +167,11 @@ int main() {
   run<4>(256, 512, 10000, out, cyc, wall);
   run<16>(256, 512, 10000, out, cyc, wall);
   run<32>(256, 512, 5000, out, cyc, wall);
+  printf("-- vector fp64 beside matrix fp64 on one SIMD (256 workgroups of eight waves)\n");
+  run_beside<8>(256, 20000, 0, out, cyc);
+  run_beside<8>(256, 20000, 1, out, cyc);
+  run_beside<1>(256, 20000, 0, out, cyc);
+  run_beside<1>(256, 20000, 1, out, cyc);
   printf("-- operands with random mantissas, two waves per SIMD, growing number of busy CUs, then burst length\n");
   for (int grid : {8, 64, 128, 192, 256}) run_rand(grid, 512, 5000, out, cyc, wall);
   for (int iters : {500, 2000, 20000, 100000}) run_rand(256, 512, iters, out, cyc, wall);
