@@ -303,7 +303,9 @@ __device__ __forceinline__ T bcast_lane(T v, int src) {   // value of v in lane 
 }
 
 // 1 / d to working precision without the division sequence: hardware reciprocal + two Newton steps
-// (the elimination's critical path runs through this once per pivot)
+// (the elimination's critical path runs through this once per pivot).  Measured (tools/rcp_probe.hip, 2^20 arguments over
+// 40 binades): v_rcp_f64 4.6e-8 relative, one step 2.2e-15 (10 ulp), two steps 0.5 ulp; v_rsq_f64 5.2e-8 / 4.1e-15 / 0.6 ulp:
+// one step would save two of a pivot's nine fp64 vector instructions and cost the factors an order of magnitude.
 template <typename T>
 __device__ __forceinline__ T fast_recip(T d) {
   if constexpr (sizeof(T) == 8) {
