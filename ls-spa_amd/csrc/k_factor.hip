@@ -1062,13 +1062,14 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
   //     e = V^T[c][j] (2 (y~_c - N_{j-1}[c]) - z_j V^T[c][j]),        lift_j = z_j sum_c e / |y_test|^2
   // (k_lift.hip).  A separate kernel used to read all of V^T back for this (1.2 GB and 0.23 ms a C3 step).  Here the
   // tile does it for its own 128 x 128 block while the block passes through LDS on its way out: the 16 columns of a
-  // chunk are scanned by four lanes a row (a 4-lane prefix), the row sums of e are reduced over the wave's rows through
-  // a small LDS tile, and N is carried from panel to panel in tl.run (tile (I', J) runs in launch J, tile (I', J + 1) in
-  // the next).  z of THIS panel is row p of the training matrix's L tile (last block row, J) and y~ of a diagonal tile's
-  // rows is row p of the test matrix's: both are written by workgroups of the SAME launch.  Those are dispatched before
-  // every X tile (the grid is L tiles first, and each XCD hands out its workgroups in order), they depend on nothing, and
-  // they raise a flag when their tile is stored; the X tile waits for it here, after its own k-loop and solve, i.e. in
-  // practice never (a wait that outlasts ~60 ms sets info bit 2 and goes on: no hang).  The last launch needs no flag.
+  // chunk are scanned by two lanes a row (eight columns each and one exchange), the sums of e over the wave's rows go
+  // through a small LDS tile, and N is carried from panel to panel in tl.run (tile (I', J) runs in launch J, tile
+  // (I', J + 1) in the next).  z of THIS panel is row p of the training matrix's L tile (last block row, J) and y~ of a
+  // diagonal tile's rows is row p of the test matrix's: both are written by workgroups of the SAME launch.  Those are
+  // dispatched before every X tile (the grid is L tiles first, and each XCD hands out its workgroups in order), they
+  // depend on nothing, and they raise a flag when their tile is stored; the X tile polls it in front of its solve's last
+  // stage (above), i.e. in practice it never waits: tools/xtile_probe.hip stamps 0.04-2.2 us there, the poll's own round
+  // trip (a wait that outlasts ~60 ms sets LSSPA_INFO_SCAN_WAIT and goes on: no hang).  The last launch needs no flag.
   PSTAMP(3);
   if (scan) {
     __syncthreads();      // every wave is done with the solve's blocks in region A
