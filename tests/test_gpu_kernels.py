@@ -270,7 +270,8 @@ def test_stats_checkpoint_resume(engine):
     engine.history_enable(0)
 
 
-@pytest.mark.parametrize("p,n,m,prec", [(100, 400, 300, "float64"), (130, 400, 300, "float64"), (257, 900, 700, "float64"),
+@pytest.mark.parametrize("p,n,m,prec", [(100, 400, 300, "float64"), (130, 400, 300, "float64"), (255, 900, 700, "float64"),
+                                        (256, 900, 700, "float64"), (257, 900, 700, "float64"),
                                         (257, 900, 700, "float32"), (383, 1200, 1100, "float64"),
                                         (640, 2000, 1800, "float32"), (1000, 3000, 2500, "float64")])
 def test_vt_tiles_agree_with_the_strip_kernel(p, n, m, prec):
