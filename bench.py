@@ -708,10 +708,11 @@ def main():
                     "algorithmic_flops_per_launch": flops, "avg_launch_ms": per_class[dom]["avg_launch_ms"],
                     "launches_per_step": lpb,
                     "traffic_gbps": (traffic / (per_class[dom]["avg_launch_ms"] * 1e-3) / 1e9) if traffic else None,
-                    "note": "peak = vendor fp64 (fp32) matrix figure; on random operands at the steady-state clock the "
-                            "isolated k-loop of these kernels sustains ~60 TFLOP/s fp64 fed from HBM and ~67 fed from the "
-                            "caches, the vendor library's GEMM 69-71 at 8192^3 and 59-67 batched at 1024^3 "
-                            "(profiles/r02_kloop_ceiling.log)"}
+                    "note": "peak = vendor fp64 (fp32) matrix figure, which the chip does sustain: a register-resident loop of "
+                            "v_mfma_f64_16x16x4 runs at 77.6 TFLOP/s on all 256 CUs for as long as asked "
+                            "(profiles/r04_mfma_cap_probe.log); the isolated k-loop of these kernels sustains ~60 TFLOP/s fp64 "
+                            "fed from HBM and ~67 fed from the caches, the vendor library's GEMM 69-71 at 8192^3 and 59-67 "
+                            "batched at 1024^3 (profiles/r02_kloop_ceiling.log)"}
         if prof_full is not None and prof_full.get(dom, (0, 0))[1]:
             ms_f, n_f = prof_full[dom]
             lpb_f = n_f / args.steps
