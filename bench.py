@@ -75,6 +75,11 @@ def parse():
                     help="skip the third pass (full-batch launches on one lane): profiler runs, where every launch of a "
                          "kernel should have the timed region's size")
     ap.add_argument("--no-ttt", action="store_true", help="skip the time-to-tolerance runs")
+    ap.add_argument("--no-full-run", action="store_true", help="skip the many-check run of the public call (full_run)")
+    ap.add_argument("--full-run-batches", type=int, default=0,
+                    help="checks of the full_run leg: ls_spa(method='argsort', batch_size=B, num_batches=this, tolerance=0); "
+                         "0 = auto: 128 (BASELINE config 4's num_batches) up to p = 2000, 64 (the reference's default "
+                         "max_samples = 8192 at batch 128) for p <= 126, 16 beyond p = 2000")
     ap.add_argument("--data", choices=("gaussian", "correlated"), default="gaussian",
                     help="gaussian: BASELINE.md section 3 (default_rng(0)), the data the metric is quoted on; correlated: "
                          "the reference's own generator (experiments/ground_truth_medium.py:74-106, seed 42) at the same "
@@ -831,11 +836,28 @@ def main():
             legs[name] = {"error": repr(exc)}
             return None
 
-    # several ranks: the legs below are off unless asked for (LSSPA_BENCH_TTT_MULTI=1; the rehearsal test asks) -- what a
-    # scaling run is for is the throughput line, and a leg that stalls in a collective would cost it
-    ttt_on = not args.no_ttt and (world == 1 or os.environ.get("LSSPA_BENCH_TTT_MULTI") == "1")
+    # several ranks: the legs below run on the sharded loop as well (round 5: BASELINE's metric is "permutations/sec +
+    # time-to-1e-2-tolerance ... 1/2/4/8 GPUs", and a scaling run that skipped them reported half of it).  A leg that
+    # stalls in a collective must not hang the job: a watchdog ends THIS rank with a non-zero status once the legs
+    # have taken longer than LSSPA_BENCH_TTT_LIMIT_S seconds (default 180) -- the launcher (or torch.distributed.run)
+    # then ends the others; nothing is re-executed.  LSSPA_BENCH_TTT_MULTI=0 switches the legs off with several ranks.
+    ttt_on = not args.no_ttt and (world == 1 or os.environ.get("LSSPA_BENCH_TTT_MULTI", "1") != "0")
     if not args.no_ttt and not ttt_on:
-        legs["time_to_tolerance"] = {"skipped": "several ranks: LSSPA_BENCH_TTT_MULTI=1 runs the sharded time-to-tolerance legs"}
+        legs["time_to_tolerance"] = {"skipped": "several ranks and LSSPA_BENCH_TTT_MULTI=0"}
+    watchdog = None
+    if ttt_on and world > 1:
+        import threading
+        limit_s = float(os.environ.get("LSSPA_BENCH_TTT_LIMIT_S", "180"))
+
+        def give_up():
+            sys.stderr.write(f"[bench] rank {rank}: the time-to-tolerance legs took longer than {limit_s:.0f} s "
+                             "(a stalled collective?): leaving with status 5\n")
+            sys.stderr.flush()
+            os._exit(5)
+
+        watchdog = threading.Timer(limit_s, give_up)
+        watchdog.daemon = True
+        watchdog.start()
     if ttt_on:
         # the legs below run whole batches on ONE lane; the timed region (two lanes, half-batches) left the lane's
         # workspace at half that size -- grown here, untimed, as any second call of a process finds it (the cold start
@@ -928,6 +950,58 @@ def main():
         else:
             legs["time_to_tolerance_e2e"] = {"skipped": "several ranks: see time_to_tolerance* for the sharded loop"}
 
+        # The public call over a run of MANY checks (round 5): every time-to-tolerance leg above stops at check 1 or 2,
+        # and the headline drives run_batch with orderings drawn beforehand -- neither shows what the sampler, the
+        # estimator and the driver cost per batch.  tolerance = 0: the stop rule is evaluated at every check and never
+        # fires.  One GPU: ls_spa() on the host arrays (reduction over PCIe included in `seconds`, not in the loop's
+        # rate); several ranks: the sharded loop on the resident problem.
+        if not args.no_full_run:
+            nb = args.full_run_batches or (64 if p <= 126 else (128 if p <= 2000 else 16))
+
+            def full_run():
+                reps = []
+                for rep in range(2):
+                    barrier()
+                    tm = {"check_s": []}
+                    t0 = time.perf_counter()
+                    if world == 1:
+                        r = ls_spa(*host, reg=reg, method="argsort", batch_size=B, num_batches=nb, tolerance=0.0, seed=42,
+                                   device=local, precision="float32" if args.dtype == "f32" else "float64", _timings=tm)
+                        checks, n_done = len(r.error_history), B * nb
+                        sum_attr, r2 = float(r.attribution.sum()), float(r.r_squared)
+                    else:
+                        eng.set_lanes(args.lanes)
+                        res = run_estimator(eng, p, max_samples=B * nb, batch_size=B, tolerance=0.0, seed=42, perms=None,
+                                            antithetical=True, return_attribution_history=False, method="argsort",
+                                            error_estimator="device", comm=comm, timings=tm, lookahead="auto")
+                        eng.set_lanes(1)
+                        checks, n_done = len(res[3]), int(res[5])
+                        sum_attr, r2 = float(res[0].sum()), None
+                    barrier()
+                    reps.append((time.perf_counter() - t0, tm, checks, n_done, sum_attr, r2))
+                secs, tm, checks, n_done, sum_attr, r2 = min(reps, key=lambda v: v[0])
+                per_check = [1e3 * v for v in tm.pop("check_s")]
+                loop_s = tm.get("sampler", 0.0) + tm.get("estimator", 0.0) + tm.get("sampling", 0.0)
+                return {"seconds": secs, "seconds_sampling_loop": loop_s, "first_call_seconds": reps[0][0],
+                        "samples": n_done, "orderings": 2 * n_done, "checks": checks,
+                        "orderings_per_s": 2 * n_done / loop_s, "orderings_per_s_whole_call": 2 * n_done / secs,
+                        "fraction_of_value": None, "tolerance": 0.0, "error_estimator": "device (default of the method)",
+                        "host_seconds": {k: round(v, 6) for k, v in tm.items()},
+                        "estimator_host_ms_per_check": {
+                            "first": per_check[0] if per_check else None, "last": per_check[-1] if per_check else None,
+                            "median": float(np.median(per_check)) if per_check else None,
+                            "max": max(per_check) if per_check else None},
+                        "sum_attribution": sum_attr, "r_squared": r2,
+                        "note": f"ls_spa(method='argsort', batch_size={B}, num_batches={nb}, tolerance=0.0): the public call "
+                                "through sampler (SciPy Sobol + argsort on a helper thread), driver, device estimator "
+                                "(running form, checks deferred by one) and statistics; orderings_per_s is over the "
+                                "sampling loop (host_seconds sampler + estimator + sampling), seconds the whole call "
+                                "(one GPU: engine, reduction over PCIe, final fit included); estimator_host_ms_per_check = "
+                                "host time inside the estimator calls of each check (enqueue + reading the deferred result)"}
+            got = guarded("full_run", full_run)
+            if got is not None:
+                legs["full_run"] = got
+
         # SURVEY 8(d)'s secondary workload: the reference's own correlated generator at the same shape.  On the iid
         # Gaussian data the stop rule fires at the first check (error ~3e-5 against 1e-2: one batch); here the
         # attribution is spread over correlated features and the loop has to run
@@ -947,8 +1021,12 @@ def main():
             got = guarded("time_to_tolerance_correlated", correlated_leg)
             if got is not None:
                 legs["time_to_tolerance_correlated"] = got
+    if watchdog is not None:
+        watchdog.cancel()
     if out is not None:
         out.update(legs)
+        if isinstance(out.get("full_run"), dict) and "orderings_per_s" in out["full_run"]:
+            out["full_run"]["fraction_of_value"] = out["full_run"]["orderings_per_s"] / out["value"]
 
     if out is not None and world == 1 and not args.no_cpu_baseline:
         G, g, H, h = eng.gram()

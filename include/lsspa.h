@@ -136,6 +136,9 @@ int lsspa_lift_discard(lsspa_ctx* ctx, int32_t ticket);
  * and merges stay in batch order on the context's stream.  Results do not depend on the setting. */
 int lsspa_set_lanes(lsspa_ctx* ctx, int32_t n);
 int lsspa_get_info(lsspa_ctx* ctx, int32_t* info);
+/* The same word without waiting for batches that were launched and never collected (they may still be running on a
+ * lane): the bits of every batch whose samples were collected are in it.  lsspa_get_info waits for everything. */
+int lsspa_get_info_collected(lsspa_ctx* ctx, int32_t* info);
 
 /* a4 -- replaces merge_sample_mean / merge_sample_cov (ls_spa/ls_spa.py:103-119, :212-216).
  * The pending-batch buffer is a device fp64 array [1 + p + p*p] = [n_b, sum(l - mu), sum (l - mu)(l - mu)^T];
@@ -175,6 +178,40 @@ int lsspa_history_append(lsspa_ctx* ctx, const double* lifts, int64_t rows);
 int lsspa_error_draws(lsspa_ctx* ctx, const double* xi, int64_t ld_xi, int64_t n_local, int64_t n_total);
 int lsspa_error_buffer(lsspa_ctx* ctx, void** device_ptr, int64_t* count);
 int lsspa_error_quantiles(lsspa_ctx* ctx, double* feature_errors, double* overall_error);
+
+/* a5, running form (what ls_spa(error_estimator='device') uses since round 5) -- the same estimator with a cost per
+ * check that does not depend on the number of samples, and no host random numbers.  Xi[d][k], draw d of sample k, is a
+ * pure function of (seed, k, d): Philox4x32-10 with key = seed and counter = (k, d / 2), Box-Muller on its four
+ * output words (k_error.hip; the generator's published known-answer vectors and the normals themselves are pinned by
+ * tests/philox_ref.py through lsspa_error_xi).  The context keeps D = Xi L [1024][p] and s = Xi 1 [1024] over the
+ * samples folded in so far; at a check x = (D - s mean^T) / sqrt(n (n - 1)), which given the lift vectors is
+ * N(0, C_unbiased / n) exactly as the reference's draws are (ls_spa/ls_spa.py:334-336), and the quantiles follow as
+ * above (:337-340).  Successive checks share the columns of Xi of the samples they share (the reference redraws).
+ *   lsspa_error_running_enable  : allocate and zero D, s (and a small staging of lift vectors: every sample that
+ *                                 lsspa_lift_batch / _collect accumulates is staged until the next advance);
+ *                                 lsspa_stats_reset zeroes D and s again; lsspa_history_enable(ctx, 0) switches it off
+ *   lsspa_error_advance         : fold the staged lift vectors in; they are samples first_id, first_id + stride, ...
+ *                                 of the run (the driver deals sample i of a chunk to rank i mod world, so the ids
+ *                                 -- hence Xi and every result -- do not depend on the number of ranks)
+ *   lsspa_error_running_draws   : x of this context's samples into the draws buffer (lsspa_error_buffer): with
+ *                                 several ranks all-reduce it (lsspa_error_allreduce) -- x is linear in (D, s)
+ *   lsspa_error_quantiles_enqueue / lsspa_error_result : the quantile kernels, then feature errors, overall error, the
+ *                                 running mean and n copied into pinned slot `slot` (0 .. 15) behind an event -- nothing
+ *                                 waits.  lsspa_error_result reads a slot: wait != 0 blocks on its event, wait == 0
+ *                                 polls (*ready = 0: not yet).  This is what lets the driver evaluate the stop rule of
+ *                                 check k while the samples of check k + 1 are already running (they are dropped on a
+ *                                 stop), so the estimator is off the critical path.
+ *   lsspa_error_state_get / _set: D [1024][p] and s [1024] to / from host memory (checkpoint / resume)
+ *   lsspa_error_xi              : test hook -- the normals Xi [1024][count] of `count` sample ids, to host memory */
+int lsspa_error_running_enable(lsspa_ctx* ctx, uint64_t seed);
+int lsspa_error_advance(lsspa_ctx* ctx, int64_t first_id, int64_t stride);
+int lsspa_error_running_draws(lsspa_ctx* ctx, int64_t n_total);
+int lsspa_error_quantiles_enqueue(lsspa_ctx* ctx, int32_t slot);
+int lsspa_error_result(lsspa_ctx* ctx, int32_t slot, int32_t wait, int32_t* ready, double* feature_errors,
+                       double* overall_error, double* mean, int64_t* n);
+int lsspa_error_state_get(lsspa_ctx* ctx, double* D, double* s);
+int lsspa_error_state_set(lsspa_ctx* ctx, const double* D, const double* s);
+int lsspa_error_xi(lsspa_ctx* ctx, uint64_t seed, int64_t first_id, int64_t stride, int64_t count, double* xi);
 
 /* (e) -- collectives.  The reference is single-process; these implement the multi-GPU form of its running-statistics
  * merge (ls_spa/ls_spa.py:103-119, :212-216): orderings are dealt over one process per GPU and the ONLY data-path

@@ -12,6 +12,19 @@
 //   row_norms_kernel : ||x_d||_2, one wave per draw, fixed summation order
 //   quantile_kernel  : one workgroup per feature (+ one for the norms): bitonic sort of 1024 values
 //                      in LDS, numpy's default linear-interpolation quantile.
+//
+// Running form (round 5): the cost of a check must not grow with the number of samples n, or a run of many checks is
+// bound by the estimator instead of the sampling (128 checks at p = 1000 drew 1.08e9 host normals).  Xi is made a pure
+// function of (seed, sample id k, draw d) -- Philox4x32-10 keyed by the seed, counter = (k, d / 2), Box-Muller on the
+// four output words -- so a column of Xi never has to be stored or drawn twice, and
+//       D = Xi L   [1024][p]      s = Xi 1   [1024]
+// stay in HBM: a chunk of new samples adds  Xi_new L_new  and  Xi_new 1  (xi_fill_kernel + the GEMM above in its
+// accumulate mode), a check is  x = (D - s mu^T) / sqrt(n (n - 1))  (running_draws_kernel) and the two quantile
+// kernels.  At every check x has, given the lift vectors, exactly the distribution N(0, C_unbiased / n) the reference
+// samples from; successive checks reuse the columns of Xi of the samples they share (the reference redraws: its
+// checks are independent given the samples, ours are positively correlated -- each one's distribution is the same).
+// With several GPUs each rank holds D and s of its own samples; x is linear in them, so ONE all-reduce of the
+// per-rank x (the same buffer and call as before) gives every rank the same draws.
 #include "kernels.h"
 #include "tiles.h"
 
@@ -19,10 +32,14 @@ namespace lsspa {
 
 constexpr int ND = 1024;  // draws, as in the reference
 
+// ACC = false: draws = (Xi H - rowsum(Xi) mean^T) * scale.   ACC = true (running form): draws += Xi H and
+// rowsum_acc += rowsum(Xi) (by the workgroups of feature tile 0), nothing centred or scaled.
+template <bool ACC>
 __global__ __launch_bounds__(256, 2) void draws_kernel(const double* __restrict__ Xi, int ldxi,
                                                        const double* __restrict__ H, int ldh, int n_pad,
                                                        const double* __restrict__ mean, double scale, int p,
-                                                       double* __restrict__ draws, int ldd) {
+                                                       double* __restrict__ draws, int ldd,
+                                                       double* __restrict__ rowsum_acc) {
   __shared__ __attribute__((aligned(16))) double s_rk[64 * RK_LD];
   __shared__ __attribute__((aligned(16))) double s_kc[16 * KC_LD];
   __shared__ double s_rs[64];
@@ -88,10 +105,66 @@ __global__ __launch_bounds__(256, 2) void draws_kernel(const double* __restrict_
 #pragma unroll
       for (int y = 0; y < 2; ++y) {
         const int a = c0 + 32 * w + 16 * y + l15;
-        const double v = (a < p) ? (acc[x][y][r] - rsum * mean[a]) * scale : 0.0;
-        draws[(int64_t)(d0 + dl) * ldd + a] = v;
+        if (ACC) {
+          if (a < p) draws[(int64_t)(d0 + dl) * ldd + a] += acc[x][y][r];
+        } else {
+          const double v = (a < p) ? (acc[x][y][r] - rsum * mean[a]) * scale : 0.0;
+          draws[(int64_t)(d0 + dl) * ldd + a] = v;
+        }
       }
     }
+  if (ACC && blockIdx.y == 0 && tid < 64) rowsum_acc[d0 + tid] += s_rs[tid];
+}
+
+// ---- running form: counter-based normals ------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11): ten rounds of two 32 x 32 -> 64 multiplies and xors, the key bumped by the
+// Weyl constants between rounds.  Pinned by the generator's published known-answer vectors (tests/philox_ref.py).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t m0 = (uint64_t)0xD2511F53u * c0, m1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(m1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)m1;
+    const uint32_t n2 = (uint32_t)(m0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)m0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Xi[2 j][k], Xi[2 j + 1][k] for sample id = first_id + k * stride: u1, u2 = the 53 high bits of (w0, w1), (w2, w3)
+// plus a half, over 2^53 -- both in (0, 1) --, then Box-Muller.  Columns k >= count are zero.
+__global__ __launch_bounds__(256) void xi_fill_kernel(uint64_t seed, int64_t first_id, int64_t stride, int count,
+                                                      int n_pad, double* __restrict__ Xi) {
+  const int k = blockIdx.x * 256 + threadIdx.x;   // column (sample)
+  const int j = blockIdx.y;                       // draw pair
+  if (k >= n_pad) return;
+  double z0 = 0.0, z1 = 0.0;
+  if (k < count) {
+    const uint64_t id = (uint64_t)(first_id + (int64_t)k * stride);
+    uint32_t w[4];
+    philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)j, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    const double u1 = ((double)(((uint64_t)(w[0] >> 5) << 26) | (uint64_t)(w[1] >> 6)) + 0.5) * 0x1p-53;
+    const double u2 = ((double)(((uint64_t)(w[2] >> 5) << 26) | (uint64_t)(w[3] >> 6)) + 0.5) * 0x1p-53;
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    z0 = rad * cs;
+    z1 = rad * sn;
+  }
+  Xi[(int64_t)(2 * j) * n_pad + k] = z0;
+  Xi[(int64_t)(2 * j + 1) * n_pad + k] = z1;
+}
+
+// x[d][a] = (D[d][a] - s[d] mean[a]) * scale; padding columns zero
+__global__ __launch_bounds__(256) void running_draws_kernel(const double* __restrict__ D, const double* __restrict__ s,
+                                                            const double* __restrict__ mean, double scale, int p,
+                                                            int ld, double* __restrict__ draws) {
+  const int d = blockIdx.y;
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= ld) return;
+  draws[(int64_t)d * ld + a] = (a < p) ? (D[(int64_t)d * ld + a] - s[d] * mean[a]) * scale : 0.0;
 }
 
 // norms[d] = ||draws[d][0..p)||_2, one wave per draw
@@ -148,8 +221,34 @@ hipError_t launch_error_draws(const double* Xi, int ldxi, const double* H, int l
   if (p < 1 || n_pad < KCH || n_pad % KCH != 0 || ldxi < n_pad || (ldxi & 1) || ldh % 128 != 0 ||
       ldh < n_tiles * 128 || ldd < n_tiles * 128)
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL(draws_kernel, dim3(ND / 64, n_tiles), dim3(256), 0, st, Xi, ldxi, H, ldh, n_pad, mean, scale,
-                     p, draws, ldd);
+  hipLaunchKernelGGL(draws_kernel<false>, dim3(ND / 64, n_tiles), dim3(256), 0, st, Xi, ldxi, H, ldh, n_pad, mean,
+                     scale, p, draws, ldd, (double*)nullptr);
+  return hipGetLastError();
+}
+
+hipError_t launch_error_xi(uint64_t seed, int64_t first_id, int64_t stride, int count, int n_pad, double* Xi,
+                           hipStream_t st) {
+  if (count < 0 || n_pad < KCH || n_pad % KCH != 0 || count > n_pad || stride < 1 || first_id < 0)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(xi_fill_kernel, dim3((n_pad + 255) / 256, ND / 2), dim3(256), 0, st, seed, first_id, stride,
+                     count, n_pad, Xi);
+  return hipGetLastError();
+}
+
+hipError_t launch_error_accumulate(const double* Xi, int n_pad, const double* L, int ldh, int p, double* D,
+                                   double* s, hipStream_t st) {
+  const int n_tiles = (p + 127) / 128;
+  if (p < 1 || n_pad < KCH || n_pad % KCH != 0 || ldh % 128 != 0 || ldh < n_tiles * 128) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(draws_kernel<true>, dim3(ND / 64, n_tiles), dim3(256), 0, st, Xi, n_pad, L, ldh, n_pad,
+                     (const double*)nullptr, 1.0, p, D, ldh, s);
+  return hipGetLastError();
+}
+
+hipError_t launch_error_running_draws(const double* D, const double* s, const double* mean, double scale, int p,
+                                      int ld, double* draws, hipStream_t st) {
+  if (p < 1 || ld < p) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(running_draws_kernel, dim3((ld + 255) / 256, ND), dim3(256), 0, st, D, s, mean, scale, p, ld,
+                     draws);
   return hipGetLastError();
 }
 

@@ -188,6 +188,16 @@ hipError_t launch_error_draws(const double* Xi, int ldxi, const double* H, int l
                               const double* mean, double scale, int p, double* draws, int ldd, hipStream_t st);
 hipError_t launch_error_quantiles(const double* draws, int ldd, int p, double* norms, double* out,
                                   hipStream_t st);
+// Running form of the estimator (k_error.hip): Xi[d][k] = standard normal made by Philox4x32-10 from (seed, sample id
+// first_id + k stride, draw d), k < count, zero up to n_pad (a multiple of 16), Xi [1024][n_pad];
+// D[1024][ldh] += Xi L and s[1024] += Xi 1 for the chunk's lift vectors L [n_pad][ldh]; and the check's draws
+// x = (D - s mean^T) * scale.
+hipError_t launch_error_xi(uint64_t seed, int64_t first_id, int64_t stride, int count, int n_pad, double* Xi,
+                           hipStream_t st);
+hipError_t launch_error_accumulate(const double* Xi, int n_pad, const double* L, int ldh, int p, double* D,
+                                   double* s, hipStream_t st);
+hipError_t launch_error_running_draws(const double* D, const double* s, const double* mean, double scale, int p,
+                                      int ld, double* draws, hipStream_t st);
 
 // unit test hook: D = A(16x4) * B(4x16) on one wave through Tr<T>::mfma / acc_row (fp64 or fp32)
 hipError_t launch_mfma_probe(const double* A, const double* B, double* D, int f32, hipStream_t st);

@@ -117,6 +117,16 @@ struct lsspa_ctx {
   bool reduce_open = false;
   int64_t hist_cap = 0, hist_n = 0;
   int ldh() const { return ((p + 127) / 128) * 128; }
+  // running form of the estimator (lsspa_error_running_*): D = Xi L, s = Xi 1 of the samples folded in so far; the
+  // history buffer then only stages the lift vectors between a collect and the next lsspa_error_advance
+  bool run_on = false;
+  uint64_t run_seed = 0;
+  DevBuf<double> Dacc, sacc;
+  static constexpr int RES_SLOTS = 16;
+  double* res_h = nullptr;            // pinned [RES_SLOTS][2 p + 2]: feature errors, overall error, mean, n
+  size_t res_h_count = 0;
+  hipEvent_t res_ev[RES_SLOTS] = {nullptr};
+  bool res_valid[RES_SLOTS] = {false};
   int flags = 0;
   // collectives (RCCL), see comm.h
   Comm* comm = nullptr;
@@ -345,6 +355,7 @@ int set_dims(lsspa_ctx* ctx, int p, int m, int tri) {
   // so does the lift history (row stride): it has to be enabled again for the new problem
   ctx->hist_cap = 0;
   ctx->hist_n = 0;
+  ctx->run_on = false;
   return LSSPA_OK;
 }
 
@@ -358,6 +369,11 @@ int stats_reset(lsspa_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->info_d.ptr, 0, sizeof(int32_t) * 8, ctx->stream));
   ctx->pend_dirty = false;
   ctx->hist_n = 0;
+  if (ctx->run_on) {
+    HIPCHK(hipMemsetAsync(ctx->Dacc.ptr, 0, ctx->Dacc.count * 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->sacc.ptr, 0, ctx->sacc.count * 8, ctx->stream));
+    for (bool& v : ctx->res_valid) v = false;
+  }
   return LSSPA_OK;
 }
 
@@ -969,6 +985,10 @@ int lsspa_destroy(lsspa_ctx* ctx) try {
     }
   }
   dev_free(ctx->hist); dev_free(ctx->xi_d); dev_free(ctx->draws); dev_free(ctx->err_out);
+  dev_free(ctx->Dacc); dev_free(ctx->sacc);
+  if (ctx->res_h) (void)hipHostFree(ctx->res_h);
+  for (hipEvent_t& e : ctx->res_ev)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->ev_problem) (void)hipEventDestroy(ctx->ev_problem);
   comm_destroy(ctx->comm);
   ctx->comm = nullptr;
@@ -1569,6 +1589,19 @@ int lsspa_get_info(lsspa_ctx* ctx, int32_t* info) try {
   return abi_caught(ctx);
 }
 
+int lsspa_get_info_collected(lsspa_ctx* ctx, int32_t* info) try {
+  if (!ctx || !info) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  // the context's stream is ordered behind every batch that was collected (lift_collect waits for the lane's last
+  // kernel before the statistics read its lift vectors): the bits of those batches are in place when it has drained
+  HIPCHK(hipMemcpyAsync(info, ctx->info_d.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
+}
+
 int lsspa_stats_reset(lsspa_ctx* ctx) try {
   if (!ctx) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
@@ -1655,8 +1688,11 @@ int lsspa_history_enable(lsspa_ctx* ctx, int64_t capacity) try {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->hist_n = 0;
   ctx->hist_cap = 0;
+  ctx->run_on = false;
   if (capacity == 0) {
     dev_free(ctx->hist);
+    dev_free(ctx->Dacc);
+    dev_free(ctx->sacc);
     return LSSPA_OK;
   }
   const int64_t rows = ((capacity + KCH - 1) / KCH) * KCH;   // the draws kernel reads whole 16-row chunks
@@ -1757,6 +1793,167 @@ int lsspa_error_quantiles(lsspa_ctx* ctx, double* feature_errors, double* overal
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::copy(out.begin(), out.begin() + p, feature_errors);
   *overall_error = out[p];
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
+}
+
+// ---- running form of the device-side estimator -------------------------------------------------------------
+int lsspa_error_running_enable(lsspa_ctx* ctx, uint64_t seed) try {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  // the staging of the lift vectors is the history buffer (one chunk at a time; it grows on demand)
+  TRY(lsspa_history_enable(ctx, 256));
+  const size_t ldh = ctx->ldh();
+  TRY(dev_alloc(ctx, ctx->Dacc, (size_t)ERR_DRAWS * ldh));
+  TRY(dev_alloc(ctx, ctx->sacc, (size_t)ERR_DRAWS));
+  HIPCHK(hipMemsetAsync(ctx->Dacc.ptr, 0, ctx->Dacc.count * 8, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->sacc.ptr, 0, ctx->sacc.count * 8, ctx->stream));
+  const size_t need = (size_t)lsspa_ctx::RES_SLOTS * (2 * (size_t)ctx->p + 2);
+  if (ctx->res_h_count < need) {
+    if (ctx->res_h) (void)hipHostFree(ctx->res_h);
+    ctx->res_h = nullptr;
+    ctx->res_h_count = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->res_h), need * 8, hipHostMallocDefault) != hipSuccess) {
+      ctx->res_h = nullptr;
+      (void)hipGetLastError();
+      return ctx->fail(LSSPA_ERR_NOMEM, "hipHostMalloc (result slots of the estimator)");
+    }
+    ctx->res_h_count = need;
+  }
+  for (int k = 0; k < lsspa_ctx::RES_SLOTS; ++k) {
+    if (!ctx->res_ev[k]) HIPCHK(hipEventCreateWithFlags(&ctx->res_ev[k], hipEventDisableTiming));
+    ctx->res_valid[k] = false;
+  }
+  ctx->run_seed = seed;
+  ctx->run_on = true;
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
+}
+
+int lsspa_error_advance(lsspa_ctx* ctx, int64_t first_id, int64_t stride) try {
+  if (!ctx || first_id < 0 || stride < 1) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  if (!ctx->run_on) return ctx->fail(LSSPA_ERR_STATE, "the running estimator is not enabled");
+  const int64_t cnt = ctx->hist_n;
+  if (cnt == 0) return LSSPA_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n_pad = ((cnt + KCH - 1) / KCH) * KCH;
+  TRY(dev_alloc(ctx, ctx->xi_d, (size_t)ERR_DRAWS * n_pad));
+  ProfScope ps(ctx, LSSPA_K_ERROR);
+  HIPCHK(launch_error_xi(ctx->run_seed, first_id, stride, (int)cnt, (int)n_pad, ctx->xi_d.ptr, ctx->stream));
+  // rows cnt .. n_pad of the staging hold older chunks' (finite) lift vectors: they meet the zero columns of Xi
+  HIPCHK(launch_error_accumulate(ctx->xi_d.ptr, (int)n_pad, ctx->hist.ptr, ctx->ldh(), ctx->p, ctx->Dacc.ptr,
+                                 ctx->sacc.ptr, ctx->stream));
+  ctx->hist_n = 0;
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
+}
+
+int lsspa_error_running_draws(lsspa_ctx* ctx, int64_t n_total) try {
+  if (!ctx || n_total < 0) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  if (!ctx->run_on) return ctx->fail(LSSPA_ERR_STATE, "the running estimator is not enabled");
+  if (ctx->hist_n != 0) return ctx->fail(LSSPA_ERR_STATE, "collected samples not yet folded in: call lsspa_error_advance");
+  if (ctx->pend_dirty) return ctx->fail(LSSPA_ERR_STATE, "merge the pending batch first: the mean is stale");
+  HIPCHK(hipSetDevice(ctx->device));
+  const double nt = (double)n_total;
+  const double scale = 1.0 / sqrt(nt * (nt - 1.0));   // inf for n_total = 1, as numpy's division gives
+  ProfScope ps(ctx, LSSPA_K_ERROR);
+  HIPCHK(launch_error_running_draws(ctx->Dacc.ptr, ctx->sacc.ptr, ctx->mean.ptr, scale, ctx->p, ctx->ldh(),
+                                    ctx->draws.ptr, ctx->stream));
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
+}
+
+int lsspa_error_quantiles_enqueue(lsspa_ctx* ctx, int32_t slot) try {
+  if (!ctx || slot < 0 || slot >= lsspa_ctx::RES_SLOTS) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  if (!ctx->run_on) return ctx->fail(LSSPA_ERR_STATE, "the running estimator is not enabled");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t p = ctx->p;
+  {
+    ProfScope ps(ctx, LSSPA_K_ERROR);
+    HIPCHK(launch_error_quantiles(ctx->draws.ptr, ctx->ldh(), (int)p, ctx->err_out.ptr + p + 1, ctx->err_out.ptr,
+                                  ctx->stream));
+  }
+  double* dst = ctx->res_h + (size_t)slot * (2 * p + 2);
+  HIPCHK(hipMemcpyAsync(dst, ctx->err_out.ptr, (p + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dst + p + 1, ctx->mean.ptr, p * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dst + 2 * p + 1, ctx->state_n.ptr, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->res_ev[slot], ctx->stream));
+  ctx->res_valid[slot] = true;
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
+}
+
+int lsspa_error_result(lsspa_ctx* ctx, int32_t slot, int32_t wait, int32_t* ready, double* feature_errors,
+                       double* overall_error, double* mean, int64_t* n) try {
+  if (!ctx || slot < 0 || slot >= lsspa_ctx::RES_SLOTS || !ready) return LSSPA_ERR_ARG;
+  if (!ctx->run_on || !ctx->res_valid[slot]) return ctx->fail(LSSPA_ERR_STATE, "nothing was enqueued into this slot");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (wait) {
+    HIPCHK(hipEventSynchronize(ctx->res_ev[slot]));
+  } else {
+    const hipError_t e = hipEventQuery(ctx->res_ev[slot]);
+    if (e == hipErrorNotReady) {
+      (void)hipGetLastError();
+      *ready = 0;
+      return LSSPA_OK;
+    }
+    HIPCHK(e);
+  }
+  const size_t p = ctx->p;
+  const double* src = ctx->res_h + (size_t)slot * (2 * p + 2);
+  if (feature_errors) std::copy(src, src + p, feature_errors);
+  if (overall_error) *overall_error = src[p];
+  if (mean) std::copy(src + p + 1, src + 2 * p + 1, mean);
+  if (n) *n = (int64_t)llround(src[2 * p + 1]);
+  *ready = 1;
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
+}
+
+int lsspa_error_state_get(lsspa_ctx* ctx, double* D, double* s) try {
+  if (!ctx || !D || !s) return LSSPA_ERR_ARG;
+  if (!ctx->run_on) return ctx->fail(LSSPA_ERR_STATE, "the running estimator is not enabled");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpy2DAsync(D, (size_t)ctx->p * 8, ctx->Dacc.ptr, (size_t)ctx->ldh() * 8, (size_t)ctx->p * 8, ERR_DRAWS,
+                          hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(s, ctx->sacc.ptr, (size_t)ERR_DRAWS * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
+}
+
+int lsspa_error_state_set(lsspa_ctx* ctx, const double* D, const double* s) try {
+  if (!ctx || !D || !s) return LSSPA_ERR_ARG;
+  if (!ctx->run_on) return ctx->fail(LSSPA_ERR_STATE, "the running estimator is not enabled");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpy2DAsync(ctx->Dacc.ptr, (size_t)ctx->ldh() * 8, D, (size_t)ctx->p * 8, (size_t)ctx->p * 8, ERR_DRAWS,
+                          hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->sacc.ptr, s, (size_t)ERR_DRAWS * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
+}
+
+int lsspa_error_xi(lsspa_ctx* ctx, uint64_t seed, int64_t first_id, int64_t stride, int64_t count, double* xi) try {
+  if (!ctx || !xi || count < 1 || count > (1 << 20) || first_id < 0 || stride < 1) return LSSPA_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n_pad = ((count + KCH - 1) / KCH) * KCH;
+  TRY(dev_alloc(ctx, ctx->xi_d, (size_t)ERR_DRAWS * n_pad));
+  HIPCHK(launch_error_xi(seed, first_id, stride, (int)count, (int)n_pad, ctx->xi_d.ptr, ctx->stream));
+  HIPCHK(hipMemcpy2DAsync(xi, (size_t)count * 8, ctx->xi_d.ptr, (size_t)n_pad * 8, (size_t)count * 8, ERR_DRAWS,
+                          hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return LSSPA_OK;
 } catch (...) {
   return abi_caught(ctx);

@@ -137,9 +137,10 @@ def _min_norm_theta(G, g):
 
 
 # 3: the identity carries `history`, `precision` and `data`, the state `attribution_history` / `history_sum` (round 3);
+# 4: the device estimator's state is its running sums (err_D, err_s) instead of the lift history (round 5);
 # a file of another version is refused by name instead of failing on a missing key.  With return_attribution_history the
 # whole n x p history is rewritten at every save (I/O quadratic in the run length): checkpoint long history runs sparsely.
-_CKPT_VERSION = 3
+_CKPT_VERSION = 4
 
 
 def _ckpt_path(path, comm):
@@ -254,7 +255,7 @@ def prepare_sampling(p, *, max_samples, batch_size, seed, perms, antithetical, m
 
 def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms, antithetical,
                   return_attribution_history, method, error_estimator, comm=None, chunk_cap=None,
-                  checkpoint=None, prepared=None, lookahead=1, timings=None):
+                  checkpoint=None, prepared=None, lookahead=1, timings=None, defer=None):
     """The sampling loop on an engine whose problem is already loaded.  Returns
     (attribution, attribution_errors, overall_error, error_history, attribution_history, n).
 
@@ -267,7 +268,6 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
     ('estimator', reads of the statistics included) and in everything else of the loop ('sampling')."""
     import time as _time
     t_loop0 = _time.perf_counter()
-    t_sampler = t_estimator = 0.0
     comm = comm or _Comm()
     if prepared is None:
         prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
@@ -275,6 +275,25 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
     rng, source, batch_size, antithetical, max_samples, never_stop = prepared
     if batch_size < 1:
         raise ValueError("batch_size must be positive")
+    if source.independent and not isinstance(source, S.PrefetchedSource):
+        # the QMC samplers draw ahead of the loop on a helper thread (their stream is nobody else's)
+        source = S.PrefetchedSource(source)
+    try:
+        return _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_samples, never_stop,
+                              tolerance=tolerance, seed=seed, return_attribution_history=return_attribution_history,
+                              method=method, error_estimator=error_estimator, chunk_cap=chunk_cap,
+                              checkpoint=checkpoint, lookahead=lookahead, timings=timings, defer=defer,
+                              t_loop0=t_loop0)
+    finally:
+        if hasattr(source, "close"):
+            source.close()
+
+
+def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_samples, never_stop, *, tolerance, seed,
+                   return_attribution_history, method, error_estimator, chunk_cap, checkpoint, lookahead, timings,
+                   defer, t_loop0):
+    import time as _time
+    t_sampler = t_estimator = 0.0
 
     estimate = p >= 9
     keep_lifts = return_attribution_history or error_estimator == "lowrank"
@@ -285,9 +304,8 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
     engine.reset_stats()
     on_device = error_estimator == "device" and estimate
     if on_device:
-        first = batch_size if max_samples >= _NO_CAP else max_samples
-        engine.history_enable(max(16, -(-first // comm.world)))
-    local_idx = []   # global sample numbers of this rank's history rows, in order
+        # the running form (include/lsspa.h): D = Xi L and s = Xi 1 stay in HBM, Xi a function of (seed, sample, draw)
+        engine.error_running_enable(int(np.random.SeedSequence(seed).generate_state(1, np.uint64)[0]))
     feat_err, total_err = np.zeros(p), 0.0
     err_hist, hist_parts, lift_parts = [], [], []
     hist_sum = np.zeros(p)
@@ -316,8 +334,7 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
             if error_estimator == "lowrank":
                 lift_parts.append(st["lifts"])
             elif on_device:
-                engine.history_append(st["lifts"])
-                local_idx.append(st["local_idx"])
+                engine.set_error_state(st["err_D"], st["err_s"])
             if (i >= max_samples or (estimate and err_hist and total_err < tolerance and not never_stop)):
                 stop = True   # the saved run had already finished
 
@@ -331,9 +348,36 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
         if error_estimator == "lowrank":
             state["lifts"] = np.concatenate(lift_parts) if lift_parts else np.zeros((0, p))
         elif on_device:
-            state["lifts"] = engine.history()
-            state["local_idx"] = np.concatenate(local_idx) if local_idx else np.zeros(0, dtype=np.int64)
+            state["err_D"], state["err_s"] = engine.error_state()
         _save_checkpoint(checkpoint, comm, state)
+
+    # The device estimator's checks are ENQUEUED, not waited for: x = (D - s mean^T) / sqrt(n (n - 1)), the all-reduce of
+    # the per-rank x, the quantile kernels and a copy of (errors, running mean, n) into a pinned slot run on the context's
+    # stream behind the chunk's statistics.  `defer` checks may be outstanding: the stop rule of check k is evaluated
+    # when check k + defer has been enqueued -- the samples in between are already running and are dropped on a stop,
+    # the results are those of check k (its own copy of the running mean) -- so the host never waits for the newest
+    # work and the estimator is off the critical path.  The FIRST check of a run is always waited
+    # for (a run on easy data ends there with nothing wasted), and a chunk that takes tens of milliseconds is too
+    # (the round trip of a check is 0.2 ms: nothing to hide, and up to defer + 1 such chunks would run for nothing).
+    # The point at which a check is resolved depends on counts only, never on timing: every rank takes the same decisions.
+    outstanding = []     # (sample count, slot), oldest first
+    slot_turn = [0]
+    can_defer = on_device and checkpoint is None and source.independent and not chunk_cap
+    if defer is None:
+        per_rank = -(-min(int(batch_size), max_samples) // comm.world) * (2 if antithetical else 1)
+        # a chunk's kernels, at 40 TFLOP/s, under 50 ms
+        defer = 1 if (can_defer and per_rank * float(p) ** 3 / 4e13 < 0.05) else 0
+    defer = int(defer) if can_defer else 0
+    if not 0 <= defer < engine.RESULT_SLOTS - 1 if on_device else False:
+        raise ValueError("defer must be between 0 and the number of result slots - 2")
+
+    def enqueue_check(n):
+        engine.error_running_draws(n)
+        comm.allreduce_draws(engine)
+        slot = slot_turn[0]
+        slot_turn[0] = (slot + 1) % engine.RESULT_SLOTS
+        engine.error_quantiles_enqueue(slot)
+        outstanding.append((n, slot))
 
     def estimate_now(n, cov_b=None):
         nonlocal feat_err, total_err, t_estimator
@@ -343,12 +387,8 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
                 centred = np.concatenate(lift_parts) - mean
                 feat_err, total_err = error_estimates_lowrank(rng, centred, n)
             elif on_device:
-                # same generator call as 'lowrank'; each rank multiplies the columns of its own samples
-                xi = rng.standard_normal((2 ** 10, n))
-                mine_idx = np.concatenate(local_idx) if local_idx else np.zeros(0, dtype=np.int64)
-                engine.error_draws(xi if len(mine_idx) == n else xi[:, mine_idx], n)
-                comm.allreduce_draws(engine)
-                feat_err, total_err = engine.error_quantiles()
+                enqueue_check(n)
+                feat_err, total_err, _, _ = engine.error_result(outstanding.pop()[1], wait=True)
             else:
                 if cov_b is None:
                     _, _, cov_b = engine.stats(want_cov=True)
@@ -420,6 +460,25 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
             first += len(e[1])
         queue.extend(entries)
 
+    stopped_at = None      # (mean, n) of the check whose stop rule fired (device estimator)
+    resolved = [0]
+
+    def resolve_due(limit):
+        """Read the oldest outstanding checks until at most `limit` are left; True if one of them stops the run."""
+        nonlocal feat_err, total_err, stopped_at, t_estimator
+        while len(outstanding) > limit:
+            t_e0 = _time.perf_counter()
+            n_k, slot = outstanding.pop(0)
+            feat_err, total_err, mean_k, _ = engine.error_result(slot, wait=True)
+            err_hist.append(total_err)
+            resolved[0] += 1
+            t_estimator += _time.perf_counter() - t_e0
+            if total_err < tolerance and not never_stop:
+                stopped_at = (mean_k, n_k)
+                outstanding.clear()      # later checks: of samples the reference would never have drawn
+                return True
+        return False
+
     while not stop:
         if not queue:
             refill(i)
@@ -437,7 +496,8 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
             else:
                 local = engine.run_batch(mine, antithetical, want_lifts=keep_lifts, accumulate=acc_mode)
             if on_device:
-                local_idx.append(np.arange(i + comm.rank, i + n_new, comm.world))
+                # this rank's samples of the chunk are samples i + rank, i + rank + world, ... of the run
+                engine.error_advance(i + comm.rank, comm.world)
         if not single:
             comm.allreduce_pending(engine)
             engine.merge()
@@ -461,11 +521,24 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
         if n_new < want and not chunk_cap:
             stop = True  # the source ran dry inside a chunk
         check = estimate and (i % batch_size == 0 or i == max_samples - 1)
-        if check:
+        if check and on_device:
+            t_e0 = _time.perf_counter()
+            enqueue_check(i)
+            t_estimator += _time.perf_counter() - t_e0
+            pending = False
+            halt = resolve_due(defer if resolved[0] else 0)
+            if timings is not None and "check_s" in timings:
+                timings["check_s"].append(_time.perf_counter() - t_e0)
+            if halt:
+                break
+            if checkpoint is not None:       # (defer is 0 with a checkpoint: the engine's state is check i's)
+                _, mean, _ = engine.stats(want_cov=False)
+                save_now(i)
+        elif check:
             t_e0 = _time.perf_counter()
             _, mean, cov_now = engine.stats(want_cov=error_estimator == "reference")
             t_estimator += _time.perf_counter() - t_e0
-            if group > 1 and not on_device and not queue and not stop and i < max_samples:
+            if group > 1 and not queue and not stop and i < max_samples:
                 refill(i)      # in flight while the host evaluates the stop rule below
             estimate_now(i, cov_now)
             pending = False
@@ -478,9 +551,18 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
     for tk in {id(e[3]): e[3] for e in queue if e[3] is not None}.values():
         engine.discard_batch(tk)     # launched, never accumulated
 
-    n, mean, _ = engine.stats(want_cov=False)
-    if estimate and pending and n > 0:
-        estimate_now(n)
+    if stopped_at is None:
+        resolve_due(0)               # the run ended with checks still outstanding: they are read in order
+    if stopped_at is not None:
+        # the engine's statistics may have moved on by up to `defer` checks' samples: the run's results are the
+        # stopping check's own copies
+        mean, n = stopped_at
+        if return_attribution_history and hist_parts:
+            hist_parts = [np.concatenate(hist_parts)[:n]]
+    else:
+        n, mean, _ = engine.stats(want_cov=False)
+        if estimate and pending and n > 0:
+            estimate_now(n)
     history = None
     if return_attribution_history:
         history = np.concatenate(hist_parts) if hist_parts else np.zeros((0, p))
@@ -495,7 +577,7 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
            tolerance=1e-2, seed=42, perms=None, antithetical=True, return_attribution_history=False, *,
            method=None, num_batches=None, return_history=None, device=0, error_estimator=None,
            precision="float64", row_sharded=False, checkpoint=None, comm=None, lookahead=1, lanes="auto",
-           _engine=None, _comm=None, _timings=None):
+           _engine=None, _comm=None, _timings=None, _defer=None):
     """Estimates the Shapley attribution of the out-of-sample R^2 of a least-squares fit.
 
     Positional parameters, defaults and behaviour follow cvxgrp/ls-spa
@@ -605,17 +687,22 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
             tm["reduction_pin"], tm["reduction_copy_gram"] = parts["pin"], parts["h2d_gram"]
             tm["reduction_unpin"], tm["reduction_finalize"] = parts["unpin"], parts["finalize"]
             tm["reduction_host"] = whole - sum(parts.values())
+        # theta and r^2 (ls_spa/ls_spa.py:240-243) depend on the reduced problem only: computed BEFORE the sampling loop,
+        # so that the call does not end behind whatever the loop launched ahead of a stop and never collected
+        t0 = _time.perf_counter()
+        theta, r_squared, info = engine.full_fit()
+        t0 = lap("final_fit", t0)
         attribution, feat_err, total_err, err_hist, history, _ = run_estimator(
             engine, p, max_samples=max_samples, batch_size=batch_size, tolerance=tolerance, seed=seed,
             perms=perms, antithetical=antithetical, return_attribution_history=return_attribution_history,
             method=method, error_estimator=error_estimator, comm=comm, checkpoint=checkpoint, prepared=prepared,
-            lookahead=lookahead, timings=tm)
+            lookahead=lookahead, timings=tm, defer=_defer)
         t0 = _time.perf_counter()
-        theta, r_squared, info = engine.full_fit()
-        if (info | engine.info()) & 4:      # LSSPA_INFO_SCAN_WAIT: a hand-over inside a panel launch timed out
+        bits = info | (engine.info_collected() if hasattr(engine, "info_collected") else engine.info())
+        if bits & 4:      # LSSPA_INFO_SCAN_WAIT: a hand-over inside a panel launch timed out
             raise LSSPANativeError("the fused lift scan gave up waiting for a row of its panel: the lift vectors of this "
                                    "run are not valid (engine fault; the lift kernel of its own is developer flag 512)")
-        if (info | engine.info()) & 1:
+        if bits & 1:
             warnings.warn("a permuted Gram matrix was not numerically positive definite; the attribution "
                           "of collinear features is not meaningful (the reference's is not either)",
                           RuntimeWarning, stacklevel=2)

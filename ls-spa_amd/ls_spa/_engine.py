@@ -249,6 +249,12 @@ class HipEngine:
         self._check(self._lib.lsspa_get_info(self._h, C.byref(v)))
         return v.value
 
+    def info_collected(self) -> int:
+        """The info bits of every batch collected so far, without waiting for batches launched and dropped."""
+        v = C.c_int32()
+        self._check(self._lib.lsspa_get_info_collected(self._h, C.byref(v)))
+        return v.value
+
     def reset_stats(self):
         self._check(self._lib.lsspa_stats_reset(self._h))
 
@@ -315,6 +321,52 @@ class HipEngine:
         feat, tot = np.empty(self.p), C.c_double()
         self._check(self._lib.lsspa_error_quantiles(self._h, N.dptr(feat), C.byref(tot)))
         return feat, tot.value
+
+    # ---- running form of the device-side estimator (include/lsspa.h) ---------------------
+    RESULT_SLOTS = 16
+
+    def error_running_enable(self, seed: int):
+        """D = Xi L and s = Xi 1 stay in HBM; Xi is a function of (seed, sample id, draw)."""
+        self._check(self._lib.lsspa_error_running_enable(self._h, int(seed) & (2 ** 64 - 1)))
+
+    def error_advance(self, first_id: int, stride: int = 1):
+        """Fold the samples accumulated since the last call in: they are samples first_id, first_id + stride, ..."""
+        self._check(self._lib.lsspa_error_advance(self._h, int(first_id), int(stride)))
+
+    def error_running_draws(self, n_total: int):
+        self._check(self._lib.lsspa_error_running_draws(self._h, int(n_total)))
+
+    def error_quantiles_enqueue(self, slot: int):
+        self._check(self._lib.lsspa_error_quantiles_enqueue(self._h, int(slot)))
+
+    def error_result(self, slot: int, wait: bool = True):
+        """(feature_errors, overall_error, mean, n) of a slot, or None if wait is False and it is not there yet."""
+        feat, mean = np.empty(self.p), np.empty(self.p)
+        tot, n, ready = C.c_double(), C.c_int64(), C.c_int32()
+        self._check(self._lib.lsspa_error_result(self._h, int(slot), int(bool(wait)), C.byref(ready), N.dptr(feat),
+                                                 C.byref(tot), N.dptr(mean), C.byref(n)))
+        if not ready.value:
+            return None
+        return feat, tot.value, mean, n.value
+
+    def error_state(self):
+        D, s = np.empty((1024, self.p)), np.empty(1024)
+        self._check(self._lib.lsspa_error_state_get(self._h, N.dptr(D), N.dptr(s)))
+        return D, s
+
+    def set_error_state(self, D, s):
+        D = np.ascontiguousarray(D, dtype=np.float64)
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        if D.shape != (1024, self.p) or s.shape != (1024,):
+            raise ValueError("D must be (1024, p) and s (1024,)")
+        self._check(self._lib.lsspa_error_state_set(self._h, N.dptr(D), N.dptr(s)))
+
+    def error_xi(self, seed: int, first_id: int, stride: int, count: int):
+        """Test hook: the estimator's normals of `count` sample ids, (1024, count)."""
+        out = np.empty((1024, int(count)))
+        self._check(self._lib.lsspa_error_xi(self._h, int(seed) & (2 ** 64 - 1), int(first_id), int(stride), int(count),
+                                             N.dptr(out)))
+        return out
 
     # ---- profiling / test hooks ---------------------------------------------------------
     def profile(self, on: bool):

@@ -55,6 +55,7 @@ SIGNATURES = {
     "lsspa_lift_discard": (C.c_int, [_vp, _i32]),
     "lsspa_set_lanes": (C.c_int, [_vp, _i32]),
     "lsspa_get_info": (C.c_int, [_vp, _pi32]),
+    "lsspa_get_info_collected": (C.c_int, [_vp, _pi32]),
     "lsspa_stats_reset": (C.c_int, [_vp]),
     "lsspa_stats_pending": (C.c_int, [_vp, C.POINTER(_vp), _pi64]),
     "lsspa_stats_merge": (C.c_int, [_vp]),
@@ -66,6 +67,14 @@ SIGNATURES = {
     "lsspa_error_draws": (C.c_int, [_vp, _pd, _i64, _i64, _i64]),
     "lsspa_error_buffer": (C.c_int, [_vp, C.POINTER(_vp), _pi64]),
     "lsspa_error_quantiles": (C.c_int, [_vp, _pd, _pd]),
+    "lsspa_error_running_enable": (C.c_int, [_vp, C.c_uint64]),
+    "lsspa_error_advance": (C.c_int, [_vp, _i64, _i64]),
+    "lsspa_error_running_draws": (C.c_int, [_vp, _i64]),
+    "lsspa_error_quantiles_enqueue": (C.c_int, [_vp, _i32]),
+    "lsspa_error_result": (C.c_int, [_vp, _i32, _i32, _pi32, _pd, _pd, _pd, _pi64]),
+    "lsspa_error_state_get": (C.c_int, [_vp, _pd, _pd]),
+    "lsspa_error_state_set": (C.c_int, [_vp, _pd, _pd]),
+    "lsspa_error_xi": (C.c_int, [_vp, C.c_uint64, _i64, _i64, _i64, _pd]),
     "lsspa_profile_enable": (C.c_int, [_vp, _i32]),
     "lsspa_profile_get": (C.c_int, [_vp, _i32, _pd, _pi64]),
     "lsspa_profile_reset": (C.c_int, [_vp]),

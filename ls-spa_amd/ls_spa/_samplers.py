@@ -176,5 +176,90 @@ class PermutohedronSource(ArgsortSource):
             left -= len(self._points(min(left, 4096)))
 
 
+class PrefetchedSource(OrderingSource):
+    """Draws an independent source's orderings ahead of the loop that consumes them, on a helper thread.
+
+    SciPy's Sobol points and the row-wise argsort of a chunk take as long on the host as the chunk's kernels take on
+    the GPU (p = 1000: 2.9 ms per 128 orderings against 6 ms; p = 100: 25 ms for the 8192 orderings the GPU evaluates
+    in 2.4 ms), and between them the driver's thread is inside GIL-free library calls.  The helper keeps up to
+    ``ahead`` orderings ready (in blocks of ``block``; ``argsort`` and SciPy's generators release the GIL for most
+    of their time), `take` hands out exactly what the inner source would have: same stream, same chunk boundaries
+    are irrelevant (a QMC sequence continues across calls, tests/test_host_logic.py::test_samplers_match_fixtures).
+    Only for sources whose stream nobody else reads (``independent``)."""
+    independent = True
+
+    def __init__(self, inner, block=256, ahead=2048):
+        assert inner.independent
+        self._inner, self._block, self._ahead = inner, int(block), int(ahead)
+        self._cv = threading.Condition()
+        self._parts, self._ready = [], 0       # blocks drawn and not yet handed out
+        self._done = self._stop = False
+        self._error = None
+        self._thread = None
+
+    def skip(self, count):
+        assert self._thread is None, "skip before the first take"
+        self._inner.skip(count)
+
+    def _work(self):
+        try:
+            while True:
+                with self._cv:
+                    while self._ready >= self._ahead and not self._stop:
+                        self._cv.wait()
+                    if self._stop:
+                        return
+                got = self._inner.take(self._block)
+                with self._cv:
+                    if len(got):
+                        self._parts.append(got)
+                        self._ready += len(got)
+                    if len(got) < self._block:
+                        self._done = True
+                    self._cv.notify_all()
+                    if self._done:
+                        return
+        except BaseException as exc:      # handed to the consumer
+            with self._cv:
+                self._error, self._done = exc, True
+                self._cv.notify_all()
+
+    def take(self, count):
+        count = int(count)
+        if self._thread is None:
+            self._block = max(self._block, min(count, 4096))
+            self._ahead = max(self._ahead, 2 * self._block)
+            self._thread = threading.Thread(target=self._work, daemon=True)
+            self._thread.start()
+        out, need = [], count
+        with self._cv:
+            while need > 0:
+                while not self._parts and not self._done:
+                    self._cv.wait()
+                if self._error is not None:
+                    raise self._error
+                if not self._parts:
+                    break
+                head = self._parts[0]
+                if len(head) <= need:
+                    out.append(self._parts.pop(0))
+                else:
+                    out.append(head[:need])
+                    self._parts[0] = head[need:]
+                need -= len(out[-1])
+                self._ready -= len(out[-1])
+                self._cv.notify_all()
+        if not out:
+            return np.empty((0, getattr(self._inner, "_p", 0)), dtype=np.int64)
+        return out[0] if len(out) == 1 else np.concatenate(out)
+
+    def close(self):
+        with self._cv:
+            self._stop = True
+            self._cv.notify_all()
+        if self._thread is not None:
+            self._thread.join(timeout=5)
+
+
 def exact_source(p):
     return IterableSource(itertools.permutations(range(p)), p)

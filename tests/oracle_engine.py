@@ -5,6 +5,7 @@ sharding) be tested without a GPU.  TESTS ONLY -- the product never imports this
 import numpy as np
 
 import lsspa_oracle as O
+import philox_ref
 
 
 class OracleEngine:
@@ -99,6 +100,8 @@ class OracleEngine:
         self._n, self._mean, self._M2 = 0, np.zeros(p), np.zeros((p, p))
         self._pend = np.zeros(1 + p + p * p)
         self._hist = [] if getattr(self, "_hist_on", False) else None
+        if getattr(self, "_run_on", False):
+            self._D, self._s, self._staged = np.zeros((1024, p)), np.zeros(1024), []
 
     def run_batch(self, perms, antithetical, want_lifts=False, accumulate=True):
         perms = np.asarray(perms)
@@ -118,6 +121,8 @@ class OracleEngine:
         self._pend[1 + p:] += (D.T @ D).ravel()
         if self._hist is not None:
             self._hist.append(lifts)
+        if getattr(self, "_run_on", False):
+            self._staged.append(lifts)
 
     def pending_buffer(self):
         return self._pend
@@ -144,6 +149,8 @@ class OracleEngine:
 
     # lift history + thin-form error estimator (mirrors lsspa_history_* / lsspa_error_*)
     def history_enable(self, capacity):
+        if capacity == 0:
+            self._run_on = False
         self._hist_on = capacity > 0
         self._hist = [] if self._hist_on else None
         self._draws = np.zeros(1024 * self.p)
@@ -171,6 +178,47 @@ class OracleEngine:
         d = self._draws.reshape(1024, self.p)
         return np.quantile(np.abs(d), 0.95, axis=0), float(np.quantile(np.linalg.norm(d, axis=1), 0.95))
 
+    # running form (mirrors lsspa_error_running_* / _advance / _quantiles_enqueue / _result): D = Xi L, s = Xi 1 with the
+    # counter-based normals of tests/philox_ref.py; a check's results are computed when it is enqueued and handed out
+    # when its slot is read
+    RESULT_SLOTS = 16
+
+    def error_running_enable(self, seed):
+        self._run_on, self._run_seed = True, int(seed)
+        self._D, self._s = np.zeros((1024, self.p)), np.zeros(1024)
+        self._staged, self._slots = [], {}
+        self._draws = np.zeros(1024 * self.p)
+        self.enqueued = 0
+
+    def error_advance(self, first_id, stride=1):
+        if not self._staged:
+            return
+        L = np.concatenate(self._staged)
+        self._staged = []
+        xi = philox_ref.normals(self._run_seed, first_id + stride * np.arange(len(L)))
+        self._D += xi @ L
+        self._s += xi.sum(axis=1)
+
+    def error_running_draws(self, n_total):
+        assert not self._staged, "advance first"
+        with np.errstate(divide="ignore", invalid="ignore"):
+            d = (self._D - np.outer(self._s, self._mean)) / np.sqrt(n_total * (n_total - 1.0))
+        self._draws[:] = d.ravel()
+
+    def error_quantiles_enqueue(self, slot):
+        feat, tot = self.error_quantiles()
+        self._slots[slot] = (feat, tot, self._mean.copy(), self._n)
+        self.enqueued += 1
+
+    def error_result(self, slot, wait=True):
+        return self._slots[slot]
+
+    def error_state(self):
+        return self._D.copy(), self._s.copy()
+
+    def set_error_state(self, D, s):
+        self._D, self._s = np.array(D, dtype=float), np.array(s, dtype=float)
+
     def full_fit(self):
         R, F, q, qt = self._red
         theta = np.linalg.lstsq(R, q, rcond=None)[0]
@@ -178,6 +226,9 @@ class OracleEngine:
         return theta, float(r2), 0
 
     def info(self):
+        return 0
+
+    def info_collected(self):
         return 0
 
     def close(self):

@@ -33,7 +33,8 @@ def test_two_ranks_of_bench_py_on_one_gpu():
     assert len(lines1) == 1
     d1 = json.loads(lines1[0])
 
-    two = _bench(2, {"LSSPA_BENCH_REHEARSE_WORLD": "2", "LSSPA_BENCH_TTT_MULTI": "1"})
+    # (no LSSPA_BENCH_TTT_MULTI: since round 5 the time-to-tolerance legs run with several ranks by default)
+    two = _bench(2, {"LSSPA_BENCH_REHEARSE_WORLD": "2"})
     assert two.returncode == 0, two.stderr[-3000:]
     lines2 = [ln for ln in two.stdout.splitlines() if ln.strip()]
     assert len(lines2) == 1, two.stdout[-2000:]            # exactly one JSON line: rank 0's
@@ -55,6 +56,12 @@ def test_two_ranks_of_bench_py_on_one_gpu():
         assert d2[leg]["samples_at_stop"] == d1[leg]["samples_at_stop"], leg
         assert abs(d2[leg]["overall_error"] - d1[leg]["overall_error"]) <= 0.3 * d1[leg]["overall_error"] + 1e-12, leg
     assert "skipped" in d2["time_to_tolerance_e2e"]
+    # the many-check run: the public call on one GPU, the sharded loop with two ranks -- all 128 checks, same sample count
+    f1, f2 = d1["full_run"], d2["full_run"]
+    assert f1["checks"] == f2["checks"] == 129 and f1["samples"] == f2["samples"] == 16 * 128      # + the one at max - 1
+    assert abs(f1["sum_attribution"] - f1["r_squared"]) < 1e-10
+    assert abs(f2["sum_attribution"] - f1["sum_attribution"]) < 1e-11
+    assert f1["orderings_per_s"] > 0 and f2["orderings_per_s"] > 0
 
 
 def test_a_failing_rank_fails_the_job():

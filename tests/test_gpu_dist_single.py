@@ -76,7 +76,7 @@ def test_pending_buffer_is_a_zero_copy_device_tensor_and_allreduce_runs(golden):
         cf = TorchComm(force_collective=True)
         c = ls_spa(*d, perms=g["perms64"], batch_size=16, tolerance=0.0, row_sharded=True,
                    error_estimator="device", comm=cf)
-        e = ls_spa(*d, perms=g["perms64"], batch_size=16, tolerance=0.0, error_estimator="lowrank")
+        e = ls_spa(*d, perms=g["perms64"], batch_size=16, tolerance=0.0, error_estimator="device")
         np.testing.assert_allclose(c.attribution, b.attribution, rtol=0, atol=1e-13)
         np.testing.assert_allclose(c.theta, b.theta, rtol=1e-12)
         np.testing.assert_allclose(c.error_history, e.error_history, rtol=1e-9)

@@ -234,6 +234,68 @@ def test_history_and_error_estimator(engine, p, n_batches, bsz):
     engine.history_enable(0)
 
 
+@pytest.mark.parametrize("p,chunks,stride", [(12, (7, 9, 16), 1), (100, (16, 33), 2), (130, (13, 5, 64, 1), 3),
+                                             (300, (9, 40), 1)])
+def test_running_error_estimator(engine, p, chunks, stride):
+    """The running form (lsspa_error_running_* / _advance / _quantiles_enqueue / _result): normals made on the device by
+    Philox4x32-10 + Box-Muller against their NumPy restatement (tests/philox_ref.py, itself pinned by the generator's
+    known-answer vectors), D = Xi L and s = Xi 1 accumulated chunk by chunk, and a check's quantiles against the same
+    arithmetic in NumPy.  Chunk sizes that are not multiples of the 16-row GEMM chunk, p across the 128-column tile
+    edge, sample ids with a stride (a rank's share of a dealt chunk)."""
+    import philox_ref as P
+    seed = 0x9E3779B97F4A7C15
+    xi = engine.error_xi(seed, 5, stride, 37)
+    want = P.normals(seed, 5 + stride * np.arange(37))
+    np.testing.assert_allclose(xi, want, rtol=0, atol=1e-12)
+    big = engine.error_xi(3, 2 ** 40, 1, 64)          # ids beyond 32 bits use the counter's second word
+    np.testing.assert_allclose(big, P.normals(3, 2 ** 40 + np.arange(64)), rtol=0, atol=1e-12)
+    Xa, Xe, ya, ye = problem(8, p, 3 * p + 20, 2 * p + 11)
+    engine.load_data(Xa, Xe, ya, ye, 0.0)
+    engine.reset_stats()
+    engine.error_running_enable(seed)
+    rng = np.random.default_rng(4)
+    lifts, ids, nxt = [], [], 3
+    for k, b in enumerate(chunks):
+        perms = np.array([rng.permutation(p) for _ in range(b)])
+        lifts.append(engine.run_batch(perms, True, want_lifts=True, accumulate=2))
+        engine.error_advance(nxt, stride)
+        ids.append(nxt + stride * np.arange(b))
+        nxt += stride * b + 1
+        L, I = np.concatenate(lifts), np.concatenate(ids)
+        n = len(L)
+        engine.error_running_draws(n)
+        engine.error_quantiles_enqueue(k)
+        feat, tot, mean, n_dev = engine.error_result(k, wait=True)
+        assert n_dev == n
+        np.testing.assert_allclose(mean, L.mean(0), rtol=0, atol=1e-14)
+        draws = P.normals(seed, I) @ (L - L.mean(0)) / np.sqrt(n * (n - 1.0))
+        np.testing.assert_allclose(feat, np.quantile(np.abs(draws), 0.95, axis=0), rtol=1e-9, atol=1e-16)
+        np.testing.assert_allclose(tot, np.quantile(np.linalg.norm(draws, axis=1), 0.95), rtol=1e-10)
+    # every earlier slot still holds its own check (nothing waits, nothing is overwritten)
+    f0, t0, m0, n0 = engine.error_result(0, wait=False)
+    assert n0 == chunks[0]
+    np.testing.assert_allclose(m0, lifts[0].mean(0), rtol=0, atol=1e-14)
+    # state out and back in (checkpoint / resume): the next check is unchanged
+    D, s_vec = engine.error_state()
+    Xi = P.normals(seed, I)
+    np.testing.assert_allclose(D, Xi @ L, rtol=0, atol=1e-11 * max(1.0, np.abs(L).max()) * np.sqrt(n))
+    np.testing.assert_allclose(s_vec, Xi.sum(1), rtol=0, atol=1e-11)
+    engine.reset_stats()
+    D0, s0 = engine.error_state()
+    assert not D0.any() and not s0.any()
+    engine.set_error_state(D, s_vec)
+    D1, s1 = engine.error_state()
+    np.testing.assert_array_equal(D1, D)
+    np.testing.assert_array_equal(s1, s_vec)
+    with pytest.raises(Exception, match="advance"):
+        engine.run_batch(perms, True, want_lifts=False, accumulate=2)
+        engine.error_running_draws(n + len(perms))
+    engine.reset_stats()
+    engine.history_enable(0)
+    with pytest.raises(Exception, match="not enabled"):
+        engine.error_advance(0, 1)
+
+
 def test_stats_checkpoint_resume(engine):
     """lsspa_stats_set + lsspa_history_append: stop after two batches, restore into a fresh problem
     load, continue -- same statistics as the uninterrupted run."""
@@ -512,6 +574,9 @@ def test_driver_lookahead_on_the_device():
     four = ls_spa(*d, lookahead=4, **kw)
     np.testing.assert_array_equal(four.attribution, one.attribution)
     np.testing.assert_allclose(four.error_history, one.error_history, rtol=1e-12)
+    waited = ls_spa(*d, _defer=0, **kw)          # every check waited for: the same numbers
+    np.testing.assert_array_equal(waited.attribution, one.attribution)
+    np.testing.assert_array_equal(waited.error_history, one.error_history)
     assert len(four.error_history) == 10      # 8 .. 64, 71, 72
     tol = float(one.error_history[2]) * 1.0000001
     if one.error_history[0] > tol and one.error_history[1] > tol:

@@ -63,7 +63,7 @@ def test_driver_through_the_native_communicator(golden):
     np.testing.assert_allclose(via.attribution, g["drv_anti1_attribution"], rtol=0, atol=1e-10)   # the reference's
     # row-sharded reduction + device-side estimator: every collective of the product path in one run
     sharded = ls_spa(*d, row_sharded=True, error_estimator="device", comm=NativeComm(0, 1, force_collective=True), **kw)
-    low = ls_spa(*d, error_estimator="lowrank", **kw)
+    low = ls_spa(*d, error_estimator="device", **kw)
     np.testing.assert_allclose(sharded.attribution, plain.attribution, rtol=0, atol=1e-13)
     np.testing.assert_allclose(sharded.theta, plain.theta, rtol=1e-12)
     np.testing.assert_allclose(sharded.error_history, low.error_history, rtol=1e-9)

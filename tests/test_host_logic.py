@@ -108,20 +108,85 @@ def test_lowrank_estimator_matches_distribution():
 
 
 # ---------------------------------------------------------------- samplers
-def test_device_estimator_path_equals_lowrank(golden):
-    """'device' consumes the generator exactly like 'lowrank' and returns the same numbers (test double)."""
+def test_philox_known_answers():
+    """The counter-based generator behind the device estimator's normals, against its published vectors."""
+    import philox_ref as P
+    for ctr, key, want in P.KAT:
+        got = P.philox4x32_10(np.array([ctr], dtype=np.uint64), key)[0]
+        assert [int(v) for v in got] == list(want)
+    x = P.normals(7, np.arange(1000, 1400))
+    from scipy import stats
+    assert stats.kstest(x.ravel(), "norm").pvalue > 1e-3
+    assert abs(x.mean()) < 0.01 and abs(x.std() - 1.0) < 0.01
+    # a sample's column depends on (seed, sample id) only
+    np.testing.assert_array_equal(P.normals(7, [1003])[:, 0], x[:, 3])
+    assert not np.array_equal(P.normals(8, [1003])[:, 0], x[:, 3])
+
+
+def test_device_estimator_is_the_running_form(golden):
+    """'device' (test double): at every check the draws are Xi (L - 1 mean^T) / sqrt(n (n - 1)) with Xi the
+    counter-based normals of the samples so far -- accumulated chunk by chunk as D = Xi L, s = Xi 1 -- and the
+    reference's quantiles of them (ls_spa/ls_spa.py:337-340); the host generator is not touched; against the host
+    low-rank form (other normals, same distribution) the pin is statistical."""
+    import philox_ref as P
     g = golden("p12")
     d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
     kw = dict(perms=g["perms64"][:40], batch_size=16, tolerance=0.0)
-    low = pkg.ls_spa(*d, error_estimator="lowrank", _engine=OracleEngine(), **kw)
+    low = pkg.ls_spa(*d, error_estimator="lowrank", return_attribution_history=True, _engine=OracleEngine(), **kw)
     eng = OracleEngine()
     dev = pkg.ls_spa(*d, error_estimator="device", _engine=eng, **kw)
-    np.testing.assert_allclose(dev.error_history, low.error_history, rtol=1e-12)
-    np.testing.assert_allclose(dev.attribution_errors, low.attribution_errors, rtol=1e-12)
     np.testing.assert_allclose(dev.attribution, low.attribution, rtol=0, atol=1e-15)
-    assert eng.history_count() == 40
+    np.testing.assert_allclose(dev.error_history, low.error_history, rtol=0.15)
+    assert eng.enqueued == 3
+    # the lift vectors, from the running means of the history
+    hist = low.attribution_history
+    lifts = np.diff(np.vstack([np.zeros(12), hist * np.arange(1, 41)[:, None]]), axis=0)
+    seed = int(np.random.SeedSequence(42).generate_state(1, np.uint64)[0])
+    want = []
+    for n in (16, 32, 40):
+        L = lifts[:n]
+        x = P.normals(seed, np.arange(n)) @ (L - L.mean(0)) / np.sqrt(n * (n - 1.0))
+        want.append(np.quantile(np.linalg.norm(x, axis=1), 0.95))
+        feat = np.quantile(np.abs(x), 0.95, axis=0)
+    np.testing.assert_allclose(dev.error_history, want, rtol=1e-9)
+    np.testing.assert_allclose(dev.attribution_errors, feat, rtol=1e-9)
     with pytest.raises(ValueError, match="error_estimator"):
         pkg.ls_spa(*d, error_estimator="gpu", _engine=OracleEngine(), **kw)
+
+
+def test_deferred_checks_give_the_stopping_checks_results(golden):
+    """QMC methods, device estimator: the stop rule of check k is evaluated when check k + 1 has been enqueued (the
+    first check of a run is waited for).  A run that stops returns the numbers of the stopping check -- its own copy
+    of the running mean -- exactly as the run that waits for every check; what was launched beyond is dropped."""
+    g = golden("p12")
+    d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+    base = dict(method="argsort", seed=5, max_samples=96, batch_size=16)
+    full = ls_spa(*d, tolerance=0.0, _engine=OracleEngine(), **base)
+    wait = ls_spa(*d, tolerance=0.0, _engine=OracleEngine(), _defer=0, **base)
+    np.testing.assert_array_equal(full.error_history, wait.error_history)
+    np.testing.assert_array_equal(full.attribution, wait.attribution)
+    assert len(full.error_history) == 7
+    for k in (0, 1, 3, 5, 6):       # stop at the first check, in the middle, at the check before the last, at the last
+        tol = float(full.error_history[k]) * 1.0000001
+        assert all(e > tol for e in full.error_history[:k])
+        e0, e1 = OracleEngine(), OracleEngine()
+        a = ls_spa(*d, tolerance=tol, _engine=e0, _defer=0, **base)
+        b = ls_spa(*d, tolerance=tol, _engine=e1, **base)
+        np.testing.assert_array_equal(b.error_history, a.error_history)
+        np.testing.assert_array_equal(b.attribution, a.attribution)
+        np.testing.assert_array_equal(b.attribution_errors, a.attribution_errors)
+        assert b.overall_error == a.overall_error and len(b.error_history) == k + 1
+        # waited for: nothing beyond the stop; deferred: one chunk more was evaluated (none after the first check,
+        # which is waited for, and none when the run's samples were used up anyway)
+        extra = 0 if k in (0, 6) else (15 if k == 4 else 16)
+        assert sum(e0.calls) == min(16 * (k + 1), 96 if k == 6 else 95 if k == 5 else 10 ** 9)
+        assert sum(e1.calls) == sum(e0.calls) + (1 if k == 5 else extra)
+    # histories are cut at the stop as well
+    tol = float(full.error_history[2]) * 1.0000001
+    a = ls_spa(*d, tolerance=tol, return_attribution_history=True, _engine=OracleEngine(), _defer=0, **base)
+    b = ls_spa(*d, tolerance=tol, return_attribution_history=True, _engine=OracleEngine(), **base)
+    assert b.attribution_history.shape == a.attribution_history.shape == (48, 12)
+    np.testing.assert_array_equal(b.attribution_history, a.attribution_history)
 
 
 def test_default_estimator_fits_the_method(golden):
@@ -135,14 +200,14 @@ def test_default_estimator_fits_the_method(golden):
     for method in ("argsort", "permutohedron"):
         eng = OracleEngine()
         auto = pkg.ls_spa(*d, method=method, _engine=eng, **base)
-        assert eng.history_count() == 48                       # the device estimator keeps the lift vectors in the engine
+        assert eng.enqueued == 4                               # checks at 16, 32, 47 and the trailing one, on the engine
         dev = pkg.ls_spa(*d, method=method, error_estimator="device", _engine=OracleEngine(), **base)
         np.testing.assert_array_equal(auto.error_history, dev.error_history)
         np.testing.assert_array_equal(auto.attribution_errors, dev.attribution_errors)
     for kw in (dict(base), dict(base, method="random"), dict(perms=g["perms64"][:48], batch_size=16, tolerance=0.0)):
         eng = OracleEngine()
         auto = pkg.ls_spa(*d, _engine=eng, **kw)
-        assert eng.history_count() == 0
+        assert getattr(eng, "enqueued", 0) == 0
         ref = pkg.ls_spa(*d, error_estimator="reference", _engine=OracleEngine(), **kw)
         np.testing.assert_array_equal(auto.error_history, ref.error_history)
         np.testing.assert_array_equal(auto.attribution, ref.attribution)
@@ -442,22 +507,33 @@ def test_lookahead_keeps_the_reference_order(golden):
     assert first.error_history[0] > tol
     e1, e3 = OracleEngine(), OracleEngine()
     kw = dict(method="argsort", seed=5, max_samples=96, batch_size=16, tolerance=tol)
-    one = ls_spa(*d, _engine=e1, **kw)
-    three = ls_spa(*d, _engine=e3, lookahead=3, **kw)
+    one = ls_spa(*d, _engine=e1, _defer=0, **kw)
+    three = ls_spa(*d, _engine=e3, lookahead=3, _defer=0, **kw)
     assert len(one.error_history) == len(three.error_history) == 2
     np.testing.assert_array_equal(three.attribution, one.attribution)
     assert e3.discarded == 1 and e3.launched == 1 and sum(e3.calls) == sum(e1.calls) == 32
     # the group ends exactly at a check.  Host-side estimator: the next group is launched before the rule is
-    # evaluated, then dropped.  Device-side estimator (the default of the QMC methods since round 4; its kernels
-    # would queue behind a new group): the next group is launched after the decision -- nothing wasted.
+    # evaluated, then dropped.  Device-side estimator with every check waited for (_defer=0): the next group is
+    # launched after the decision -- nothing wasted.
+    ref_hist = ls_spa(*d, method="argsort", seed=5, max_samples=96, batch_size=16, tolerance=0.0,
+                      error_estimator="reference", _engine=OracleEngine()).error_history
+    assert ref_hist[0] > ref_hist[1]
     e2 = OracleEngine()
-    two = ls_spa(*d, _engine=e2, lookahead=2, error_estimator="reference", **kw)
+    two = ls_spa(*d, _engine=e2, lookahead=2, error_estimator="reference",
+                 **dict(kw, tolerance=float(ref_hist[1]) * 1.0000001))
     np.testing.assert_array_equal(two.attribution, one.attribution)
     assert e2.launched == 2 and e2.discarded == 1 and sum(e2.calls) == 32
     e2 = OracleEngine()
-    two = ls_spa(*d, _engine=e2, lookahead=2, **kw)
+    two = ls_spa(*d, _engine=e2, lookahead=2, _defer=0, **kw)
     np.testing.assert_array_equal(two.attribution, one.attribution)
     assert e2.launched == 1 and e2.discarded == 0 and sum(e2.calls) == 32
+    # the default of the QMC methods (round 5): the decision of check k is taken when check k + 1 has been enqueued --
+    # same results (the stopping check's own copy of the running mean), one chunk more evaluated, the rest dropped
+    e2 = OracleEngine()
+    two = ls_spa(*d, _engine=e2, lookahead=2, **kw)
+    np.testing.assert_array_equal(two.attribution, one.attribution)
+    np.testing.assert_array_equal(two.error_history, one.error_history)
+    assert e2.launched == 2 and e2.discarded == 1 and sum(e2.calls) == 48
     # sources somebody else reads are not drawn ahead
     for kw in (dict(perms=iter(g["perms64"]), batch_size=16, tolerance=0.0),
                dict(max_samples=48, batch_size=16, tolerance=0.0, seed=3)):
