@@ -1002,6 +1002,25 @@ def main():
             if got is not None:
                 legs["full_run"] = got
 
+                def estimator_gpu_ms():
+                    # what a check costs the GPU: eight checks of the same loop on one lane with a HIP-event pair around
+                    # every launch; the estimator's launches (fold the chunk into D = Xi L / s = Xi 1; the two quantile
+                    # kernels) are class "error".  Nothing in them depends on how many samples came before.
+                    eng.set_lanes(1)
+                    eng.profile(True)
+                    eng.profile_reset()
+                    run_estimator(eng, p, max_samples=B * 8, batch_size=B, tolerance=0.0, seed=42, perms=None,
+                                  antithetical=True, return_attribution_history=False, method="argsort",
+                                  error_estimator="device", comm=comm, lookahead=1, defer=0)
+                    barrier()
+                    ms, cnt = eng.profile_read()["error"]
+                    eng.profile(False)
+                    return {"ms_per_check": ms / 8.0, "launches_per_check": cnt / 8.0}
+                g2 = guarded("full_run_estimator_gpu", estimator_gpu_ms)
+                if g2 is not None:
+                    legs["full_run"]["estimator_gpu"] = g2
+                legs.pop("full_run_estimator_gpu", None)
+
         # SURVEY 8(d)'s secondary workload: the reference's own correlated generator at the same shape.  On the iid
         # Gaussian data the stop rule fires at the first check (error ~3e-5 against 1e-2: one batch); here the
         # attribution is spread over correlated features and the loop has to run

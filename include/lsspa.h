@@ -207,6 +207,9 @@ int lsspa_error_running_enable(lsspa_ctx* ctx, uint64_t seed);
 int lsspa_error_advance(lsspa_ctx* ctx, int64_t first_id, int64_t stride);
 int lsspa_error_running_draws(lsspa_ctx* ctx, int64_t n_total);
 int lsspa_error_quantiles_enqueue(lsspa_ctx* ctx, int32_t slot);
+/* one rank: lsspa_error_running_draws + lsspa_error_quantiles_enqueue in one call and two launches -- the quantile
+ * kernels evaluate x = (D - s mean^T) / sqrt(n (n - 1)) as they read it, the draws buffer is not written */
+int lsspa_error_check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot);
 int lsspa_error_result(lsspa_ctx* ctx, int32_t slot, int32_t wait, int32_t* ready, double* feature_errors,
                        double* overall_error, double* mean, int64_t* n);
 int lsspa_error_state_get(lsspa_ctx* ctx, double* D, double* s);

@@ -32,14 +32,55 @@ namespace lsspa {
 
 constexpr int ND = 1024;  // draws, as in the reference
 
+// ---- running form: counter-based normals ------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11): ten rounds of two 32 x 32 -> 64 multiplies and xors, the key bumped by the
+// Weyl constants between rounds.  Pinned by the generator's published known-answer vectors (tests/philox_ref.py).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t m0 = (uint64_t)0xD2511F53u * c0, m1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(m1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)m1;
+    const uint32_t n2 = (uint32_t)(m0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)m0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// The two normals Philox call j of sample `id` yields: u1, u2 = the 53 high bits of (w0, w1), (w2, w3) plus a half, over
+// 2^53 -- both in (0, 1) --, then Box-Muller.  They are draws 64 b + r and 64 b + r + 32 of the sample, j = 32 b + r
+// (r < 32): the two rows a thread of the GEMM below stages of a 64-draw tile, so that the tile can be made in
+// registers without a wasted output.
+__device__ __forceinline__ void xi_pair(uint64_t seed, uint64_t id, uint32_t j, double& z0, double& z1) {
+  uint32_t w[4];
+  philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), j, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  const double u1 = ((double)(((uint64_t)(w[0] >> 5) << 26) | (uint64_t)(w[1] >> 6)) + 0.5) * 0x1p-53;
+  const double u2 = ((double)(((uint64_t)(w[2] >> 5) << 26) | (uint64_t)(w[3] >> 6)) + 0.5) * 0x1p-53;
+  const double rad = sqrt(-2.0 * log(u1));
+  double sn, cs;
+  sincospi(2.0 * u2, &sn, &cs);
+  z0 = rad * cs;
+  z1 = rad * sn;
+}
+
 // ACC = false: draws = (Xi H - rowsum(Xi) mean^T) * scale.   ACC = true (running form): draws += Xi H and
 // rowsum_acc += rowsum(Xi) (by the workgroups of feature tile 0), nothing centred or scaled.
-template <bool ACC>
+// GEN (with ACC): Xi is not read but MADE, tile by tile, in the registers that would stage it: thread (row, c) of a
+// 64 x 16 tile holds draws row, row + 32 of samples 2 c, 2 c + 1 of the chunk = two Philox calls (xi_pair).
+struct XiGen {
+  uint64_t seed;
+  int64_t first_id, stride;
+  int count;
+};
+
+template <bool ACC, bool GEN>
 __global__ __launch_bounds__(256, 2) void draws_kernel(const double* __restrict__ Xi, int ldxi,
                                                        const double* __restrict__ H, int ldh, int n_pad,
                                                        const double* __restrict__ mean, double scale, int p,
                                                        double* __restrict__ draws, int ldd,
-                                                       double* __restrict__ rowsum_acc) {
+                                                       double* __restrict__ rowsum_acc, XiGen gen) {
   __shared__ __attribute__((aligned(16))) double s_rk[64 * RK_LD];
   __shared__ __attribute__((aligned(16))) double s_kc[16 * KC_LD];
   __shared__ double s_rs[64];
@@ -60,7 +101,21 @@ __global__ __launch_bounds__(256, 2) void draws_kernel(const double* __restrict_
   const int nch = n_pad / KCH;
   RKRegs<double, 64> ra = {};
   KCRegs<double> rb = {};
-  rk_load<double, 64>(ra, srcA, ldxi, tid, 64);
+  // the staging layout of rk_load / rk_store (tiles.h): vector c = tid % 8 of rows tid / 8 and tid / 8 + 32
+  auto make_a = [&](int chunk) {
+    const int cc = tid & 7, row = tid >> 3;
+    const uint32_t j = (uint32_t)(32 * blockIdx.x + row);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = chunk * KCH + 2 * cc + e;
+      double z0 = 0.0, z1 = 0.0;
+      if (k < gen.count) xi_pair(gen.seed, (uint64_t)(gen.first_id + (int64_t)k * gen.stride), j, z0, z1);
+      ra.v[0][e] = z0;
+      ra.v[1][e] = z1;
+    }
+  };
+  if (GEN) make_a(0);
+  else rk_load<double, 64>(ra, srcA, ldxi, tid, 64);
   kc_load<double>(rb, srcB, ldh, tid);
   for (int c = 0; c < nch; ++c) {
     __syncthreads();
@@ -68,7 +123,8 @@ __global__ __launch_bounds__(256, 2) void draws_kernel(const double* __restrict_
     kc_store<double>(rb, s_kc, tid);
     __syncthreads();
     if (c + 1 < nch) {
-      rk_load<double, 64>(ra, srcA + (c + 1) * KCH, ldxi, tid, 64);
+      if (GEN) make_a(c + 1);
+      else rk_load<double, 64>(ra, srcA + (c + 1) * KCH, ldxi, tid, 64);
       kc_load<double>(rb, srcB + (int64_t)(c + 1) * KCH * ldh, ldh, tid);
     }
 #pragma unroll
@@ -116,45 +172,18 @@ __global__ __launch_bounds__(256, 2) void draws_kernel(const double* __restrict_
   if (ACC && blockIdx.y == 0 && tid < 64) rowsum_acc[d0 + tid] += s_rs[tid];
 }
 
-// ---- running form: counter-based normals ------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al., SC'11): ten rounds of two 32 x 32 -> 64 multiplies and xors, the key bumped by the
-// Weyl constants between rounds.  Pinned by the generator's published known-answer vectors (tests/philox_ref.py).
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1, uint32_t out[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t m0 = (uint64_t)0xD2511F53u * c0, m1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(m1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)m1;
-    const uint32_t n2 = (uint32_t)(m0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)m0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-// Xi[2 j][k], Xi[2 j + 1][k] for sample id = first_id + k * stride: u1, u2 = the 53 high bits of (w0, w1), (w2, w3)
-// plus a half, over 2^53 -- both in (0, 1) --, then Box-Muller.  Columns k >= count are zero.
+// Xi [1024][n_pad] for sample ids first_id + k * stride, k < count; columns k >= count are zero (test hook: the
+// product path makes the same numbers inside the GEMM and never stores them)
 __global__ __launch_bounds__(256) void xi_fill_kernel(uint64_t seed, int64_t first_id, int64_t stride, int count,
                                                       int n_pad, double* __restrict__ Xi) {
   const int k = blockIdx.x * 256 + threadIdx.x;   // column (sample)
-  const int j = blockIdx.y;                       // draw pair
+  const int j = blockIdx.y;                       // Philox call of the sample
   if (k >= n_pad) return;
   double z0 = 0.0, z1 = 0.0;
-  if (k < count) {
-    const uint64_t id = (uint64_t)(first_id + (int64_t)k * stride);
-    uint32_t w[4];
-    philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)j, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
-    const double u1 = ((double)(((uint64_t)(w[0] >> 5) << 26) | (uint64_t)(w[1] >> 6)) + 0.5) * 0x1p-53;
-    const double u2 = ((double)(((uint64_t)(w[2] >> 5) << 26) | (uint64_t)(w[3] >> 6)) + 0.5) * 0x1p-53;
-    const double rad = sqrt(-2.0 * log(u1));
-    double sn, cs;
-    sincospi(2.0 * u2, &sn, &cs);
-    z0 = rad * cs;
-    z1 = rad * sn;
-  }
-  Xi[(int64_t)(2 * j) * n_pad + k] = z0;
-  Xi[(int64_t)(2 * j + 1) * n_pad + k] = z1;
+  if (k < count) xi_pair(seed, (uint64_t)(first_id + (int64_t)k * stride), (uint32_t)j, z0, z1);
+  const int d = 64 * (j >> 5) + (j & 31);
+  Xi[(int64_t)d * n_pad + k] = z0;
+  Xi[(int64_t)(d + 32) * n_pad + k] = z1;
 }
 
 // x[d][a] = (D[d][a] - s[d] mean[a]) * scale; padding columns zero
@@ -167,13 +196,27 @@ __global__ __launch_bounds__(256) void running_draws_kernel(const double* __rest
   draws[(int64_t)d * ld + a] = (a < p) ? (D[(int64_t)d * ld + a] - s[d] * mean[a]) * scale : 0.0;
 }
 
-// norms[d] = ||draws[d][0..p)||_2, one wave per draw
-__global__ __launch_bounds__(256) void row_norms_kernel(const double* __restrict__ draws, int ldd, int p,
-                                                        double* __restrict__ norms) {
+// Where the quantile kernels take the draws from: the draws buffer (after lsspa_error_draws / _running_draws and, with
+// several ranks, the all-reduce), or -- one rank, running form -- x = (D - s mean^T) * scale evaluated as it is read,
+// so that a check is two launches and the 8 MB of x are never written.
+struct DrawSrc {
+  const double* draws;     // [1024][ld] or null
+  const double* D;         // [1024][ld]
+  const double* s;         // [1024]
+  const double* mean;      // [p]
+  double scale;
+  int ld;
+  __device__ __forceinline__ double at(int d, int a) const {
+    return draws ? draws[(int64_t)d * ld + a] : (D[(int64_t)d * ld + a] - s[d] * mean[a]) * scale;
+  }
+};
+
+// norms[d] = ||x[d][0..p)||_2, one wave per draw
+__global__ __launch_bounds__(256) void row_norms_kernel(DrawSrc src, int p, double* __restrict__ norms) {
   const int lane = threadIdx.x & 63, d = blockIdx.x * 4 + (threadIdx.x >> 6);
   double v = 0.0;
   for (int a = lane; a < p; a += 64) {
-    const double x = draws[(int64_t)d * ldd + a];
+    const double x = src.at(d, a);
     v += x * x;
   }
 #pragma unroll
@@ -181,13 +224,15 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const double* __restrict
   if (lane == 0) norms[d] = sqrt(v);
 }
 
-// numpy.quantile(v, q) with the default 'linear' method on ND values
-__global__ __launch_bounds__(512) void quantile_kernel(const double* __restrict__ draws, int ldd,
-                                                       const double* __restrict__ norms, int p, double q,
-                                                       double* __restrict__ out /*[p + 1]*/) {
+// numpy.quantile(v, q) with the default 'linear' method on ND values.  out = [feature errors (p), overall error] and,
+// with pack_mean, behind them [running mean (p), n]: one copy then brings a whole check to the host.
+__global__ __launch_bounds__(512) void quantile_kernel(DrawSrc src, const double* __restrict__ norms, int p, double q,
+                                                       double* __restrict__ out /*[p + 1] or [2 p + 2]*/,
+                                                       const double* __restrict__ pack_mean,
+                                                       const double* __restrict__ pack_n) {
   __shared__ double s[ND];
   const int a = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < ND; i += 512) s[i] = (a < p) ? fabs(draws[(int64_t)i * ldd + a]) : norms[i];
+  for (int i = tid; i < ND; i += 512) s[i] = (a < p) ? fabs(src.at(i, a)) : norms[i];
   __syncthreads();
   for (int k = 2; k <= ND; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -212,6 +257,10 @@ __global__ __launch_bounds__(512) void quantile_kernel(const double* __restrict_
     const double va = s[lo], vb = s[hi];
     // numpy's _lerp: a + (b - a) t, evaluated from b's side when t >= 0.5
     out[a] = (t >= 0.5) ? vb - (vb - va) * (1.0 - t) : va + (vb - va) * t;
+    if (pack_mean) {
+      if (a < p) out[p + 1 + a] = pack_mean[a];
+      else out[2 * p + 1] = pack_n[0];
+    }
   }
 }
 
@@ -221,8 +270,8 @@ hipError_t launch_error_draws(const double* Xi, int ldxi, const double* H, int l
   if (p < 1 || n_pad < KCH || n_pad % KCH != 0 || ldxi < n_pad || (ldxi & 1) || ldh % 128 != 0 ||
       ldh < n_tiles * 128 || ldd < n_tiles * 128)
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL(draws_kernel<false>, dim3(ND / 64, n_tiles), dim3(256), 0, st, Xi, ldxi, H, ldh, n_pad, mean,
-                     scale, p, draws, ldd, (double*)nullptr);
+  hipLaunchKernelGGL((draws_kernel<false, false>), dim3(ND / 64, n_tiles), dim3(256), 0, st, Xi, ldxi, H, ldh, n_pad,
+                     mean, scale, p, draws, ldd, (double*)nullptr, XiGen{});
   return hipGetLastError();
 }
 
@@ -235,12 +284,14 @@ hipError_t launch_error_xi(uint64_t seed, int64_t first_id, int64_t stride, int 
   return hipGetLastError();
 }
 
-hipError_t launch_error_accumulate(const double* Xi, int n_pad, const double* L, int ldh, int p, double* D,
-                                   double* s, hipStream_t st) {
+hipError_t launch_error_accumulate(uint64_t seed, int64_t first_id, int64_t stride, int count, int n_pad,
+                                   const double* L, int ldh, int p, double* D, double* s, hipStream_t st) {
   const int n_tiles = (p + 127) / 128;
-  if (p < 1 || n_pad < KCH || n_pad % KCH != 0 || ldh % 128 != 0 || ldh < n_tiles * 128) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(draws_kernel<true>, dim3(ND / 64, n_tiles), dim3(256), 0, st, Xi, n_pad, L, ldh, n_pad,
-                     (const double*)nullptr, 1.0, p, D, ldh, s);
+  if (p < 1 || count < 1 || n_pad < KCH || n_pad % KCH != 0 || count > n_pad || stride < 1 || first_id < 0 ||
+      ldh % 128 != 0 || ldh < n_tiles * 128)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL((draws_kernel<true, true>), dim3(ND / 64, n_tiles), dim3(256), 0, st, (const double*)nullptr, 0,
+                     L, ldh, n_pad, (const double*)nullptr, 1.0, p, D, ldh, s, XiGen{seed, first_id, stride, count});
   return hipGetLastError();
 }
 
@@ -252,14 +303,26 @@ hipError_t launch_error_running_draws(const double* D, const double* s, const do
   return hipGetLastError();
 }
 
-hipError_t launch_error_quantiles(const double* draws, int ldd, int p, double* norms, double* out,
-                                  hipStream_t st) {
-  if (p < 1 || ldd < p) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(row_norms_kernel, dim3(ND / 4), dim3(256), 0, st, draws, ldd, p, norms);
+static hipError_t launch_quantiles(const DrawSrc& src, int p, double* norms, double* out, const double* pack_mean,
+                                   const double* pack_n, hipStream_t st) {
+  hipLaunchKernelGGL(row_norms_kernel, dim3(ND / 4), dim3(256), 0, st, src, p, norms);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(quantile_kernel, dim3(p + 1), dim3(512), 0, st, draws, ldd, norms, p, 0.95, out);
+  hipLaunchKernelGGL(quantile_kernel, dim3(p + 1), dim3(512), 0, st, src, (const double*)norms, p, 0.95, out, pack_mean,
+                     pack_n);
   return hipGetLastError();
+}
+
+hipError_t launch_error_quantiles(const double* draws, int ldd, int p, double* norms, double* out, hipStream_t st,
+                                  const double* pack_mean, const double* pack_n) {
+  if (p < 1 || ldd < p) return hipErrorInvalidValue;
+  return launch_quantiles(DrawSrc{draws, nullptr, nullptr, nullptr, 0.0, ldd}, p, norms, out, pack_mean, pack_n, st);
+}
+
+hipError_t launch_error_quantiles_running(const double* D, const double* s, const double* mean, double scale, int ld,
+                                          int p, double* norms, double* out, const double* pack_n, hipStream_t st) {
+  if (p < 1 || ld < p) return hipErrorInvalidValue;
+  return launch_quantiles(DrawSrc{nullptr, D, s, mean, scale, ld}, p, norms, out, mean, pack_n, st);
 }
 
 }  // namespace lsspa

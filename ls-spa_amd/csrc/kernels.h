@@ -186,16 +186,20 @@ hipError_t launch_gram_finalize(const double* C, int p, double scale, double reg
 constexpr int ERR_DRAWS = 1024;
 hipError_t launch_error_draws(const double* Xi, int ldxi, const double* H, int ldh, int n_pad,
                               const double* mean, double scale, int p, double* draws, int ldd, hipStream_t st);
+// pack_mean / pack_n (optional): out is [2 p + 2] and also receives the running mean and n behind the p + 1 quantiles.
 hipError_t launch_error_quantiles(const double* draws, int ldd, int p, double* norms, double* out,
-                                  hipStream_t st);
+                                  hipStream_t st, const double* pack_mean = nullptr, const double* pack_n = nullptr);
+// the same on x = (D - s mean^T) * scale evaluated as it is read (one rank: no draws buffer); always packed
+hipError_t launch_error_quantiles_running(const double* D, const double* s, const double* mean, double scale, int ld,
+                                          int p, double* norms, double* out, const double* pack_n, hipStream_t st);
 // Running form of the estimator (k_error.hip): Xi[d][k] = standard normal made by Philox4x32-10 from (seed, sample id
-// first_id + k stride, draw d), k < count, zero up to n_pad (a multiple of 16), Xi [1024][n_pad];
-// D[1024][ldh] += Xi L and s[1024] += Xi 1 for the chunk's lift vectors L [n_pad][ldh]; and the check's draws
-// x = (D - s mean^T) * scale.
+// first_id + k stride, draw d), k < count, zero up to n_pad (a multiple of 16).  launch_error_xi stores Xi [1024][n_pad]
+// (test hook); launch_error_accumulate makes the same numbers in registers and adds D[1024][ldh] += Xi L,
+// s[1024] += Xi 1 for the chunk's lift vectors L [n_pad][ldh]; launch_error_running_draws: x = (D - s mean^T) * scale.
 hipError_t launch_error_xi(uint64_t seed, int64_t first_id, int64_t stride, int count, int n_pad, double* Xi,
                            hipStream_t st);
-hipError_t launch_error_accumulate(const double* Xi, int n_pad, const double* L, int ldh, int p, double* D,
-                                   double* s, hipStream_t st);
+hipError_t launch_error_accumulate(uint64_t seed, int64_t first_id, int64_t stride, int count, int n_pad,
+                                   const double* L, int ldh, int p, double* D, double* s, hipStream_t st);
 hipError_t launch_error_running_draws(const double* D, const double* s, const double* mean, double scale, int p,
                                       int ld, double* draws, hipStream_t st);
 

@@ -1700,7 +1700,7 @@ int lsspa_history_enable(lsspa_ctx* ctx, int64_t capacity) try {
   // zero once: padding columns and the rows of a partial last chunk are read (times a zero of Xi)
   HIPCHK(hipMemsetAsync(ctx->hist.ptr, 0, ctx->hist.count * 8, ctx->stream));
   TRY(dev_alloc(ctx, ctx->draws, (size_t)ERR_DRAWS * ctx->ldh()));
-  TRY(dev_alloc(ctx, ctx->err_out, (size_t)ctx->p + 1 + ERR_DRAWS));
+  TRY(dev_alloc(ctx, ctx->err_out, 2 * (size_t)ctx->p + 2 + ERR_DRAWS));   // [quantiles, mean, n], row norms
   HIPCHK(hipMemsetAsync(ctx->draws.ptr, 0, ctx->draws.count * 8, ctx->stream));
   ctx->hist_cap = capacity;
   return LSSPA_OK;
@@ -1785,7 +1785,7 @@ int lsspa_error_quantiles(lsspa_ctx* ctx, double* feature_errors, double* overal
   const int p = ctx->p;
   {
     ProfScope ps(ctx, LSSPA_K_ERROR);
-    HIPCHK(launch_error_quantiles(ctx->draws.ptr, ctx->ldh(), p, ctx->err_out.ptr + p + 1, ctx->err_out.ptr,
+    HIPCHK(launch_error_quantiles(ctx->draws.ptr, ctx->ldh(), p, ctx->err_out.ptr + 2 * p + 2, ctx->err_out.ptr,
                                   ctx->stream));
   }
   std::vector<double> out((size_t)p + 1);
@@ -1840,12 +1840,10 @@ int lsspa_error_advance(lsspa_ctx* ctx, int64_t first_id, int64_t stride) try {
   if (cnt == 0) return LSSPA_OK;
   HIPCHK(hipSetDevice(ctx->device));
   const int64_t n_pad = ((cnt + KCH - 1) / KCH) * KCH;
-  TRY(dev_alloc(ctx, ctx->xi_d, (size_t)ERR_DRAWS * n_pad));
   ProfScope ps(ctx, LSSPA_K_ERROR);
-  HIPCHK(launch_error_xi(ctx->run_seed, first_id, stride, (int)cnt, (int)n_pad, ctx->xi_d.ptr, ctx->stream));
   // rows cnt .. n_pad of the staging hold older chunks' (finite) lift vectors: they meet the zero columns of Xi
-  HIPCHK(launch_error_accumulate(ctx->xi_d.ptr, (int)n_pad, ctx->hist.ptr, ctx->ldh(), ctx->p, ctx->Dacc.ptr,
-                                 ctx->sacc.ptr, ctx->stream));
+  HIPCHK(launch_error_accumulate(ctx->run_seed, first_id, stride, (int)cnt, (int)n_pad, ctx->hist.ptr, ctx->ldh(),
+                                 ctx->p, ctx->Dacc.ptr, ctx->sacc.ptr, ctx->stream));
   ctx->hist_n = 0;
   return LSSPA_OK;
 } catch (...) {
@@ -1869,6 +1867,16 @@ int lsspa_error_running_draws(lsspa_ctx* ctx, int64_t n_total) try {
   return abi_caught(ctx);
 }
 
+// the shared tail of the two enqueue forms: one copy of [quantiles, mean, n] into the pinned slot, then its event
+static int finish_check(lsspa_ctx* ctx, int slot) {
+  const size_t p = ctx->p;
+  double* dst = ctx->res_h + (size_t)slot * (2 * p + 2);
+  HIPCHK(hipMemcpyAsync(dst, ctx->err_out.ptr, (2 * p + 2) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->res_ev[slot], ctx->stream));
+  ctx->res_valid[slot] = true;
+  return LSSPA_OK;
+}
+
 int lsspa_error_quantiles_enqueue(lsspa_ctx* ctx, int32_t slot) try {
   if (!ctx || slot < 0 || slot >= lsspa_ctx::RES_SLOTS) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
@@ -1877,16 +1885,31 @@ int lsspa_error_quantiles_enqueue(lsspa_ctx* ctx, int32_t slot) try {
   const size_t p = ctx->p;
   {
     ProfScope ps(ctx, LSSPA_K_ERROR);
-    HIPCHK(launch_error_quantiles(ctx->draws.ptr, ctx->ldh(), (int)p, ctx->err_out.ptr + p + 1, ctx->err_out.ptr,
-                                  ctx->stream));
+    HIPCHK(launch_error_quantiles(ctx->draws.ptr, ctx->ldh(), (int)p, ctx->err_out.ptr + 2 * p + 2, ctx->err_out.ptr,
+                                  ctx->stream, ctx->mean.ptr, ctx->state_n.ptr));
   }
-  double* dst = ctx->res_h + (size_t)slot * (2 * p + 2);
-  HIPCHK(hipMemcpyAsync(dst, ctx->err_out.ptr, (p + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(dst + p + 1, ctx->mean.ptr, p * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(dst + 2 * p + 1, ctx->state_n.ptr, 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipEventRecord(ctx->res_ev[slot], ctx->stream));
-  ctx->res_valid[slot] = true;
-  return LSSPA_OK;
+  return finish_check(ctx, slot);
+} catch (...) {
+  return abi_caught(ctx);
+}
+
+int lsspa_error_check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot) try {
+  if (!ctx || n_total < 0 || slot < 0 || slot >= lsspa_ctx::RES_SLOTS) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  if (!ctx->run_on) return ctx->fail(LSSPA_ERR_STATE, "the running estimator is not enabled");
+  if (ctx->hist_n != 0) return ctx->fail(LSSPA_ERR_STATE, "collected samples not yet folded in: call lsspa_error_advance");
+  if (ctx->pend_dirty) return ctx->fail(LSSPA_ERR_STATE, "merge the pending batch first: the mean is stale");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t p = ctx->p;
+  const double nt = (double)n_total;
+  const double scale = 1.0 / sqrt(nt * (nt - 1.0));
+  {
+    ProfScope ps(ctx, LSSPA_K_ERROR);
+    HIPCHK(launch_error_quantiles_running(ctx->Dacc.ptr, ctx->sacc.ptr, ctx->mean.ptr, scale, ctx->ldh(), (int)p,
+                                          ctx->err_out.ptr + 2 * p + 2, ctx->err_out.ptr, ctx->state_n.ptr,
+                                          ctx->stream));
+  }
+  return finish_check(ctx, slot);
 } catch (...) {
   return abi_caught(ctx);
 }

@@ -351,6 +351,24 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
             state["err_D"], state["err_s"] = engine.error_state()
         _save_checkpoint(checkpoint, comm, state)
 
+    # lookahead > 1 (QMC samplers only: their stream is nobody else's): the orderings of several chunks are launched
+    # as ONE batch -- a chunk of batch_size / world samples may fill a fraction of the GPU -- and then accumulated,
+    # all-reduced and checked chunk by chunk in the reference's order (ls_spa/ls_spa.py:212-230).  When the stop
+    # rule fires, the chunks launched beyond it are dropped: nothing of them ever reaches the statistics.  With a
+    # host-side estimator the next group is launched AFTER the statistics of the group's last chunk have been read
+    # back and BEFORE the host's estimate and decision, so the GPU works while the host computes (a stop then
+    # wastes up to k chunks of GPU work, which only the final read-back waits for).  With the device-side estimator the
+    # checks are enqueued behind the chunks' statistics and read late (below): the next group is launched when the
+    # current one has been taken up, whatever its checks will say.
+    if lookahead == "auto":
+        # automatic: a chunk of fewer than 64 samples per rank leaves most of an MI355X idle (§6 of DESIGN.md) --
+        # launch as many chunks together as make up 64, eight at most.  Small problems (the one-workgroup-per-ordering
+        # kernels, p <= 126): a launch of 2048 orderings fills the chip four times over and costs the host one call --
+        # as many chunks as make up 1024 samples, eight at most.
+        per_rank = -(-int(batch_size) // comm.world)
+        want = 1024 if p <= 126 else 64
+        lookahead = max(1, min(8, want // max(per_rank, 1)))
+    group = max(1, int(lookahead)) if (hasattr(engine, "launch_batch") and source.independent and not chunk_cap) else 1
     # The device estimator's checks are ENQUEUED, not waited for: x = (D - s mean^T) / sqrt(n (n - 1)), the all-reduce of
     # the per-rank x, the quantile kernels and a copy of (errors, running mean, n) into a pinned slot run on the context's
     # stream behind the chunk's statistics.  `defer` checks may be outstanding: the stop rule of check k is evaluated
@@ -365,18 +383,22 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
     can_defer = on_device and checkpoint is None and source.independent and not chunk_cap
     if defer is None:
         per_rank = -(-min(int(batch_size), max_samples) // comm.world) * (2 if antithetical else 1)
-        # a chunk's kernels, at 40 TFLOP/s, under 50 ms
-        defer = 1 if (can_defer and per_rank * float(p) ** 3 / 4e13 < 0.05) else 0
+        # a chunk's kernels, at 40 TFLOP/s, under 50 ms; the chunks of a look-ahead group are checked without waiting
+        # in between (their kernels were one launch)
+        defer = max(1, group) if (can_defer and per_rank * float(p) ** 3 / 4e13 < 0.05) else 0
     defer = int(defer) if can_defer else 0
     if not 0 <= defer < engine.RESULT_SLOTS - 1 if on_device else False:
         raise ValueError("defer must be between 0 and the number of result slots - 2")
 
     def enqueue_check(n):
-        engine.error_running_draws(n)
-        comm.allreduce_draws(engine)
         slot = slot_turn[0]
         slot_turn[0] = (slot + 1) % engine.RESULT_SLOTS
-        engine.error_quantiles_enqueue(slot)
+        if single and hasattr(engine, "error_check_enqueue"):
+            engine.error_check_enqueue(n, slot)      # one rank: nothing to all-reduce, the draws are never written
+        else:
+            engine.error_running_draws(n)
+            comm.allreduce_draws(engine)
+            engine.error_quantiles_enqueue(slot)
         outstanding.append((n, slot))
 
     def estimate_now(n, cov_b=None):
@@ -396,21 +418,6 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
         err_hist.append(total_err)
         t_estimator += _time.perf_counter() - t_e0
 
-    # lookahead > 1 (QMC samplers only: their stream is nobody else's): the orderings of several chunks are launched
-    # as ONE batch -- a chunk of batch_size / world samples may fill a fraction of the GPU -- and then accumulated,
-    # all-reduced and checked chunk by chunk in the reference's order (ls_spa/ls_spa.py:212-230).  When the stop
-    # rule fires, the chunks launched beyond it are dropped: nothing of them ever reaches the statistics.  With a
-    # host-side estimator the next group is launched AFTER the statistics of the group's last chunk have been read
-    # back and BEFORE the host's estimate and decision, so the GPU works while the host computes (a stop then
-    # wastes up to k chunks of GPU work, which only the final read-back waits for); the engine has one stream, so
-    # with the device-side estimator, whose kernels would queue behind a new group, the next group is launched
-    # after the decision instead (nothing wasted, nothing overlapped).
-    if lookahead == "auto":
-        # automatic: a chunk of fewer than 64 samples per rank leaves most of an MI355X idle (§6 of DESIGN.md) --
-        # launch as many chunks together as make up 64, eight at most
-        per_rank = -(-int(batch_size) // comm.world)
-        lookahead = max(1, min(8, 64 // max(per_rank, 1)))
-    group = max(1, int(lookahead)) if (hasattr(engine, "launch_batch") and source.independent and not chunk_cap) else 1
     # Two lanes (engine.lanes == 2, set by ls_spa() on the general path for the QMC samplers): successive groups run on
     # two workspaces and two streams, the statistics on the context's own.  The next group is then launched as soon as
     # the current one's last chunk is taken up -- BEFORE its statistics are read back: the read-back waits for the
@@ -576,7 +583,7 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
 def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_size=2 ** 8,
            tolerance=1e-2, seed=42, perms=None, antithetical=True, return_attribution_history=False, *,
            method=None, num_batches=None, return_history=None, device=0, error_estimator=None,
-           precision="float64", row_sharded=False, checkpoint=None, comm=None, lookahead=1, lanes="auto",
+           precision="float64", row_sharded=False, checkpoint=None, comm=None, lookahead=None, lanes="auto",
            _engine=None, _comm=None, _timings=None, _defer=None):
     """Estimates the Shapley attribution of the out-of-sample R^2 of a least-squares fit.
 
@@ -606,8 +613,9 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
     lookahead:  QMC samplers ('argsort', 'permutohedron') only.  k > 1 launches the orderings of k chunks as one GPU
         batch (a chunk of batch_size / n_gpus samples may fill a fraction of the GPU), accumulates and checks them
         chunk by chunk in the reference's order and drops the chunks beyond a stop.  Same results; at most k
-        chunks of wasted GPU work at the end of a run (none with error_estimator='device').  'auto': 1 when a rank's chunk has 64 samples or more, else as
-        many chunks as make up 64 samples, eight at most.  Default 1 (every chunk its own launch).
+        chunks of wasted GPU work at the end of a run.  'auto': 1 when a rank's chunk has 64 samples or more (1024 for
+        p <= 126, the one-workgroup-per-ordering kernels), else as many chunks as make up that, eight at most.  Default:
+        'auto' for the QMC methods with the device estimator (whose checks the loop does not wait for), else 1.
     lanes:  1, 2 or 'auto'.  2: successive chunk groups alternate between two workspaces on two HIP streams, the next
         group's kernels starting when the current group's are half way, its orderings drawn and uploaded before the
         current group's statistics are read back; a chunk of 64 samples or more per rank goes as two half-chunks (QMC
@@ -661,6 +669,11 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
             comm.bind(engine)      # RCCL communicator on this engine's GPU and stream (collective)
         if precision != "float64" or getattr(engine, "precision", "float64") != "float64":
             engine.set_precision(precision)
+        if lookahead is None:
+            # the device estimator's checks never make the loop wait: launching the chunks of a thin batch together costs
+            # nothing but the samples already in flight at a stop
+            lookahead = "auto" if (error_estimator == "device" and perms is None
+                                   and method in ("argsort", "permutohedron")) else 1
         if lookahead != "auto" and int(lookahead) < 1:
             raise ValueError("lookahead must be >= 1 or 'auto'")
         if lanes == "auto":

@@ -339,6 +339,10 @@ class HipEngine:
     def error_quantiles_enqueue(self, slot: int):
         self._check(self._lib.lsspa_error_quantiles_enqueue(self._h, int(slot)))
 
+    def error_check_enqueue(self, n_total: int, slot: int):
+        """One rank: draws and quantiles of a check in one call (the draws are evaluated as they are read)."""
+        self._check(self._lib.lsspa_error_check_enqueue(self._h, int(n_total), int(slot)))
+
     def error_result(self, slot: int, wait: bool = True):
         """(feature_errors, overall_error, mean, n) of a slot, or None if wait is False and it is not there yet."""
         feat, mean = np.empty(self.p), np.empty(self.p)

@@ -71,6 +71,7 @@ SIGNATURES = {
     "lsspa_error_advance": (C.c_int, [_vp, _i64, _i64]),
     "lsspa_error_running_draws": (C.c_int, [_vp, _i64]),
     "lsspa_error_quantiles_enqueue": (C.c_int, [_vp, _i32]),
+    "lsspa_error_check_enqueue": (C.c_int, [_vp, _i64, _i32]),
     "lsspa_error_result": (C.c_int, [_vp, _i32, _i32, _pi32, _pd, _pd, _pd, _pi64]),
     "lsspa_error_state_get": (C.c_int, [_vp, _pd, _pd]),
     "lsspa_error_state_set": (C.c_int, [_vp, _pd, _pd]),

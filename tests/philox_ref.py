@@ -2,7 +2,8 @@
 
 TESTS ONLY.  Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11) with
 key = the 64-bit seed and counter = (sample id low, sample id high, draw pair, 0); the four output words give two
-53-bit uniforms in (0, 1) and Box-Muller turns them into draws 2 j and 2 j + 1 of that sample.  The generator itself
+53-bit uniforms in (0, 1) and Box-Muller turns them into two draws of that sample (call j = 32 b + r, r < 32, makes
+draws 64 b + r and 64 b + r + 32: the two rows one thread of the device GEMM stages of a 64-draw tile).  The generator itself
 is pinned by its published known-answer vectors (test_host_logic.py), the device against this file
 (test_gpu_kernels.py).
 """
@@ -40,9 +41,11 @@ def normals(seed, sample_ids, draws=1024):
     u1 = (u1 + 0.5) * 2.0 ** -53
     u2 = (u2 + 0.5) * 2.0 ** -53
     rad = np.sqrt(-2.0 * np.log(u1))
+    # call j = 32 b + r (r < 32) gives draws 64 b + r and 64 b + r + 32
     out = np.empty((draws, len(ids)))
-    out[0::2] = rad * np.cos(2.0 * np.pi * u2)
-    out[1::2] = rad * np.sin(2.0 * np.pi * u2)
+    d = 64 * (np.arange(draws // 2) // 32) + np.arange(draws // 2) % 32
+    out[d] = rad * np.cos(2.0 * np.pi * u2)
+    out[d + 32] = rad * np.sin(2.0 * np.pi * u2)
     return out
 
 

@@ -58,7 +58,7 @@ def _worker(rank, world, port, out_dir):
             return super().run_batch(*a, **k)
     ck = os.path.join(out_dir, "state.npz")
     kw = dict(perms=None, method="argsort", seed=3, max_samples=80, batch_size=16, tolerance=0.0,
-              error_estimator="device")
+              error_estimator="device", lookahead=1)
     try:
         ls_spa(*d, checkpoint=ck, _engine=Dies(), comm=TorchComm(), **kw)
     except KeyboardInterrupt:
@@ -139,7 +139,7 @@ def test_two_ranks_match_single_process(tmp_path):
         assert str(s["lonely"]) == "refused"
     # two-rank resume == uninterrupted single-process run with the same sampler and estimator
     straight = ls_spa(*d, method="argsort", seed=3, max_samples=80, batch_size=16, tolerance=0.0,
-                      error_estimator="device", _engine=OracleEngine())
+                      error_estimator="device", lookahead=1, _engine=OracleEngine())
     for rk in (0, 1):
         s = np.load(tmp_path / f"s{rk}.npz")
         np.testing.assert_allclose(s["res_attr"], straight.attribution, rtol=0, atol=1e-13)

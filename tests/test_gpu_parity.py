@@ -301,7 +301,9 @@ def test_device_error_estimator_end_to_end():
     distribution (ls_spa/ls_spa.py:321-341) -- statistically against 'lowrank' (host)."""
     import philox_ref as P
     d = O.correlated_workload(np.random.default_rng(21), 100, 2000, 1500)
-    kw = dict(max_samples=512, batch_size=64, tolerance=0.0, seed=7)
+    # (a QMC method: with the shared generator of method=None the orderings after the first check depend on how many
+    # normals the estimator drew from it -- 'lowrank' draws, 'device' does not touch it)
+    kw = dict(method="argsort", max_samples=512, batch_size=64, tolerance=0.0, seed=7)
     low = ls_spa(*d, error_estimator="lowrank", return_attribution_history=True, **kw)
     dev = ls_spa(*d, error_estimator="device", **kw)
     assert len(dev.error_history) == len(low.error_history) == 9       # 64 .. 512, and 511
@@ -348,7 +350,8 @@ def test_checkpoint_resume_on_the_product_path(tmp_path, estimator):
             return super().run_batch(*a, **k)
 
     d = O.gaussian_workload(30, 400, 300, seed=4)
-    kw = dict(max_samples=160, batch_size=32, tolerance=0.0, seed=3, method="argsort", error_estimator=estimator)
+    kw = dict(max_samples=160, batch_size=32, tolerance=0.0, seed=3, method="argsort", error_estimator=estimator,
+              lookahead=1)
     full = ls_spa(*d, **kw)
     ck = str(tmp_path / "run.npz")
     eng = Dies(0)

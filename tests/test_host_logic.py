@@ -160,7 +160,7 @@ def test_deferred_checks_give_the_stopping_checks_results(golden):
     of the running mean -- exactly as the run that waits for every check; what was launched beyond is dropped."""
     g = golden("p12")
     d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
-    base = dict(method="argsort", seed=5, max_samples=96, batch_size=16)
+    base = dict(method="argsort", seed=5, max_samples=96, batch_size=16, lookahead=1)
     full = ls_spa(*d, tolerance=0.0, _engine=OracleEngine(), **base)
     wait = ls_spa(*d, tolerance=0.0, _engine=OracleEngine(), _defer=0, **base)
     np.testing.assert_array_equal(full.error_history, wait.error_history)
@@ -181,6 +181,15 @@ def test_deferred_checks_give_the_stopping_checks_results(golden):
         extra = 0 if k in (0, 6) else (15 if k == 4 else 16)
         assert sum(e0.calls) == min(16 * (k + 1), 96 if k == 6 else 95 if k == 5 else 10 ** 9)
         assert sum(e1.calls) == sum(e0.calls) + (1 if k == 5 else extra)
+    # the default look-ahead of this method and estimator ('auto': chunks of 16 samples at p = 12 go eight to a launch,
+    # and as many checks may be outstanding): the same numbers again
+    tol = float(full.error_history[3]) * 1.0000001
+    e8 = OracleEngine()
+    c = ls_spa(*d, tolerance=tol, _engine=e8, **dict(base, lookahead=None))
+    a = ls_spa(*d, tolerance=tol, _engine=OracleEngine(), _defer=0, **base)
+    np.testing.assert_array_equal(c.error_history, a.error_history)
+    np.testing.assert_array_equal(c.attribution, a.attribution)
+    assert e8.launched == 1 and len(c.error_history) == 4
     # histories are cut at the stop as well
     tol = float(full.error_history[2]) * 1.0000001
     a = ls_spa(*d, tolerance=tol, return_attribution_history=True, _engine=OracleEngine(), _defer=0, **base)
@@ -226,7 +235,7 @@ def test_checkpoint_resume_continues_the_same_run(golden, tmp_path, method, esti
 
     g = golden("p12")
     d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
-    kw = dict(batch_size=16, tolerance=0.0, seed=11, method=method, error_estimator=estimator)
+    kw = dict(batch_size=16, tolerance=0.0, seed=11, method=method, error_estimator=estimator, lookahead=1)
     full = pkg.ls_spa(*d, max_samples=112, _engine=OracleEngine(), **kw)
     ck = str(tmp_path / "state.npz")
     with pytest.raises(KeyboardInterrupt):
@@ -527,13 +536,14 @@ def test_lookahead_keeps_the_reference_order(golden):
     two = ls_spa(*d, _engine=e2, lookahead=2, _defer=0, **kw)
     np.testing.assert_array_equal(two.attribution, one.attribution)
     assert e2.launched == 1 and e2.discarded == 0 and sum(e2.calls) == 32
-    # the default of the QMC methods (round 5): the decision of check k is taken when check k + 1 has been enqueued --
-    # same results (the stopping check's own copy of the running mean), one chunk more evaluated, the rest dropped
+    # the default of the QMC methods (round 5): as many checks as a group has chunks may be outstanding -- the decision
+    # of check 2 is taken when check 4 has been enqueued: same results (the stopping check's own copy of the running
+    # mean), two chunks more evaluated
     e2 = OracleEngine()
     two = ls_spa(*d, _engine=e2, lookahead=2, **kw)
     np.testing.assert_array_equal(two.attribution, one.attribution)
     np.testing.assert_array_equal(two.error_history, one.error_history)
-    assert e2.launched == 2 and e2.discarded == 1 and sum(e2.calls) == 48
+    assert e2.launched == 2 and e2.discarded == 0 and sum(e2.calls) == 64
     # sources somebody else reads are not drawn ahead
     for kw in (dict(perms=iter(g["perms64"]), batch_size=16, tolerance=0.0),
                dict(max_samples=48, batch_size=16, tolerance=0.0, seed=3)):
@@ -542,12 +552,13 @@ def test_lookahead_keeps_the_reference_order(golden):
         assert e4.launched == 0 and e4.discarded == 0
     with pytest.raises(ValueError):
         ls_spa(*d, lookahead=0, _engine=OracleEngine())
-    # 'auto': chunks of 16 samples are launched four at a time (64 samples), chunks of 64 and more one at a time
+    # 'auto': small problems (p <= 126, one workgroup per ordering) go eight chunks to a launch up to 1024 samples,
+    # chunks of 1024 samples and more one at a time
     ea, eb = OracleEngine(), OracleEngine()
     auto = ls_spa(*d, method="argsort", seed=5, max_samples=96, batch_size=16, tolerance=0.0, lookahead="auto", _engine=ea)
     np.testing.assert_array_equal(auto.attribution, first.attribution)
-    assert ea.launched == 2                       # 7 chunks in groups of 4 and 3
-    ls_spa(*d, method="argsort", seed=5, max_samples=128, batch_size=64, tolerance=0.0, lookahead="auto", _engine=eb)
+    assert ea.launched == 1                       # 7 chunks in one group of (up to) 8
+    ls_spa(*d, method="argsort", seed=5, max_samples=2048, batch_size=1024, tolerance=0.0, lookahead="auto", _engine=eb)
     assert eb.launched == 0
 
 
@@ -704,7 +715,8 @@ def test_checkpoint_keeps_the_attribution_history(golden, tmp_path):
 
     g = golden("p12")
     d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
-    kw = dict(batch_size=16, tolerance=0.0, seed=4, method="argsort", max_samples=64, return_attribution_history=True)
+    kw = dict(batch_size=16, tolerance=0.0, seed=4, method="argsort", max_samples=64, return_attribution_history=True,
+              lookahead=1)
     full = ls_spa(*d, _engine=OracleEngine(), **kw)
     ck = str(tmp_path / "h.npz")
     with pytest.raises(KeyboardInterrupt):
