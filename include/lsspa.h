@@ -196,7 +196,7 @@ int lsspa_error_quantiles(lsspa_ctx* ctx, double* feature_errors, double* overal
  *   lsspa_error_running_draws   : x of this context's samples into the draws buffer (lsspa_error_buffer): with
  *                                 several ranks all-reduce it (lsspa_error_allreduce) -- x is linear in (D, s)
  *   lsspa_error_quantiles_enqueue / lsspa_error_result : the quantile kernels, then feature errors, overall error, the
- *                                 running mean and n copied into pinned slot `slot` (0 .. 15) behind an event -- nothing
+ *                                 running mean and n copied into pinned slot `slot` (0 .. 31) behind an event -- nothing
  *                                 waits.  lsspa_error_result reads a slot: wait != 0 blocks on its event, wait == 0
  *                                 polls (*ready = 0: not yet).  This is what lets the driver evaluate the stop rule of
  *                                 check k while the samples of check k + 1 are already running (they are dropped on a
@@ -212,6 +212,15 @@ int lsspa_error_quantiles_enqueue(lsspa_ctx* ctx, int32_t slot);
 int lsspa_error_check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot);
 int lsspa_error_result(lsspa_ctx* ctx, int32_t slot, int32_t wait, int32_t* ready, double* feature_errors,
                        double* overall_error, double* mean, int64_t* n);
+/* The per-chunk tail of a launched batch in one call, for hosts whose own call overhead would bound a small problem
+ * (a chunk of 256 orderings takes the GPU 37 us at p = 100).  For every chunk c = 0 .. n_chunks - 1, in order:
+ * lsspa_lift_collect(ticket, first[c], count[c], NULL, accumulate) -- skipped for count[c] == 0 --; with a communicator
+ * of several ranks lsspa_stats_allreduce + lsspa_stats_merge; lsspa_error_advance(first_id[c], stride); and, where
+ * n_after[c] > 0, the check of that global sample count into slot[c] (one rank: lsspa_error_check_enqueue; several:
+ * lsspa_error_running_draws + lsspa_error_allreduce + lsspa_error_quantiles_enqueue).  Nothing waits; the results are
+ * read with lsspa_error_result.  Order and arithmetic are those of the separate calls (ls_spa/ls_spa.py:203-230). */
+int lsspa_group_collect(lsspa_ctx* ctx, int32_t ticket, int32_t n_chunks, const int32_t* first, const int32_t* count,
+                        const int64_t* first_id, int64_t stride, const int64_t* n_after, const int32_t* slot);
 int lsspa_error_state_get(lsspa_ctx* ctx, double* D, double* s);
 int lsspa_error_state_set(lsspa_ctx* ctx, const double* D, const double* s);
 int lsspa_error_xi(lsspa_ctx* ctx, uint64_t seed, int64_t first_id, int64_t stride, int64_t count, double* xi);

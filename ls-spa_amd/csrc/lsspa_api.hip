@@ -122,7 +122,7 @@ struct lsspa_ctx {
   bool run_on = false;
   uint64_t run_seed = 0;
   DevBuf<double> Dacc, sacc;
-  static constexpr int RES_SLOTS = 16;
+  static constexpr int RES_SLOTS = 32;
   double* res_h = nullptr;            // pinned [RES_SLOTS][2 p + 2]: feature errors, overall error, mean, n
   size_t res_h_count = 0;
   hipEvent_t res_ev[RES_SLOTS] = {nullptr};
@@ -1977,6 +1977,44 @@ int lsspa_error_xi(lsspa_ctx* ctx, uint64_t seed, int64_t first_id, int64_t stri
   HIPCHK(hipMemcpy2DAsync(xi, (size_t)count * 8, ctx->xi_d.ptr, (size_t)n_pad * 8, (size_t)count * 8, ERR_DRAWS,
                           hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
+}
+
+// The per-chunk tail of a launched group in ONE call (the host loop of a small problem is bound by its own call
+// overhead otherwise: a chunk of 256 orderings takes the GPU 37 us at p = 100).  For every chunk c, in order:
+// collect (fold into the statistics), all-reduce + merge when the context's communicator spans several ranks, fold the
+// chunk into the running estimator, and -- where n_after[c] > 0 -- enqueue the check of that sample count into slot[c].
+int lsspa_group_collect(lsspa_ctx* ctx, int32_t ticket, int32_t n_chunks, const int32_t* first, const int32_t* count,
+                        const int64_t* first_id, int64_t stride, const int64_t* n_after, const int32_t* slot) try {
+  if (!ctx || ticket < 0 || ticket > 1 || n_chunks < 1 || !first || !count || !first_id || !n_after || !slot)
+    return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  if (!ctx->run_on) return ctx->fail(LSSPA_ERR_STATE, "the running estimator is not enabled");
+  HIPCHK(hipSetDevice(ctx->device));
+  // a communicator on the context (of one rank or of many): the moments and the draws go through it, as in the
+  // separate calls; none: the chunk is folded and merged at once
+  const bool several = ctx->comm != nullptr;
+  for (int c = 0; c < n_chunks; ++c) {
+    if (count[c] > 0) {
+      TRY(lift_collect(ctx, ctx->lanes[ticket], first[c], count[c], nullptr, several ? 1 : 2));
+      TRY(lsspa_error_advance(ctx, first_id[c], stride));
+    }
+    if (several) {
+      TRY(lsspa_stats_allreduce(ctx));
+      TRY(lsspa_stats_merge(ctx));
+    }
+    if (n_after[c] > 0) {
+      if (several) {
+        TRY(lsspa_error_running_draws(ctx, n_after[c]));
+        TRY(lsspa_error_allreduce(ctx));
+        TRY(lsspa_error_quantiles_enqueue(ctx, slot[c]));
+      } else {
+        TRY(lsspa_error_check_enqueue(ctx, n_after[c], slot[c]));
+      }
+    }
+  }
   return LSSPA_OK;
 } catch (...) {
   return abi_caught(ctx);

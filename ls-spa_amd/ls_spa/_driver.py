@@ -385,7 +385,7 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
         per_rank = -(-min(int(batch_size), max_samples) // comm.world) * (2 if antithetical else 1)
         # a chunk's kernels, at 40 TFLOP/s, under 50 ms; the chunks of a look-ahead group are checked without waiting
         # in between (their kernels were one launch)
-        defer = max(1, group) if (can_defer and per_rank * float(p) ** 3 / 4e13 < 0.05) else 0
+        defer = min(max(1, group), engine.RESULT_SLOTS - 2) if (can_defer and per_rank * float(p) ** 3 / 4e13 < 0.05) else 0
     defer = int(defer) if can_defer else 0
     if not 0 <= defer < engine.RESULT_SLOTS - 1 if on_device else False:
         raise ValueError("defer must be between 0 and the number of result slots - 2")
@@ -467,13 +467,20 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
             first += len(e[1])
         queue.extend(entries)
 
+    # the whole group in one library call: device estimator with its checks deferred by a group at least, nothing that
+    # needs a chunk's lift vectors on the host, and moments that travel through the engine's own communicator (or not
+    # at all)
+    fast_group = (on_device and defer >= group and defer > 0 and not keep_lifts and checkpoint is None
+                  and hasattr(engine, "group_collect")
+                  and (single or getattr(comm, "_engine", None) is engine))
     stopped_at = None      # (mean, n) of the check whose stop rule fired (device estimator)
     resolved = [0]
 
     def resolve_due(limit):
-        """Read the oldest outstanding checks until at most `limit` are left; True if one of them stops the run."""
+        """Read the oldest outstanding checks until at most `limit` are left (the first check of a run is always read,
+        whatever the limit); True if one of them stops the run."""
         nonlocal feat_err, total_err, stopped_at, t_estimator
-        while len(outstanding) > limit:
+        while outstanding and (len(outstanding) > limit or not resolved[0]):
             t_e0 = _time.perf_counter()
             n_k, slot = outstanding.pop(0)
             feat_err, total_err, mean_k, _ = engine.error_result(slot, wait=True)
@@ -493,6 +500,42 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
             break
         chunk, mine, want, ticket, first = queue.pop(0)
         n_new = len(chunk)
+        if fast_group and ticket is not None:
+            # every chunk of the launched group in ONE call into the library (lsspa_group_collect): collect, all-reduce
+            # and merge, fold into the estimator, enqueue the check -- per chunk, in the reference's order; at p = 100 a
+            # chunk is 37 us of GPU work and this loop's own calls were what a run waited for
+            members = [(chunk, mine, want, ticket, first)]
+            while queue and queue[0][3] is ticket:
+                members.append(tuple(queue.pop(0)))
+            if (all(len(m[0]) == m[2] for m in members)
+                    and len(outstanding) + len(members) < engine.RESULT_SLOTS):
+                t_g0 = _time.perf_counter()
+                cursor = i
+                if prefetch and not queue:
+                    refill(i + sum(len(m[0]) for m in members))      # the next group, on the other lane
+                firsts, counts, ids, n_after, slots = [], [], [], [], []
+                for ch, mn, _, _, fs in members:
+                    firsts.append(fs)
+                    counts.append(len(mn))
+                    ids.append(cursor + comm.rank)
+                    cursor += len(ch)
+                    due = estimate and (cursor % batch_size == 0 or cursor == max_samples - 1)
+                    n_after.append(cursor if due else 0)
+                    slots.append(slot_turn[0] if due else 0)
+                    if due:
+                        slot_turn[0] = (slot_turn[0] + 1) % engine.RESULT_SLOTS
+                engine.group_collect(ticket, firsts, counts, ids, comm.world, n_after, slots)
+                outstanding.extend((n_a, sl) for n_a, sl in zip(n_after, slots) if n_a)
+                i, pending = cursor, n_after[-1] == 0
+                halt = resolve_due(defer)
+                if timings is not None and "check_s" in timings:
+                    k = max(1, sum(1 for v in n_after if v))
+                    timings["check_s"].extend([(_time.perf_counter() - t_g0) / k] * k)
+                if halt or i >= max_samples:
+                    break
+                continue
+            for m in reversed(members[1:]):      # a chunk cut short by a dry source: chunk by chunk below
+                queue.insert(0, list(m))
         if prefetch and not queue and ticket is not None and len(chunk) == want:
             refill(i + n_new)      # the next group, on the other lane
         local = None
@@ -533,7 +576,7 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
             enqueue_check(i)
             t_estimator += _time.perf_counter() - t_e0
             pending = False
-            halt = resolve_due(defer if resolved[0] else 0)
+            halt = resolve_due(defer)
             if timings is not None and "check_s" in timings:
                 timings["check_s"].append(_time.perf_counter() - t_e0)
             if halt:

@@ -323,7 +323,7 @@ class HipEngine:
         return feat, tot.value
 
     # ---- running form of the device-side estimator (include/lsspa.h) ---------------------
-    RESULT_SLOTS = 16
+    RESULT_SLOTS = 32
 
     def error_running_enable(self, seed: int):
         """D = Xi L and s = Xi 1 stay in HBM; Xi is a function of (seed, sample id, draw)."""
@@ -352,6 +352,20 @@ class HipEngine:
         if not ready.value:
             return None
         return feat, tot.value, mean, n.value
+
+    def group_collect(self, ticket, first, count, first_id, stride, n_after, slot):
+        """The chunks of a launched batch in one call (include/lsspa.h, lsspa_group_collect): per chunk collect,
+        (all-reduce + merge), fold into the running estimator and -- where n_after > 0 -- enqueue its check."""
+        first = np.ascontiguousarray(first, dtype=np.int32)
+        count = np.ascontiguousarray(count, dtype=np.int32)
+        first_id = np.ascontiguousarray(first_id, dtype=np.int64)
+        n_after = np.ascontiguousarray(n_after, dtype=np.int64)
+        slot = np.ascontiguousarray(slot, dtype=np.int32)
+        k = len(first)
+        assert len(count) == len(first_id) == len(n_after) == len(slot) == k
+        self._check(self._lib.lsspa_group_collect(
+            self._h, ticket[0], k, N.iptr(first), N.iptr(count), first_id.ctypes.data_as(N._pi64), int(stride),
+            n_after.ctypes.data_as(N._pi64), N.iptr(slot)))
 
     def error_state(self):
         D, s = np.empty((1024, self.p)), np.empty(1024)

@@ -73,6 +73,7 @@ SIGNATURES = {
     "lsspa_error_quantiles_enqueue": (C.c_int, [_vp, _i32]),
     "lsspa_error_check_enqueue": (C.c_int, [_vp, _i64, _i32]),
     "lsspa_error_result": (C.c_int, [_vp, _i32, _i32, _pi32, _pd, _pd, _pd, _pi64]),
+    "lsspa_group_collect": (C.c_int, [_vp, _i32, _i32, _pi32, _pi32, _pi64, _i64, _pi64, _pi32]),
     "lsspa_error_state_get": (C.c_int, [_vp, _pd, _pd]),
     "lsspa_error_state_set": (C.c_int, [_vp, _pd, _pd]),
     "lsspa_error_xi": (C.c_int, [_vp, C.c_uint64, _i64, _i64, _i64, _pd]),

@@ -181,7 +181,7 @@ class OracleEngine:
     # running form (mirrors lsspa_error_running_* / _advance / _quantiles_enqueue / _result): D = Xi L, s = Xi 1 with the
     # counter-based normals of tests/philox_ref.py; a check's results are computed when it is enqueued and handed out
     # when its slot is read
-    RESULT_SLOTS = 16
+    RESULT_SLOTS = 32
 
     def error_running_enable(self, seed):
         self._run_on, self._run_seed = True, int(seed)
@@ -204,6 +204,17 @@ class OracleEngine:
         with np.errstate(divide="ignore", invalid="ignore"):
             d = (self._D - np.outer(self._s, self._mean)) / np.sqrt(n_total * (n_total - 1.0))
         self._draws[:] = d.ravel()
+
+    def group_collect(self, ticket, first, count, first_id, stride, n_after, slot):
+        """lsspa_group_collect on one rank: per chunk collect + fold + (where due) enqueue the check."""
+        self.group_calls = getattr(self, "group_calls", 0) + 1
+        for f, c, fid, na, sl in zip(first, count, first_id, n_after, slot):
+            if c > 0:
+                self.collect_batch(ticket, want_lifts=False, accumulate=2, first=f, count=c)
+                self.error_advance(fid, stride)
+            if na > 0:
+                self.error_running_draws(na)
+                self.error_quantiles_enqueue(sl)
 
     def error_quantiles_enqueue(self, slot):
         feat, tot = self.error_quantiles()

@@ -190,6 +190,12 @@ def test_deferred_checks_give_the_stopping_checks_results(golden):
     np.testing.assert_array_equal(c.error_history, a.error_history)
     np.testing.assert_array_equal(c.attribution, a.attribution)
     assert e8.launched == 1 and len(c.error_history) == 4
+    assert e8.group_calls == 1            # ... and the group's chunks went through ONE library call (lsspa_group_collect)
+    e3 = OracleEngine()
+    c3 = ls_spa(*d, tolerance=0.0, _engine=e3, **dict(base, lookahead=3))
+    np.testing.assert_array_equal(c3.error_history, full.error_history)
+    np.testing.assert_array_equal(c3.attribution, full.attribution)
+    assert e3.group_calls == 3 and e3.calls == [16, 16, 16, 16, 16, 15, 1]
     # histories are cut at the stop as well
     tol = float(full.error_history[2]) * 1.0000001
     a = ls_spa(*d, tolerance=tol, return_attribution_history=True, _engine=OracleEngine(), _defer=0, **base)
