@@ -215,6 +215,44 @@ def algorithmic_flops(kclass, p, n_ord, tri, launches_per_batch, vt=False):
     return 0.0
 
 
+def read_gpu_sysfs(index):
+    """{'sclk_mhz', 'power_w'} of HIP device `index` from the amdgpu driver's sysfs files (hwmon freq1_input /
+    power1_average, pp_dpm_sclk as a fallback): no child process, nothing executed."""
+    import glob
+    base = None
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        if os.path.isdir(f"/sys/bus/pci/devices/{bdf}"):
+            base = f"/sys/bus/pci/devices/{bdf}"
+    except Exception:
+        base = None
+    if base is None:
+        cards = []
+        for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                if open(os.path.join(dev, "vendor")).read().strip() == "0x1002" and glob.glob(dev + "/hwmon/hwmon*"):
+                    cards.append(dev)
+            except OSError:
+                pass
+        base = cards[index]
+    out = {}
+    for hw in glob.glob(base + "/hwmon/hwmon*"):
+        for name in ("power1_average", "power1_input"):
+            f = os.path.join(hw, name)
+            if "power_w" not in out and os.path.exists(f):
+                out["power_w"] = int(open(f).read().strip()) / 1e6
+        f = os.path.join(hw, "freq1_input")
+        if os.path.exists(f):
+            out["sclk_mhz"] = int(open(f).read().strip()) / 1e6
+    if "sclk_mhz" not in out and os.path.exists(base + "/pp_dpm_sclk"):
+        for ln in open(base + "/pp_dpm_sclk"):
+            if "*" in ln:
+                out["sclk_mhz"] = float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+    return out
+
+
 def host_threads():
     try:
         return len(os.sched_getaffinity(0))
@@ -445,6 +483,9 @@ def main():
         eng.synchronize()
         reduce_warm_ms = 1e3 * (time.perf_counter() - t0)
     gram_ms, gram_n = eng.profile_read()["gram"]
+    # theta and R^2 of the full model, as the public call computes them before its loop: from here on every batch of the
+    # engine is checked on the device against "the lifts of a sample sum to R^2" (LSSPA_INFO_SUM, include/lsspa.h)
+    _, r2_full, _ = eng.full_fit()
     del dXa, dXe, dya, dye
     torch.cuda.empty_cache()
 
@@ -554,7 +595,7 @@ def main():
     # 0.13 s at C3 -- and the chip needs ~0.4 s of back-to-back launches to settle on the clock it holds under load.  The
     # same step function over >= SUSTAIN_S seconds (the step count follows from the headline time, identical on every
     # rank), after the headline region so that `value` keeps its definition; the orderings are the region's, cyclically.
-    # Rank 0 asks rocm-smi for clock and power about a second into the region (in a helper thread; None if it does not answer).
+    # Rank 0 reads clock and power from the driver's sysfs files about a second into the region (helper thread; None if absent).
     sustained = None
     if not args.no_sustained:
         SUSTAIN_S = 3.0
@@ -574,17 +615,12 @@ def main():
         smi = {}
 
         def ask_smi():
-            import subprocess
+            # clock and power from sysfs, in-process (round 5): up to round 4 this started `rocm-smi`, a
+            # `#!/usr/bin/env python3` script -- under rocprofv3 the child inherits the profiler's preload, which
+            # initialises the GPU in `env`, and `env` then execs: the exec-after-GPU-init this pool forbids
             time.sleep(1.0)
             try:
-                r = subprocess.run(["rocm-smi", "-d", str(local), "--showclocks", "--showpower", "--json"],
-                                   capture_output=True, text=True, timeout=10)
-                card = next(iter(json.loads(r.stdout).values()))
-                for k, v in card.items():
-                    if "sclk" in k.lower() and "clock speed" in k.lower():
-                        smi["sclk_mhz"] = float(str(v).strip("()").lower().replace("mhz", ""))
-                    if "power" in k.lower() and "(w)" in k.lower():
-                        smi["power_w"] = float(v)
+                smi.update(read_gpu_sysfs(local))
             except Exception as exc:
                 smi["error"] = repr(exc)
 
@@ -599,9 +635,9 @@ def main():
             th.join(timeout=15)
         sustained = {"steps": n_sus, "seconds": el_sus, "ms_per_step": 1e3 * el_sus / n_sus,
                      "orderings_per_s": world * n_ord * n_sus / el_sus, "ms_per_step_min_rank": 1e3 * el_sus_min / n_sus,
-                     "sclk_mhz": smi.get("sclk_mhz"), "power_w": smi.get("power_w"), "rocm_smi_error": smi.get("error"),
+                     "sclk_mhz": smi.get("sclk_mhz"), "power_w": smi.get("power_w"), "sysfs_error": smi.get("error"),
                      "note": "the same step function as the headline region over >= 3 s (max over ranks); clock and power "
-                             "as rocm-smi reports them about one second into the region"}
+                             "as the amdgpu driver's sysfs files (hwmon) report them about one second into the region"}
     # pass 2: the same K steps again with a HIP-event pair around every launch on the engine's
     # stream -> per-kernel durations for the roofline figures (one lane: each kernel alone on the GPU)
     eng.set_lanes(1)
@@ -751,8 +787,11 @@ def main():
             "reduction_ms": reduce_ms, "reduction_ms_warm_call": reduce_warm_ms,
             "host_data_generation_s": gen_s,
             # engine_info: LSSPA_INFO_* bits raised by any launch of this process so far (1: a pivot was not positive,
-            # 4: a hand-over inside a panel launch timed out) -- 0 on the benchmark data
-            "check": {"samples": int(n_seen), "sum_attribution": float(mean.sum()), "engine_info": int(eng.info())},
+            # 4: a hand-over inside a panel launch timed out, 8: a sample's lifts did not sum to R^2) -- 0 on the benchmark data
+            # sum_deviation_max: largest |sum of a sample's lifts - R^2| over the batches since the last reset (checked on
+            # the device for every batch; beyond 1e-9 / 1e-4 (fp32 work) it raises bit 8)
+            "check": {"samples": int(n_seen), "sum_attribution": float(mean.sum()), "r_squared": float(r2_full),
+                      "engine_info": int(eng.info()), "sum_deviation_max": float(eng.sum_deviation())},
             "ms_per_step_min_rank": 1e3 * elapsed_min / args.steps,
             "sustained": sustained,
             "timing_note": "value/ms_per_step: K steps without events (two lanes: launch sequences overlap across two "

@@ -35,6 +35,7 @@ extern "C" {
 /* info bit flags (lsspa_get_info) */
 #define LSSPA_INFO_NOT_PD 1 /* a non-positive pivot was met in a Cholesky step */
 #define LSSPA_INFO_SCAN_WAIT 4 /* an X tile gave up waiting for row p of its panel (fused lift scan): results invalid */
+#define LSSPA_INFO_SUM 8 /* a sample's lifts did not sum to the R^2 of the full model (to 1e-9, fp32 work: 1e-4): results invalid */
 
 typedef struct lsspa_ctx lsspa_ctx;
 
@@ -139,6 +140,12 @@ int lsspa_get_info(lsspa_ctx* ctx, int32_t* info);
 /* The same word without waiting for batches that were launched and never collected (they may still be running on a
  * lane): the bits of every batch whose samples were collected are in it.  lsspa_get_info waits for everything. */
 int lsspa_get_info_collected(lsspa_ctx* ctx, int32_t* info);
+/* Every ordering's lifts telescope to the R^2 of the full model (ls_spa/ls_spa.py:284-285), so every sample's lift
+ * vector must sum to it.  Once lsspa_full_fit has computed that R^2, every batch is checked on the device right after
+ * its lifts: a deviation beyond 1e-9 max(1, |R^2|) (fp32 per-ordering work: 1e-4) raises LSSPA_INFO_SUM -- the data a
+ * kernel took from another workgroup, a tile left out, an ordering read wrong all show here.  This returns the largest
+ * deviation of all batches since the last lsspa_stats_reset (waits for everything in flight). */
+int lsspa_get_sum_deviation(lsspa_ctx* ctx, double* max_deviation);
 
 /* a4 -- replaces merge_sample_mean / merge_sample_cov (ls_spa/ls_spa.py:103-119, :212-216).
  * The pending-batch buffer is a device fp64 array [1 + p + p*p] = [n_b, sum(l - mu), sum (l - mu)(l - mu)^T];

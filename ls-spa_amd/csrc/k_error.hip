@@ -4,8 +4,8 @@
 // feature and of ||x||_2 (cvxgrp/ls-spa ls_spa/ls_spa.py:321-341), which costs a p x p Cholesky or,
 // on the always-singular sample covariance, an SVD.  With H the n x p matrix of lift vectors and
 // Xi ~ N(0, I) of shape 1024 x n,   x = Xi (H - 1 mu^T) / sqrt(n (n - 1))   has exactly that
-// covariance, so the draws are one thin GEMM.  Xi comes from the host generator (the stream the
-// reference's sampler shares); everything else stays in HBM:
+// covariance, so the draws are one thin GEMM.  In the thin form with the caller's own normals (lsspa_error_draws) Xi
+// comes from the host; everything else stays in HBM:
 //   draws_kernel     : 64 x 128 tiles of Xi * H on the fp64 MFMA, centring and scaling fused into the
 //                      store.  With several GPUs each rank multiplies its own samples' rows of H by
 //                      the matching columns of Xi; the partial draws are summed by ONE all-reduce.
@@ -15,12 +15,12 @@
 //
 // Running form (round 5): the cost of a check must not grow with the number of samples n, or a run of many checks is
 // bound by the estimator instead of the sampling (128 checks at p = 1000 drew 1.08e9 host normals).  Xi is made a pure
-// function of (seed, sample id k, draw d) -- Philox4x32-10 keyed by the seed, counter = (k, d / 2), Box-Muller on the
-// four output words -- so a column of Xi never has to be stored or drawn twice, and
+// function of (seed, sample id k, draw d) -- Philox4x32-10 keyed by the seed, counter = (k, Philox call), Box-Muller on
+// the four output words -- so a column of Xi never has to be kept or drawn twice, and
 //       D = Xi L   [1024][p]      s = Xi 1   [1024]
-// stay in HBM: a chunk of new samples adds  Xi_new L_new  and  Xi_new 1  (xi_fill_kernel + the GEMM above in its
-// accumulate mode), a check is  x = (D - s mu^T) / sqrt(n (n - 1))  (running_draws_kernel) and the two quantile
-// kernels.  At every check x has, given the lift vectors, exactly the distribution N(0, C_unbiased / n) the reference
+// stay in HBM: a chunk of new samples adds  Xi_new L_new  and  Xi_new 1  (xi_fill_kernel + acc_small_kernel), a check
+// is  x = (D - s mu^T) / sqrt(n (n - 1))  -- evaluated by the quantile kernels as they read it (one rank) or written
+// by running_draws_kernel for the all-reduce (several) -- and the two quantile kernels.  At every check x has, given the lift vectors, exactly the distribution N(0, C_unbiased / n) the reference
 // samples from; successive checks reuse the columns of Xi of the samples they share (the reference redraws: its
 // checks are independent given the samples, ours are positively correlated -- each one's distribution is the same).
 // With several GPUs each rank holds D and s of its own samples; x is linear in them, so ONE all-reduce of the
@@ -51,8 +51,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 // The two normals Philox call j of sample `id` yields: u1, u2 = the 53 high bits of (w0, w1), (w2, w3) plus a half, over
 // 2^53 -- both in (0, 1) --, then Box-Muller.  They are draws 64 b + r and 64 b + r + 32 of the sample, j = 32 b + r
-// (r < 32): the two rows a thread of the GEMM below stages of a 64-draw tile, so that the tile can be made in
-// registers without a wasted output.
+// (r < 32).
 __device__ __forceinline__ void xi_pair(uint64_t seed, uint64_t id, uint32_t j, double& z0, double& z1) {
   uint32_t w[4];
   philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), j, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
@@ -65,22 +64,11 @@ __device__ __forceinline__ void xi_pair(uint64_t seed, uint64_t id, uint32_t j, 
   z1 = rad * sn;
 }
 
-// ACC = false: draws = (Xi H - rowsum(Xi) mean^T) * scale.   ACC = true (running form): draws += Xi H and
-// rowsum_acc += rowsum(Xi) (by the workgroups of feature tile 0), nothing centred or scaled.
-// GEN (with ACC): Xi is not read but MADE, tile by tile, in the registers that would stage it: thread (row, c) of a
-// 64 x 16 tile holds draws row, row + 32 of samples 2 c, 2 c + 1 of the chunk = two Philox calls (xi_pair).
-struct XiGen {
-  uint64_t seed;
-  int64_t first_id, stride;
-  int count;
-};
-
-template <bool ACC, bool GEN>
+// draws = (Xi H - rowsum(Xi) mean^T) * scale: the thin form with the caller's normals (lsspa_error_draws)
 __global__ __launch_bounds__(256, 2) void draws_kernel(const double* __restrict__ Xi, int ldxi,
                                                        const double* __restrict__ H, int ldh, int n_pad,
                                                        const double* __restrict__ mean, double scale, int p,
-                                                       double* __restrict__ draws, int ldd,
-                                                       double* __restrict__ rowsum_acc, XiGen gen) {
+                                                       double* __restrict__ draws, int ldd) {
   __shared__ __attribute__((aligned(16))) double s_rk[64 * RK_LD];
   __shared__ __attribute__((aligned(16))) double s_kc[16 * KC_LD];
   __shared__ double s_rs[64];
@@ -101,21 +89,7 @@ __global__ __launch_bounds__(256, 2) void draws_kernel(const double* __restrict_
   const int nch = n_pad / KCH;
   RKRegs<double, 64> ra = {};
   KCRegs<double> rb = {};
-  // the staging layout of rk_load / rk_store (tiles.h): vector c = tid % 8 of rows tid / 8 and tid / 8 + 32
-  auto make_a = [&](int chunk) {
-    const int cc = tid & 7, row = tid >> 3;
-    const uint32_t j = (uint32_t)(32 * blockIdx.x + row);
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int k = chunk * KCH + 2 * cc + e;
-      double z0 = 0.0, z1 = 0.0;
-      if (k < gen.count) xi_pair(gen.seed, (uint64_t)(gen.first_id + (int64_t)k * gen.stride), j, z0, z1);
-      ra.v[0][e] = z0;
-      ra.v[1][e] = z1;
-    }
-  };
-  if (GEN) make_a(0);
-  else rk_load<double, 64>(ra, srcA, ldxi, tid, 64);
+  rk_load<double, 64>(ra, srcA, ldxi, tid, 64);
   kc_load<double>(rb, srcB, ldh, tid);
   for (int c = 0; c < nch; ++c) {
     __syncthreads();
@@ -123,8 +97,7 @@ __global__ __launch_bounds__(256, 2) void draws_kernel(const double* __restrict_
     kc_store<double>(rb, s_kc, tid);
     __syncthreads();
     if (c + 1 < nch) {
-      if (GEN) make_a(c + 1);
-      else rk_load<double, 64>(ra, srcA + (c + 1) * KCH, ldxi, tid, 64);
+      rk_load<double, 64>(ra, srcA + (c + 1) * KCH, ldxi, tid, 64);
       kc_load<double>(rb, srcB + (int64_t)(c + 1) * KCH * ldh, ldh, tid);
     }
 #pragma unroll
@@ -161,19 +134,13 @@ __global__ __launch_bounds__(256, 2) void draws_kernel(const double* __restrict_
 #pragma unroll
       for (int y = 0; y < 2; ++y) {
         const int a = c0 + 32 * w + 16 * y + l15;
-        if (ACC) {
-          if (a < p) draws[(int64_t)(d0 + dl) * ldd + a] += acc[x][y][r];
-        } else {
-          const double v = (a < p) ? (acc[x][y][r] - rsum * mean[a]) * scale : 0.0;
-          draws[(int64_t)(d0 + dl) * ldd + a] = v;
-        }
+        const double v = (a < p) ? (acc[x][y][r] - rsum * mean[a]) * scale : 0.0;
+        draws[(int64_t)(d0 + dl) * ldd + a] = v;
       }
     }
-  if (ACC && blockIdx.y == 0 && tid < 64) rowsum_acc[d0 + tid] += s_rs[tid];
 }
 
-// Xi [1024][n_pad] for sample ids first_id + k * stride, k < count; columns k >= count are zero (test hook: the
-// product path makes the same numbers inside the GEMM and never stores them)
+// Xi [1024][n_pad] for sample ids first_id + k * stride, k < count; columns k >= count are zero
 __global__ __launch_bounds__(256) void xi_fill_kernel(uint64_t seed, int64_t first_id, int64_t stride, int count,
                                                       int n_pad, double* __restrict__ Xi) {
   const int k = blockIdx.x * 256 + threadIdx.x;   // column (sample)
@@ -264,14 +231,72 @@ __global__ __launch_bounds__(512) void quantile_kernel(DrawSrc src, const double
   }
 }
 
+// D[1024][ld] += Xi L and s += Xi 1 for ONE chunk of samples (tens to a few hundred): the 64 x 128-tile kernel above
+// has 16 workgroups per feature tile and walks the samples 16 at a time between two barriers -- 22 us at p = 100, 128
+// samples, all of it latency.  Here a workgroup owns 16 draws x 128 features (64 workgroups per feature tile), its four
+// waves split the samples among them, every lane fetches its own matrix-instruction operands straight from memory (no
+// staging, no barrier in the loop), and the four partial tiles meet once in LDS.
+__global__ __launch_bounds__(256) void acc_small_kernel(const double* __restrict__ Xi, int n_pad,
+                                                        const double* __restrict__ L, int ldl, int k_valid, int c_valid,
+                                                        int p, double* __restrict__ D, int ld,
+                                                        double* __restrict__ rowsum_acc) {
+  __shared__ double part[4 * 8 * 4 * 64];   // [wave][feature tile][r][lane]
+  __shared__ double s_rs[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int d0 = blockIdx.x * 16, c0 = blockIdx.y * 128;
+  d4 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = d4_zero();
+  double rs = 0.0;
+  const int kq = n_pad / 4;                  // this wave's samples: [w kq, (w + 1) kq), kq a multiple of 4
+  const double* arow = Xi + (int64_t)(d0 + l15) * n_pad + w * kq + l4;
+#pragma unroll 2
+  for (int st = 0; st < kq / 4; ++st) {
+    const int k = w * kq + 4 * st + l4;
+    const double a = arow[4 * st];
+    rs += a;
+    double b[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int c = c0 + 16 * t + l15;
+      b[t] = (k < k_valid && c < c_valid) ? L[(int64_t)k * ldl + c] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = mfma(a, b[t], acc[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[((w * 8 + t) * 4 + r) * 64 + lane] = acc[t][r];
+  rs += __shfl_xor(rs, 16, 64);
+  rs += __shfl_xor(rs, 32, 64);
+  if (l4 == 0) s_rs[w][l15] = rs;
+  __syncthreads();
+  // wave w adds up feature tiles 2 w and 2 w + 1 and folds them into D
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int t = 2 * w + u;
+    const int c = c0 + 16 * t + l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) v += part[((ww * 8 + t) * 4 + r) * 64 + lane];
+      if (c < p) D[(int64_t)(d0 + acc_row(l4, r)) * ld + c] += v;
+    }
+  }
+  if (blockIdx.y == 0 && tid < 16) rowsum_acc[d0 + tid] += (s_rs[0][tid] + s_rs[1][tid]) + (s_rs[2][tid] + s_rs[3][tid]);
+}
+
 hipError_t launch_error_draws(const double* Xi, int ldxi, const double* H, int ldh, int n_pad,
                               const double* mean, double scale, int p, double* draws, int ldd, hipStream_t st) {
   const int n_tiles = (p + 127) / 128;
   if (p < 1 || n_pad < KCH || n_pad % KCH != 0 || ldxi < n_pad || (ldxi & 1) || ldh % 128 != 0 ||
       ldh < n_tiles * 128 || ldd < n_tiles * 128)
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL((draws_kernel<false, false>), dim3(ND / 64, n_tiles), dim3(256), 0, st, Xi, ldxi, H, ldh, n_pad,
-                     mean, scale, p, draws, ldd, (double*)nullptr, XiGen{});
+  hipLaunchKernelGGL(draws_kernel, dim3(ND / 64, n_tiles), dim3(256), 0, st, Xi, ldxi, H, ldh, n_pad, mean, scale, p,
+                     draws, ldd);
   return hipGetLastError();
 }
 
@@ -284,14 +309,23 @@ hipError_t launch_error_xi(uint64_t seed, int64_t first_id, int64_t stride, int 
   return hipGetLastError();
 }
 
-hipError_t launch_error_accumulate(uint64_t seed, int64_t first_id, int64_t stride, int count, int n_pad,
-                                   const double* L, int ldh, int p, double* D, double* s, hipStream_t st) {
+hipError_t launch_error_accumulate(uint64_t seed, int64_t first_id, int64_t stride, int count, int n_pad, double* Xi,
+                                   const double* L, int ldl, int raw, int ldh, int p, double* D, double* s,
+                                   hipStream_t st) {
   const int n_tiles = (p + 127) / 128;
   if (p < 1 || count < 1 || n_pad < KCH || n_pad % KCH != 0 || count > n_pad || stride < 1 || first_id < 0 ||
-      ldh % 128 != 0 || ldh < n_tiles * 128)
+      ldh % 128 != 0 || ldh < n_tiles * 128 || (raw ? ldl < p : ldl != ldh) || !Xi)
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL((draws_kernel<true, true>), dim3(ND / 64, n_tiles), dim3(256), 0, st, (const double*)nullptr, 0,
-                     L, ldh, n_pad, (const double*)nullptr, 1.0, p, D, ldh, s, XiGen{seed, first_id, stride, count});
+  // the normals by a launch of their own, one thread per Philox call (count x 512 of them: a thousand waves), not inside
+  // the GEMM: its 64 waves would make them one after the other -- fp64 log and sincospi are ~300 instructions a call,
+  // 28 us against 3 + 5 (measured at p = 100, 128 samples)
+  hipLaunchKernelGGL(xi_fill_kernel, dim3((n_pad + 255) / 256, ND / 2), dim3(256), 0, st, seed, first_id, stride, count,
+                     n_pad, Xi);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // the lift vectors as the lift kernels left them ([count][ldl], no padding: guarded reads) or the padded staging
+  hipLaunchKernelGGL(acc_small_kernel, dim3(ND / 16, n_tiles), dim3(256), 0, st, (const double*)Xi, n_pad, L, ldl,
+                     raw ? count : n_pad, raw ? p : ldh, p, D, ldh, s);
   return hipGetLastError();
 }
 
@@ -305,6 +339,8 @@ hipError_t launch_error_running_draws(const double* D, const double* s, const do
 
 static hipError_t launch_quantiles(const DrawSrc& src, int p, double* norms, double* out, const double* pack_mean,
                                    const double* pack_n, hipStream_t st) {
+  // (the overall error's workgroup summing its 1024 draws' squares itself, to save the launch: 105 us instead of 4.7 + 21
+  // at p = 100 -- one workgroup's dependent shuffle chains against 256 workgroups' -- measured, not kept)
   hipLaunchKernelGGL(row_norms_kernel, dim3(ND / 4), dim3(256), 0, st, src, p, norms);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

@@ -172,6 +172,34 @@ __global__ __launch_bounds__(256) void lift_finish_paired_kernel(LiftArgs a) {
   a.lifts[(int64_t)sample * p + a.perms[(int64_t)ord * p + j]] = v0 + v1;
 }
 
+// Every ordering's lifts telescope to the R^2 of the full model (ls_spa/ls_spa.py:284-285: R_sq[p] - R_sq[0]), hence so
+// does every sample's antithetical mean: a free end-to-end check of a batch -- a hand-over inside a panel launch that
+// delivered stale data, a tile skipped, an ordering read wrong all break it.  One wave per sample; a sum off by more
+// than tol (or not a number) raises LSSPA_INFO_SUM, and the largest deviation seen is kept next to the info word.
+__global__ __launch_bounds__(256) void sum_check_kernel(const double* __restrict__ lifts, int n_samples, int p, double r2,
+                                                        double tol, int32_t* __restrict__ info) {
+  const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= n_samples) return;
+  double v = 0.0;
+  for (int a = lane; a < p; a += 64) v += lifts[(int64_t)s * p + a];
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  if (lane == 0) {
+    double dev = fabs(v - r2);
+    if (!(dev <= tol)) atomicOr(info, 8);                  // LSSPA_INFO_SUM (also when the sum is not a number)
+    if (!(dev == dev)) dev = __longlong_as_double(0x7ff0000000000000ll);
+    // non-negative doubles order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned long long*>(info + 2), (unsigned long long)__double_as_longlong(dev));
+  }
+}
+
+hipError_t launch_sum_check(const double* lifts, int n_samples, int p, double r2, double tol, int32_t* info,
+                            hipStream_t st) {
+  if (n_samples < 1 || p < 1 || !(tol >= 0.0)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sum_check_kernel, dim3((n_samples + 3) / 4), dim3(256), 0, st, lifts, n_samples, p, r2, tol, info);
+  return hipGetLastError();
+}
+
 hipError_t launch_lift(const LiftArgs& a, hipStream_t st) {
   if (a.p < 1 || a.p_pad % NB != 0 || a.m_pad % 128 != 0 || a.n_ord < 1 ||
       (a.per_sample != 1 && a.per_sample != 2) || a.n_ord % a.per_sample != 0 || !(a.y_norm_sq > 0.0))

@@ -132,6 +132,10 @@ struct LiftArgs {
   int fused = 0;           // vt: Ppart already holds the X tiles' own sums, one row per 128-row block of V^T (PanelLift)
 };
 hipError_t launch_lift(const LiftArgs& a, hipStream_t st);
+// |sum of a sample's lifts - r2| <= tol for every sample, else bit 8 (LSSPA_INFO_SUM) of info[0]; the largest deviation
+// of all launches since the last reset as a double in info[2..3]
+hipError_t launch_sum_check(const double* lifts, int n_samples, int p, double r2, double tol, int32_t* info,
+                            hipStream_t st);
 
 // pending-batch moments about the current running mean: buf = [n_b, S (p), Q (p x p)]
 // parts: workspace of stats_batch_slices(n_samples, p) * (1 + p + p*p) doubles (or NULL: one slice)
@@ -194,12 +198,15 @@ hipError_t launch_error_quantiles_running(const double* D, const double* s, cons
                                           int p, double* norms, double* out, const double* pack_n, hipStream_t st);
 // Running form of the estimator (k_error.hip): Xi[d][k] = standard normal made by Philox4x32-10 from (seed, sample id
 // first_id + k stride, draw d), k < count, zero up to n_pad (a multiple of 16).  launch_error_xi stores Xi [1024][n_pad]
-// (test hook); launch_error_accumulate makes the same numbers in registers and adds D[1024][ldh] += Xi L,
-// s[1024] += Xi 1 for the chunk's lift vectors L [n_pad][ldh]; launch_error_running_draws: x = (D - s mean^T) * scale.
+// (also the test hook); launch_error_accumulate does that into the workspace Xi [1024][n_pad] and adds
+// D[1024][ldh] += Xi L, s[1024] += Xi 1 for the chunk's lift vectors L; launch_error_running_draws:
+// x = (D - s mean^T) * scale.
 hipError_t launch_error_xi(uint64_t seed, int64_t first_id, int64_t stride, int count, int n_pad, double* Xi,
                            hipStream_t st);
-hipError_t launch_error_accumulate(uint64_t seed, int64_t first_id, int64_t stride, int count, int n_pad,
-                                   const double* L, int ldh, int p, double* D, double* s, hipStream_t st);
+// L: raw == 0: [n_pad][ldl = ldh], padded and zero-filled; raw != 0: [count][ldl >= p] as the lift kernels wrote it
+hipError_t launch_error_accumulate(uint64_t seed, int64_t first_id, int64_t stride, int count, int n_pad, double* Xi,
+                                   const double* L, int ldl, int raw, int ldh, int p, double* D, double* s,
+                                   hipStream_t st);
 hipError_t launch_error_running_draws(const double* D, const double* s, const double* mean, double scale, int p,
                                       int ld, double* draws, hipStream_t st);
 

@@ -88,6 +88,8 @@ struct lsspa_ctx {
   bool have_problem = false;
   int p = 0, p_pad = 0, m = 0, m_pad = 0, tri = 0;
   double aug_train = 0.0, y_norm_sq = 0.0;
+  double r2 = 0.0;               // R^2 of the full model (lsspa_full_fit): what every lift vector must sum to
+  bool r2_valid = false;
   DevBuf<double> G, g, H, h, Ft, ytil, scal;
   DevBuf<float> Gf, Hf;        // fp32 copies of G / H for the fp32 gather, made on first use
   bool src_f32_valid = false;
@@ -124,6 +126,8 @@ struct lsspa_ctx {
   DevBuf<double> Dacc, sacc;
   static constexpr int RES_SLOTS = 32;
   double* res_h = nullptr;            // pinned [RES_SLOTS][2 p + 2]: feature errors, overall error, mean, n
+  double* res_hd = nullptr;           // the same memory as the device sees it: the quantile kernel writes a check's
+                                      // results there itself (no copy in the chain of a check)
   size_t res_h_count = 0;
   hipEvent_t res_ev[RES_SLOTS] = {nullptr};
   bool res_valid[RES_SLOTS] = {false};
@@ -320,6 +324,7 @@ int set_dims(lsspa_ctx* ctx, int p, int m, int tri) {
   }
   TRY(sync_all(ctx));  // buffers below may be re-allocated
   ctx->have_problem = false;
+  ctx->r2_valid = false;
   ctx->src_f32_valid = false;
   // a workspace sized for another shape is released now: kept, it would count as unavailable memory when the
   // new one is sized from hipMemGetInfo (and its layout depends on p_pad / m_pad / tri anyway)
@@ -685,7 +690,15 @@ int ensure_f32_sources(lsspa_ctx* ctx) {
 // lifts for sample s land in lifts_d[(s_off + s)][p].  (Rounds 1-3 could cut a batch into two slices on two streams of
 // ONE lane, developer flag 32, +0.8 %; the two lanes of round 4 do that across batches and better -- removed.)
 int run_orderings(lsspa_ctx* ctx, Lane& L, int n_ord, int per_sample, int s_off) {
-  return run_slice(ctx, L, 0, n_ord, per_sample, s_off, ctx->lane_stream(L));
+  const hipStream_t st = ctx->lane_stream(L);
+  TRY(run_slice(ctx, L, 0, n_ord, per_sample, s_off, st));
+  // the batch's own end-to-end check, once the full model's R^2 is known (lsspa_full_fit): every lift vector sums to it
+  if (ctx->r2_valid && !ctx->general_path_once) {
+    const double tol = (ctx->f32 ? 1e-4 : 1e-9) * std::max(1.0, std::fabs(ctx->r2));
+    HIPCHK(launch_sum_check(L.lifts.ptr + (size_t)s_off * ctx->p, n_ord / per_sample, ctx->p, ctx->r2, tol,
+                            ctx->info_d.ptr, st));
+  }
+  return LSSPA_OK;
 }
 
 // Stage `count` orderings (with their reverses when per_sample == 2) on lane L and run them.
@@ -808,7 +821,24 @@ int check_accumulate(lsspa_ctx* ctx, int accumulate) {
 // Fold `count` samples of a launched batch, from sample `first` on, into the pending statistics (accumulate) and /
 // or copy their lift vectors out -- on the context's stream, in order.  The parts of a batch are taken front to
 // back; the lane is given back with the last one.
-int lift_collect(lsspa_ctx* ctx, Lane& L, int first, int count, double* lifts_out, int accumulate) {
+// What becomes of a collected chunk's lift vectors beyond the statistics: appended to the history (the thin-form
+// estimator, or the running form's staging until lsspa_error_advance names their sample ids) or, when the caller knows
+// the ids already (lsspa_group_collect), folded into the running estimator's sums straight from the lane's buffer.
+int keep_lifts(lsspa_ctx* ctx, const double* src, int count, const int64_t* ids /* first_id, stride or null */) {
+  if (ctx->run_on && ids) {
+    const int n_pad = ((count + KCH - 1) / KCH) * KCH;
+    TRY(dev_alloc(ctx, ctx->xi_d, (size_t)ERR_DRAWS * n_pad));
+    ProfScope ps(ctx, LSSPA_K_ERROR);
+    HIPCHK(launch_error_accumulate(ctx->run_seed, ids[0], ids[1], count, n_pad, ctx->xi_d.ptr, src, ctx->p, 1,
+                                   ctx->ldh(), ctx->p, ctx->Dacc.ptr, ctx->sacc.ptr, ctx->stream));
+    return LSSPA_OK;
+  }
+  if (ctx->hist_cap > 0) TRY(hist_append(ctx, src, count, hipMemcpyDeviceToDevice));
+  return LSSPA_OK;
+}
+
+int lift_collect(lsspa_ctx* ctx, Lane& L, int first, int count, double* lifts_out, int accumulate,
+                 const int64_t* est_ids = nullptr) {
   if (!L.in_flight) return ctx->fail(LSSPA_ERR_STATE, "no launched batch on this lane");
   const int p = ctx->p;
   if (count <= 0) count = L.B - first;
@@ -825,7 +855,7 @@ int lift_collect(lsspa_ctx* ctx, Lane& L, int first, int count, double* lifts_ou
                                     ctx->M2.ptr, count, p, ctx->stream));
     std::swap(ctx->mean, ctx->mean_alt);
     std::swap(ctx->state_n, ctx->state_alt);
-    if (ctx->hist_cap > 0) TRY(hist_append(ctx, src, count, hipMemcpyDeviceToDevice));
+    TRY(keep_lifts(ctx, src, count, est_ids));
   } else if (accumulate) {
     {
       ProfScope ps(ctx, LSSPA_K_STATS);
@@ -834,8 +864,8 @@ int lift_collect(lsspa_ctx* ctx, Lane& L, int first, int count, double* lifts_ou
       HIPCHK(launch_stats_batch(src, ctx->mean.ptr, ctx->pend.ptr, count, p, ctx->pend_dirty ? 1 : 0,
                                 nz > 1 ? ctx->stat_parts.ptr : nullptr, ctx->stream));
       ctx->pend_dirty = true;
-      if (ctx->hist_cap > 0) TRY(hist_append(ctx, src, count, hipMemcpyDeviceToDevice));
     }
+    TRY(keep_lifts(ctx, src, count, est_ids));
     if (accumulate == 2) TRY(lsspa_stats_merge(ctx));   // the general path: the same effect in its usual launches
   }
   if (lifts_out) {
@@ -1461,6 +1491,9 @@ int lsspa_full_fit(lsspa_ctx* ctx, double* theta, double* r_squared, int32_t* in
     double s = 0.0;
     for (int j = 0; j < p; ++j) s += l[j];
     *r_squared = s;
+    // from now on every batch is checked against it (run_orderings); not after a factorisation that broke down
+    ctx->r2 = s;
+    ctx->r2_valid = (now == 0) && std::isfinite(s);
   }
   return LSSPA_OK;
 } catch (...) {
@@ -1583,6 +1616,18 @@ int lsspa_get_info(lsspa_ctx* ctx, int32_t* info) try {
   HIPCHK(hipSetDevice(ctx->device));
   TRY(sync_all(ctx));   // the flag is raised by kernels on the lanes' streams
   HIPCHK(hipMemcpyAsync(info, ctx->info_d.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
+}
+
+int lsspa_get_sum_deviation(lsspa_ctx* ctx, double* max_deviation) try {
+  if (!ctx || !max_deviation) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  TRY(sync_all(ctx));
+  HIPCHK(hipMemcpyAsync(max_deviation, ctx->info_d.ptr + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return LSSPA_OK;
 } catch (...) {
@@ -1814,15 +1859,20 @@ int lsspa_error_running_enable(lsspa_ctx* ctx, uint64_t seed) try {
     if (ctx->res_h) (void)hipHostFree(ctx->res_h);
     ctx->res_h = nullptr;
     ctx->res_h_count = 0;
-    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->res_h), need * 8, hipHostMallocDefault) != hipSuccess) {
-      ctx->res_h = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->res_h), need * 8, hipHostMallocMapped | hipHostMallocCoherent) !=
+            hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->res_hd), ctx->res_h, 0) != hipSuccess) {
+      if (ctx->res_h) (void)hipHostFree(ctx->res_h);
+      ctx->res_h = ctx->res_hd = nullptr;
       (void)hipGetLastError();
       return ctx->fail(LSSPA_ERR_NOMEM, "hipHostMalloc (result slots of the estimator)");
     }
     ctx->res_h_count = need;
   }
   for (int k = 0; k < lsspa_ctx::RES_SLOTS; ++k) {
-    if (!ctx->res_ev[k]) HIPCHK(hipEventCreateWithFlags(&ctx->res_ev[k], hipEventDisableTiming));
+    // (release to system scope: the kernel's stores to the pinned slot are the host's to read once the event is done)
+    if (!ctx->res_ev[k])
+      HIPCHK(hipEventCreateWithFlags(&ctx->res_ev[k], hipEventDisableTiming | hipEventReleaseToSystem));
     ctx->res_valid[k] = false;
   }
   ctx->run_seed = seed;
@@ -1840,10 +1890,11 @@ int lsspa_error_advance(lsspa_ctx* ctx, int64_t first_id, int64_t stride) try {
   if (cnt == 0) return LSSPA_OK;
   HIPCHK(hipSetDevice(ctx->device));
   const int64_t n_pad = ((cnt + KCH - 1) / KCH) * KCH;
+  TRY(dev_alloc(ctx, ctx->xi_d, (size_t)ERR_DRAWS * n_pad));
   ProfScope ps(ctx, LSSPA_K_ERROR);
   // rows cnt .. n_pad of the staging hold older chunks' (finite) lift vectors: they meet the zero columns of Xi
-  HIPCHK(launch_error_accumulate(ctx->run_seed, first_id, stride, (int)cnt, (int)n_pad, ctx->hist.ptr, ctx->ldh(),
-                                 ctx->p, ctx->Dacc.ptr, ctx->sacc.ptr, ctx->stream));
+  HIPCHK(launch_error_accumulate(ctx->run_seed, first_id, stride, (int)cnt, (int)n_pad, ctx->xi_d.ptr, ctx->hist.ptr,
+                                 ctx->ldh(), 0, ctx->ldh(), ctx->p, ctx->Dacc.ptr, ctx->sacc.ptr, ctx->stream));
   ctx->hist_n = 0;
   return LSSPA_OK;
 } catch (...) {
@@ -1867,11 +1918,9 @@ int lsspa_error_running_draws(lsspa_ctx* ctx, int64_t n_total) try {
   return abi_caught(ctx);
 }
 
-// the shared tail of the two enqueue forms: one copy of [quantiles, mean, n] into the pinned slot, then its event
+// the shared tail of the two enqueue forms: the quantile kernel has written [quantiles, mean, n] into the pinned slot
+// itself; its event tells the host when
 static int finish_check(lsspa_ctx* ctx, int slot) {
-  const size_t p = ctx->p;
-  double* dst = ctx->res_h + (size_t)slot * (2 * p + 2);
-  HIPCHK(hipMemcpyAsync(dst, ctx->err_out.ptr, (2 * p + 2) * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipEventRecord(ctx->res_ev[slot], ctx->stream));
   ctx->res_valid[slot] = true;
   return LSSPA_OK;
@@ -1885,8 +1934,9 @@ int lsspa_error_quantiles_enqueue(lsspa_ctx* ctx, int32_t slot) try {
   const size_t p = ctx->p;
   {
     ProfScope ps(ctx, LSSPA_K_ERROR);
-    HIPCHK(launch_error_quantiles(ctx->draws.ptr, ctx->ldh(), (int)p, ctx->err_out.ptr + 2 * p + 2, ctx->err_out.ptr,
-                                  ctx->stream, ctx->mean.ptr, ctx->state_n.ptr));
+    HIPCHK(launch_error_quantiles(ctx->draws.ptr, ctx->ldh(), (int)p, ctx->err_out.ptr + 2 * p + 2,
+                                  ctx->res_hd + (size_t)slot * (2 * p + 2), ctx->stream, ctx->mean.ptr,
+                                  ctx->state_n.ptr));
   }
   return finish_check(ctx, slot);
 } catch (...) {
@@ -1906,8 +1956,8 @@ int lsspa_error_check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot) try
   {
     ProfScope ps(ctx, LSSPA_K_ERROR);
     HIPCHK(launch_error_quantiles_running(ctx->Dacc.ptr, ctx->sacc.ptr, ctx->mean.ptr, scale, ctx->ldh(), (int)p,
-                                          ctx->err_out.ptr + 2 * p + 2, ctx->err_out.ptr, ctx->state_n.ptr,
-                                          ctx->stream));
+                                          ctx->err_out.ptr + 2 * p + 2, ctx->res_hd + (size_t)slot * (2 * p + 2),
+                                          ctx->state_n.ptr, ctx->stream));
   }
   return finish_check(ctx, slot);
 } catch (...) {
@@ -1992,14 +2042,19 @@ int lsspa_group_collect(lsspa_ctx* ctx, int32_t ticket, int32_t n_chunks, const 
     return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   if (!ctx->run_on) return ctx->fail(LSSPA_ERR_STATE, "the running estimator is not enabled");
+  if (ctx->hist_n != 0) return ctx->fail(LSSPA_ERR_STATE, "collected samples not yet folded in: call lsspa_error_advance");
+  if (stride < 1) return ctx->fail(LSSPA_ERR_ARG, "stride must be positive");
+  for (int c = 0; c < n_chunks; ++c)
+    if (first_id[c] < 0 || n_after[c] < 0 || slot[c] < 0 || slot[c] >= lsspa_ctx::RES_SLOTS)
+      return ctx->fail(LSSPA_ERR_ARG, "sample ids and counts must be non-negative, slots within range");
   HIPCHK(hipSetDevice(ctx->device));
   // a communicator on the context (of one rank or of many): the moments and the draws go through it, as in the
   // separate calls; none: the chunk is folded and merged at once
   const bool several = ctx->comm != nullptr;
   for (int c = 0; c < n_chunks; ++c) {
     if (count[c] > 0) {
-      TRY(lift_collect(ctx, ctx->lanes[ticket], first[c], count[c], nullptr, several ? 1 : 2));
-      TRY(lsspa_error_advance(ctx, first_id[c], stride));
+      const int64_t ids[2] = {first_id[c], stride};
+      TRY(lift_collect(ctx, ctx->lanes[ticket], first[c], count[c], nullptr, several ? 1 : 2, ids));
     }
     if (several) {
       TRY(lsspa_stats_allreduce(ctx));

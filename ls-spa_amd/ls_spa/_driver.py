@@ -758,6 +758,9 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         if bits & 4:      # LSSPA_INFO_SCAN_WAIT: a hand-over inside a panel launch timed out
             raise LSSPANativeError("the fused lift scan gave up waiting for a row of its panel: the lift vectors of this "
                                    "run are not valid (engine fault; the lift kernel of its own is developer flag 512)")
+        if bits & 8 and not bits & 1:      # LSSPA_INFO_SUM (with a pivot that broke down the lifts are meaningless anyway)
+            raise LSSPANativeError("a sample's lifts did not sum to the R^2 of the full model (every ordering's must, "
+                                   "ls_spa/ls_spa.py:284-285): the lift vectors of this run are not valid (engine fault)")
         if bits & 1:
             warnings.warn("a permuted Gram matrix was not numerically positive definite; the attribution "
                           "of collinear features is not meaningful (the reference's is not either)",

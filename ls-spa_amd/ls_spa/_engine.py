@@ -255,6 +255,12 @@ class HipEngine:
         self._check(self._lib.lsspa_get_info_collected(self._h, C.byref(v)))
         return v.value
 
+    def sum_deviation(self) -> float:
+        """Largest |sum of a sample's lifts - R^2| of all batches since the last reset (0 before full_fit)."""
+        v = C.c_double()
+        self._check(self._lib.lsspa_get_sum_deviation(self._h, C.byref(v)))
+        return v.value
+
     def reset_stats(self):
         self._check(self._lib.lsspa_stats_reset(self._h))
 

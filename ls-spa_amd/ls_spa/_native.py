@@ -56,6 +56,7 @@ SIGNATURES = {
     "lsspa_set_lanes": (C.c_int, [_vp, _i32]),
     "lsspa_get_info": (C.c_int, [_vp, _pi32]),
     "lsspa_get_info_collected": (C.c_int, [_vp, _pi32]),
+    "lsspa_get_sum_deviation": (C.c_int, [_vp, _pd]),
     "lsspa_stats_reset": (C.c_int, [_vp]),
     "lsspa_stats_pending": (C.c_int, [_vp, C.POINTER(_vp), _pi64]),
     "lsspa_stats_merge": (C.c_int, [_vp]),

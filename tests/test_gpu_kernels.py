@@ -380,7 +380,10 @@ def test_a_hand_over_that_never_comes_times_out_and_is_reported():
     """The fused lift scan waits, inside a panel launch, for row p of its panel from another workgroup of the same
     launch.  That wait must end whatever happens: with the flags muted (developer flag 4096) every X tile of the first two
     launches runs into the time-out, the launches finish, LSSPA_INFO_SCAN_WAIT (4) is set -- and the engine is fine
-    afterwards."""
+    afterwards.  Round 5: the scan then went on with whatever z and y~ it found, and ONLY the time-out said so; a flag
+    that arrives with stale data would say nothing.  Every ordering's lifts sum to the full model's R^2
+    (ls_spa/ls_spa.py:284-285), and once lsspa_full_fit has computed it every batch is checked against it on the device:
+    LSSPA_INFO_SUM (8) catches the garbage on its own."""
     import time
     from ls_spa._engine import HipEngine
     p, n, m = 257, 900, 700
@@ -392,17 +395,45 @@ def test_a_hand_over_that_never_comes_times_out_and_is_reported():
         eng.load_data(Xa, Xe, ya, ye, 1e-3)
         good = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
         assert eng.info() == 0
+        assert eng.sum_deviation() == 0.0          # no R^2 known yet: nothing was checked
+        _, r2, _ = eng.full_fit()
+        eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        assert eng.info() == 0 and 0.0 < eng.sum_deviation() + 1e-300 < 1e-12
+        np.testing.assert_allclose(good.sum(1), r2, rtol=0, atol=1e-12)
         eng.set_flags(4096)
         t0 = time.perf_counter()
-        eng.run_batch(perms, True, want_lifts=True, accumulate=False)
+        bad = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
         waited = time.perf_counter() - t0
-        assert eng.info() & 4
+        bits = eng.info()
+        assert bits & 4 and bits & 8, bits
+        assert eng.sum_deviation() == pytest.approx(np.abs(bad.sum(1) - r2).max(), rel=1e-9)
         assert waited < 20.0
         eng.set_flags(0)
         eng.load_data(Xa, Xe, ya, ye, 1e-3)      # (loading a problem clears the info word)
         again = eng.run_batch(perms, True, want_lifts=True, accumulate=False)
         assert eng.info() == 0
         np.testing.assert_array_equal(again, good)
+        # the public call raises on either bit
+        from ls_spa import ls_spa
+        from ls_spa._native import LSSPANativeError
+
+        class Muted(HipEngine):
+            def reset_stats(self):
+                super().reset_stats()
+                self.set_flags(4096)
+        e2 = Muted(0)
+        try:
+            with pytest.raises(LSSPANativeError, match="gave up waiting|did not sum"):
+                ls_spa(Xa, Xe, ya, ye, reg=1e-3, perms=perms, batch_size=2, _engine=e2)
+        finally:
+            e2.close()
+        # ... and the small-problem kernels are under the same check (the check itself, on a healthy engine)
+        Xs, Xt, ys, yt = problem(5, 40, 300, 200)
+        eng.load_data(Xs, Xt, ys, yt, 0.0)
+        eng.full_fit()
+        eng.reset_stats()
+        eng.run_batch(np.array([rng.permutation(40) for _ in range(64)]), True, want_lifts=False, accumulate=2)
+        assert eng.info() == 0 and eng.sum_deviation() < 1e-12
     finally:
         eng.close()
 
