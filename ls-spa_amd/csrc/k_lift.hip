@@ -179,17 +179,28 @@ __global__ __launch_bounds__(256) void lift_finish_paired_kernel(LiftArgs a) {
 __global__ __launch_bounds__(256) void sum_check_kernel(const double* __restrict__ lifts, int n_samples, int p, double r2,
                                                         double tol, int32_t* __restrict__ info) {
   const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (s >= n_samples) return;
-  double v = 0.0;
-  for (int a = lane; a < p; a += 64) v += lifts[(int64_t)s * p + a];
+  double v = r2;                 // (a wave beyond the last sample contributes no deviation)
+  if (s < n_samples) {
+    v = 0.0;
+    for (int a = lane; a < p; a += 64) v += lifts[(int64_t)s * p + a];
+  } else {
+    v = (lane == 0) ? r2 : 0.0;
+  }
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-  if (lane == 0) {
-    double dev = fabs(v - r2);
-    if (!(dev <= tol)) atomicOr(info, 8);                  // LSSPA_INFO_SUM (also when the sum is not a number)
-    if (!(dev == dev)) dev = __longlong_as_double(0x7ff0000000000000ll);
+  __shared__ double s_dev[4];
+  double dev = fabs(v - r2);
+  if (!(dev == dev)) dev = __longlong_as_double(0x7ff0000000000000ll);   // not a number counts as infinitely far off
+  if (lane == 0) s_dev[threadIdx.x >> 6] = dev;
+  __syncthreads();
+  if (threadIdx.x == 0) {     // one atomic per workgroup, and none while the deviation is exactly zero
+    const int nw = min(4, n_samples - blockIdx.x * 4);
+    double worst = 0.0;
+    for (int k = 0; k < nw; ++k) worst = fmax(worst, s_dev[k]);
+    if (!(worst <= tol)) atomicOr(info, 8);                  // LSSPA_INFO_SUM
     // non-negative doubles order like their bit patterns
-    atomicMax(reinterpret_cast<unsigned long long*>(info + 2), (unsigned long long)__double_as_longlong(dev));
+    if (worst > 0.0)
+      atomicMax(reinterpret_cast<unsigned long long*>(info + 2), (unsigned long long)__double_as_longlong(worst));
   }
 }
 

@@ -131,6 +131,7 @@ struct lsspa_ctx {
   size_t res_h_count = 0;
   hipEvent_t res_ev[RES_SLOTS] = {nullptr};
   bool res_valid[RES_SLOTS] = {false};
+  int res_via[RES_SLOTS] = {0};       // the slot whose event covers this one (itself, or the last check of its group)
   int flags = 0;
   // collectives (RCCL), see comm.h
   Comm* comm = nullptr;
@@ -1920,13 +1921,23 @@ int lsspa_error_running_draws(lsspa_ctx* ctx, int64_t n_total) try {
 
 // the shared tail of the two enqueue forms: the quantile kernel has written [quantiles, mean, n] into the pinned slot
 // itself; its event tells the host when
-static int finish_check(lsspa_ctx* ctx, int slot) {
-  HIPCHK(hipEventRecord(ctx->res_ev[slot], ctx->stream));
+// record == false (lsspa_group_collect, all but the group's last check): the slot shares the event of a LATER check of
+// the same call -- a host that reads its checks group by group need not pay an event per check
+static int finish_check(lsspa_ctx* ctx, int slot, bool record = true) {
+  if (record) HIPCHK(hipEventRecord(ctx->res_ev[slot], ctx->stream));
   ctx->res_valid[slot] = true;
+  ctx->res_via[slot] = slot;
   return LSSPA_OK;
 }
 
+static int quantiles_enqueue(lsspa_ctx* ctx, int32_t slot, bool record);
 int lsspa_error_quantiles_enqueue(lsspa_ctx* ctx, int32_t slot) try {
+  return quantiles_enqueue(ctx, slot, true);
+} catch (...) {
+  return abi_caught(ctx);
+}
+
+static int quantiles_enqueue(lsspa_ctx* ctx, int32_t slot, bool record) {
   if (!ctx || slot < 0 || slot >= lsspa_ctx::RES_SLOTS) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   if (!ctx->run_on) return ctx->fail(LSSPA_ERR_STATE, "the running estimator is not enabled");
@@ -1938,12 +1949,17 @@ int lsspa_error_quantiles_enqueue(lsspa_ctx* ctx, int32_t slot) try {
                                   ctx->res_hd + (size_t)slot * (2 * p + 2), ctx->stream, ctx->mean.ptr,
                                   ctx->state_n.ptr));
   }
-  return finish_check(ctx, slot);
+  return finish_check(ctx, slot, record);
+}
+
+static int check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot, bool record);
+int lsspa_error_check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot) try {
+  return check_enqueue(ctx, n_total, slot, true);
 } catch (...) {
   return abi_caught(ctx);
 }
 
-int lsspa_error_check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot) try {
+static int check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot, bool record) {
   if (!ctx || n_total < 0 || slot < 0 || slot >= lsspa_ctx::RES_SLOTS) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   if (!ctx->run_on) return ctx->fail(LSSPA_ERR_STATE, "the running estimator is not enabled");
@@ -1959,9 +1975,7 @@ int lsspa_error_check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot) try
                                           ctx->err_out.ptr + 2 * p + 2, ctx->res_hd + (size_t)slot * (2 * p + 2),
                                           ctx->state_n.ptr, ctx->stream));
   }
-  return finish_check(ctx, slot);
-} catch (...) {
-  return abi_caught(ctx);
+  return finish_check(ctx, slot, record);
 }
 
 int lsspa_error_result(lsspa_ctx* ctx, int32_t slot, int32_t wait, int32_t* ready, double* feature_errors,
@@ -1969,10 +1983,11 @@ int lsspa_error_result(lsspa_ctx* ctx, int32_t slot, int32_t wait, int32_t* read
   if (!ctx || slot < 0 || slot >= lsspa_ctx::RES_SLOTS || !ready) return LSSPA_ERR_ARG;
   if (!ctx->run_on || !ctx->res_valid[slot]) return ctx->fail(LSSPA_ERR_STATE, "nothing was enqueued into this slot");
   HIPCHK(hipSetDevice(ctx->device));
+  const int via = ctx->res_via[slot];
   if (wait) {
-    HIPCHK(hipEventSynchronize(ctx->res_ev[slot]));
+    HIPCHK(hipEventSynchronize(ctx->res_ev[via]));
   } else {
-    const hipError_t e = hipEventQuery(ctx->res_ev[slot]);
+    const hipError_t e = hipEventQuery(ctx->res_ev[via]);
     if (e == hipErrorNotReady) {
       (void)hipGetLastError();
       *ready = 0;
@@ -2051,6 +2066,9 @@ int lsspa_group_collect(lsspa_ctx* ctx, int32_t ticket, int32_t n_chunks, const 
   // a communicator on the context (of one rank or of many): the moments and the draws go through it, as in the
   // separate calls; none: the chunk is folded and merged at once
   const bool several = ctx->comm != nullptr;
+  int last_check = -1;
+  for (int c = 0; c < n_chunks; ++c)
+    if (n_after[c] > 0) last_check = c;
   for (int c = 0; c < n_chunks; ++c) {
     if (count[c] > 0) {
       const int64_t ids[2] = {first_id[c], stride};
@@ -2061,15 +2079,19 @@ int lsspa_group_collect(lsspa_ctx* ctx, int32_t ticket, int32_t n_chunks, const 
       TRY(lsspa_stats_merge(ctx));
     }
     if (n_after[c] > 0) {
+      const bool record = (c == last_check);
       if (several) {
         TRY(lsspa_error_running_draws(ctx, n_after[c]));
         TRY(lsspa_error_allreduce(ctx));
-        TRY(lsspa_error_quantiles_enqueue(ctx, slot[c]));
+        TRY(quantiles_enqueue(ctx, slot[c], record));
       } else {
-        TRY(lsspa_error_check_enqueue(ctx, n_after[c], slot[c]));
+        TRY(check_enqueue(ctx, n_after[c], slot[c], record));
       }
     }
   }
+  // the earlier checks of the call are done when its last one is: they are read through that slot's event
+  for (int c = 0; c < n_chunks; ++c)
+    if (n_after[c] > 0) ctx->res_via[slot[c]] = slot[last_check];
   return LSSPA_OK;
 } catch (...) {
   return abi_caught(ctx);

@@ -250,6 +250,10 @@ def prepare_sampling(p, *, max_samples, batch_size, seed, perms, antithetical, m
         source = S.PermutohedronSource(p, seed, max_samples)
     else:
         raise ValueError(f"method must be one of {S.METHODS} or None")
+    if source.independent:
+        # the QMC samplers draw ahead of the loop on a helper thread (their stream is nobody else's), from now on --
+        # in ls_spa() that is under the data reduction
+        source = S.PrefetchedSource(source, block=1024 if p <= 126 else 256)
     return rng, source, batch_size, antithetical, max_samples, never_stop
 
 
@@ -275,9 +279,6 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
     rng, source, batch_size, antithetical, max_samples, never_stop = prepared
     if batch_size < 1:
         raise ValueError("batch_size must be positive")
-    if source.independent and not isinstance(source, S.PrefetchedSource):
-        # the QMC samplers draw ahead of the loop on a helper thread (their stream is nobody else's)
-        source = S.PrefetchedSource(source)
     try:
         return _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_samples, never_stop,
                               tolerance=tolerance, seed=seed, return_attribution_history=return_attribution_history,
@@ -707,6 +708,7 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         engine, kept = _acquire_engine(device)
     t0 = lap("engine_create", t0)
     ok = False
+    prepared = None
     try:
         if comm is not None and hasattr(comm, "bind"):
             comm.bind(engine)      # RCCL communicator on this engine's GPU and stream (collective)
@@ -779,6 +781,8 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         ok = True
     finally:
         t0 = _time.perf_counter()
+        if prepared is not None and hasattr(prepared[1], "close"):
+            prepared[1].close()      # the sampler's helper thread (already ended by a run that got as far as its loop)
         if owns:
             try:
                 if comm is not None and hasattr(comm, "close"):

@@ -109,6 +109,27 @@ class _BackgroundBuild:
         return self._value
 
 
+def _argsort_rows(a):
+    """np.argsort(a, axis=1); large blocks are cut into row ranges sorted on a few threads (the sort releases the
+    GIL) -- same result, row by row."""
+    n = len(a)
+    if a.size < (1 << 17) or n < 64:
+        return np.argsort(a, axis=1)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(4, (os.cpu_count() or 2) // 2, n // 32))
+    if workers == 1:
+        return np.argsort(a, axis=1)
+    out = np.empty(a.shape, dtype=np.intp)
+    cuts = np.linspace(0, n, workers + 1).astype(int)
+
+    def one(k):
+        out[cuts[k]:cuts[k + 1]] = np.argsort(a[cuts[k]:cuts[k + 1]], axis=1)
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(one, range(workers)))
+    return out
+
+
 class ArgsortSource(OrderingSource):
     independent = True
 
@@ -130,7 +151,7 @@ class ArgsortSource(OrderingSource):
         self._left -= n
         if n <= 0:
             return np.empty((0, self._p), dtype=np.int64)
-        return np.argsort(self._points(n), axis=1)
+        return _argsort_rows(self._points(n))
 
     def skip(self, count):
         n = int(min(count, self._left))
@@ -166,7 +187,7 @@ class PermutohedronSource(ArgsortSource):
             return np.empty((0, self._p), dtype=np.int64)
         pts = self._points(n)
         pts = pts / np.linalg.norm(pts, axis=1, keepdims=True)
-        return np.argsort(pts @ self._basis, axis=1)
+        return _argsort_rows(pts @ self._basis)
 
     def _fast_forward(self, n):
         # MultivariateNormalQMC has no fast_forward of its own: drawing n points advances the underlying
@@ -181,25 +202,35 @@ class PrefetchedSource(OrderingSource):
 
     SciPy's Sobol points and the row-wise argsort of a chunk take as long on the host as the chunk's kernels take on
     the GPU (p = 1000: 2.9 ms per 128 orderings against 6 ms; p = 100: 25 ms for the 8192 orderings the GPU evaluates
-    in 2.4 ms), and between them the driver's thread is inside GIL-free library calls.  The helper keeps up to
-    ``ahead`` orderings ready (in blocks of ``block``; ``argsort`` and SciPy's generators release the GIL for most
-    of their time), `take` hands out exactly what the inner source would have: same stream, same chunk boundaries
-    are irrelevant (a QMC sequence continues across calls, tests/test_host_logic.py::test_samplers_match_fixtures).
-    Only for sources whose stream nobody else reads (``independent``)."""
+    in 2.4 ms), and between them the driver's thread is inside GIL-free library calls.  The helper starts when the
+    source is made -- in ls_spa() that is before the data reduction -- and keeps up to ``ahead`` orderings ready, drawn
+    ``block`` at a time (SciPy's generators and ``argsort`` release the GIL for most of their time).  `take` hands out
+    exactly what the inner source would have: a QMC sequence continues across calls whatever their sizes
+    (tests/test_host_logic.py::test_samplers_match_fixtures).  Only for sources whose stream nobody else reads
+    (``independent``)."""
     independent = True
 
-    def __init__(self, inner, block=256, ahead=2048):
+    def __init__(self, inner, block=256, ahead=None):
         assert inner.independent
-        self._inner, self._block, self._ahead = inner, int(block), int(ahead)
+        p = max(1, int(getattr(inner, "_p", 1)))
+        if ahead is None:
+            ahead = max(2 * block, min(8192, (64 << 20) // (8 * p)))     # at most 64 MB of orderings waiting
+        self._inner, self._block, self._ahead, self._p = inner, int(block), int(ahead), p
         self._cv = threading.Condition()
         self._parts, self._ready = [], 0       # blocks drawn and not yet handed out
         self._done = self._stop = False
         self._error = None
-        self._thread = None
+        self._thread = threading.Thread(target=self._work, daemon=True)
+        self._thread.start()
 
     def skip(self, count):
-        assert self._thread is None, "skip before the first take"
-        self._inner.skip(count)
+        # the helper is already drawing: the orderings before a checkpoint's position are taken and dropped
+        left = int(count)
+        while left > 0:
+            got = len(self.take(min(left, 4096)))
+            if got == 0:
+                break
+            left -= got
 
     def _work(self):
         try:
@@ -225,13 +256,7 @@ class PrefetchedSource(OrderingSource):
                 self._cv.notify_all()
 
     def take(self, count):
-        count = int(count)
-        if self._thread is None:
-            self._block = max(self._block, min(count, 4096))
-            self._ahead = max(self._ahead, 2 * self._block)
-            self._thread = threading.Thread(target=self._work, daemon=True)
-            self._thread.start()
-        out, need = [], count
+        out, need = [], int(count)
         with self._cv:
             while need > 0:
                 while not self._parts and not self._done:
@@ -250,15 +275,14 @@ class PrefetchedSource(OrderingSource):
                 self._ready -= len(out[-1])
                 self._cv.notify_all()
         if not out:
-            return np.empty((0, getattr(self._inner, "_p", 0)), dtype=np.int64)
+            return np.empty((0, self._p), dtype=np.int64)
         return out[0] if len(out) == 1 else np.concatenate(out)
 
     def close(self):
         with self._cv:
             self._stop = True
             self._cv.notify_all()
-        if self._thread is not None:
-            self._thread.join(timeout=5)
+        self._thread.join(timeout=5)
 
 
 def exact_source(p):
