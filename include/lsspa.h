@@ -274,21 +274,20 @@ int lsspa_profile_enable(lsspa_ctx* ctx, int32_t on);
 int lsspa_profile_get(lsspa_ctx* ctx, int32_t kernel_class, double* total_ms, int64_t* launches);
 int lsspa_profile_reset(lsspa_ctx* ctx);
 
-/* developer switches for in-process A/B timing and cross-checks of kernel variants (0 = shipped configuration):
- *    64  plain (matrix, tile) dispatch order in the panel kernel
+/* developer switches: cross-checks of kernel variants against each other (0 = shipped configuration):
  *   128  tri mode: V by the strip kernel (the shipped path of rect mode) instead of V^T by the panel launches' X tiles
  *   512  tri mode: the lift kernel reads V^T back and scans it, instead of the X tiles scanning their own blocks
- *   256  unpaired gather                             1024  general path also for small problems (p + 1 <= 128
- *  2048  no skipping of the all-padding 16 x 16 tiles       normally takes the fused one-workgroup kernel)
+ *  1024  general path also for small problems (p + 1 <= 128 normally takes the fused one-workgroup kernel)
  *  4096  fault injection: the L tiles never raise the flag the fused lift scan waits for -- every X tile runs into the
- *        scan's time-out (~0.1 s a launch), LSSPA_INFO_SCAN_WAIT is set, nothing hangs (tests/test_gpu_kernels.py)
+ *        scan's time-out (~0.1 s a launch), LSSPA_INFO_SCAN_WAIT and LSSPA_INFO_SUM are set, nothing hangs
  * 16384  small problems: the LDS-resident kernel also where the register-resident one applies (p + 1 <= 112)
  * 65536  Gram kernel: workgroup id = unit (the units of a row slice spread over the XCDs instead of sharing one L2)
  * Every combination computes the same lifts (tests/test_gpu_kernels.py).  Environment, read once per process:
  * LSSPA_HANDOVER=k moves the point at which the second lane's next launch sequence may start to "after panel launch k"
- * (default: the middle one; a scan knob, tools/handover_scan.sh).  Rounds 1-3 carried more (one-level kernels,
- * whole-factorisation kernel, 256-column strips, two half-batches on two streams of one lane, page-locking of caller
- * memory): measured slower or superseded, removed in round 4. */
+ * (default: the middle one).  Retired in round 5 (each switched between two code paths that both stay in use and
+ * are pinned against the oracle by themselves): 64 plain dispatch order in the panel kernel (what a matrix count that
+ * is not a multiple of eight takes), 256 unpaired gather (what antithetical = 0 takes), 2048 no skipping of the
+ * all-padding tiles.  Earlier rounds carried more; DESIGN_HISTORY.md. */
 int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);
 
 /* test hooks */

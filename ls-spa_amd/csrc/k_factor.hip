@@ -350,29 +350,8 @@ __device__ __forceinline__ void full_mult_lower_half(typename Tr<T>::acc_t (&acc
 // LDS: s_t  64 x DI_LD  the block; its unused upper 16 x 16 blocks (jb, ib) hold Y[ib][jb], ib > jb
 //      s_x  4 x 16 x XD_LD  the diagonal sub-blocks of the inverse; then 16 pivots' 1/sqrt(d)
 // ---------------------------------------------------------------------------------------------
-#ifdef LSSPA_FACTOR_STAMPS
-__device__ long long g_stamps[32];
-#define FSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
-#else
-#define FSTAMP(i) do { } while (0)
-#endif
 // Phase stamps of the panel kernel (tools/panel_probe.hip; compiled out of the library): 100 MHz wall clock at the
 // phase boundaries of a few workgroups spread over the grid, [workgroup slot][phase].
-#ifdef LSSPA_PANEL_STAMPS
-#ifndef LSSPA_PST_SLOTS
-#define LSSPA_PST_SLOTS 64
-#endif
-constexpr int PST_SLOTS = LSSPA_PST_SLOTS, PST_PHASES = 16;
-__device__ long long g_pstamps[PST_SLOTS * PST_PHASES];
-#define PSTAMP(i)                                                                                   \
-  do {                                                                                              \
-    const unsigned pst_stride = gridDim.x / PST_SLOTS ? gridDim.x / PST_SLOTS : 1;                  \
-    if (threadIdx.x == 0 && blockIdx.x % pst_stride == 0 && blockIdx.x / pst_stride < PST_SLOTS)    \
-      g_pstamps[(blockIdx.x / pst_stride) * PST_PHASES + (i)] = wall_clock64();                     \
-  } while (0)
-#else
-#define PSTAMP(i) do { } while (0)
-#endif
 constexpr int XD_LD = 17;
 constexpr int FB_SX_ELEMS = 4 * 16 * XD_LD + 16;
 
@@ -472,11 +451,9 @@ __device__ __forceinline__ void factor_block64_put(const Block64Regs<T, NT>& b, 
 
 template <typename T, int NT>
 __device__ __forceinline__ void factor_block64_load(const T* __restrict__ M, int p_pad, int r0, T* s_t, int tid) {
-  FSTAMP(0);
   Block64Regs<T, NT> b;
   factor_block64_fetch<T, NT>(b, M, p_pad, r0, tid);
   factor_block64_put<T, NT>(b, s_t, tid);
-  FSTAMP(1);
 }
 
 // second half: factor the block held in s_t, store L to M and the inverse to Dg.  On return s_t still holds L
@@ -537,7 +514,6 @@ __device__ __forceinline__ void factor_block64_core(T* __restrict__ M, int p_pad
       }
     }
     __syncthreads();
-    FSTAMP(2 + 3 * kb);
     T* const inv = s_x + kb * 16 * XD_LD;
     // (2): 3 - kb panel tiles and kb inverse tiles: three tiles in all, one per wave
     if (w < 3) {
@@ -552,7 +528,6 @@ __device__ __forceinline__ void factor_block64_core(T* __restrict__ M, int p_pad
       }
     }
     __syncthreads();
-    FSTAMP(3 + 3 * kb);
   }
   // store L (lower) and its inverse (lower; off-diagonal blocks from the upper block positions), 16-byte vectors
   {
@@ -573,7 +548,6 @@ __device__ __forceinline__ void factor_block64_core(T* __restrict__ M, int p_pad
       *reinterpret_cast<vec_t*>(Dg + row * 64 + col) = xv;
     }
   }
-  FSTAMP(14);
   if (bad && lane == 0) atomicOr(&info[0], 1);
 }
 
@@ -608,9 +582,7 @@ __device__ __forceinline__ void factor_diag128(T* __restrict__ M, int p_pad, int
   Block64Regs<T, NT> a22;   // fetched now, needed after the first factorisation: its latency is off the critical path
   factor_block64_fetch<T, NT>(a22, M, p_pad, r0 + NB, tid);
   const double tol64_b = piv_tol * diag0[r0 + NB + (tid & 63)];   // the second block's pivot thresholds, likewise
-  FSTAMP(16);
   factor_block64<T, NT>(M, p_pad, r0, Dg, diag0, piv_tol, info, s_a, s_x, tid);
-  FSTAMP(17);
   // L21^T = L11^-1 A21^T, L11^-1 block (xp, x) read from the upper block (x, xp) of s_a / the diagonal blocks in s_x
 #pragma unroll
   for (int xp = 0; xp < 4; ++xp) {
@@ -624,14 +596,12 @@ __device__ __forceinline__ void factor_diag128(T* __restrict__ M, int p_pad, int
         o[xp] = Tr<T>::mfma(av, c[x][r], o[xp]);
       }
   }
-  FSTAMP(18);
   __syncthreads();   // L11^-1 has been read by everyone (and stored): the region now takes L21 in operand layout
 #pragma unroll
   for (int xp = 0; xp < 4; ++xp)
 #pragma unroll
     for (int r = 0; r < 4; ++r) s_a[(16 * w + l15) * DI_LD + 16 * xp + Tr<T>::acc_row(l4, r)] = o[xp][r];
   __syncthreads();
-  FSTAMP(19);
   // store L21 (contiguous 16-column row pieces in the chunk-major layout)
   {
     constexpr int VE = Tr<T>::VE, VPR = 64 / VE, NV = 4096 / VE;
@@ -658,10 +628,8 @@ __device__ __forceinline__ void factor_diag128(T* __restrict__ M, int p_pad, int
                            u[q]);
     }
   }
-  FSTAMP(20);
   __syncthreads();   // L21 has been read: the region takes A22
   factor_block64_put<T, NT>(a22, s_a, tid);
-  FSTAMP(21);
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     const int t = w + 4 * q;
@@ -673,9 +641,7 @@ __device__ __forceinline__ void factor_diag128(T* __restrict__ M, int p_pad, int
     }
   }
   __syncthreads();
-  FSTAMP(22);
   factor_block64_core<T, NT>(M, p_pad, r0 + NB, Dg + 4096, tol64_b, info, s_a, s_x, tid);
-  FSTAMP(23);
 }
 
 template <typename T>
@@ -715,10 +681,9 @@ struct TileLift {
   int mode;                // 0: no scan (the lift kernel reads V^T back); 1: scan; 2: scan, last panel's V^T not stored
 };
 
-// Timing-only builds (developer: LSSPA_CXXFLAGS=-DLSSPA_T_NOINIT python ls-spa_amd/build.py --force --out ...,
-// tools/variants_bench.sh): LSSPA_T_NOINIT / NOKLOOP / NOLOADS / NOMFMA / NOSOLVE / NOSTORE / NOUPDATE / NOFACTOR compile
-// ONE phase of the tile out and leave the launch structure, the dispatch and every other phase as they are.  The results
-// of such a build are garbage; what it shows is what the phase costs the step.
+// (Rounds 3-4 carried eight timing-only build variants of this function -- one phase compiled out each -- and wall-clock
+// stamps at its phase boundaries; the tables they produced are profiles/r04_phase_removal*.log and profiles/r04_probes.log,
+// the code is in the history at the end of round 4, DESIGN_HISTORY.md says where.)
 template <typename T, int NT, bool XLAST = false>
 __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restrict__ MJ, const T* __restrict__ Bt,
                                             T* __restrict__ Dm, const double* __restrict__ diag0,
@@ -746,7 +711,6 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
   const int l15 = lane & 15, l4 = lane >> 4;
   const int J0 = Jo * 128;
   const int I0 = xt ? tile * 128 : J0 + 128 + tile * 128;
-  PSTAMP(0);
   // Rows of a wave.  The tile's eight 16-row sub-tiles are dealt to the four waves as {w, 7 - w}: wave w owns rows
   // rb[0] = 16 w .. and rb[1] = 16 (7 - w) .. (any assignment would do: rows are independent of each other from the
   // tile's start to its store).  The pairing matters for the X tiles' first k-block, below.
@@ -799,12 +763,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
 
   // acc[x][y][r] <-> (panel column j = 16 x + acc_row(l4, r), tile row i = RW w + 16 y + l15); holds -C^T.
   acc_t acc[8][YT];
-#ifdef LSSPA_T_NOINIT
-  constexpr bool T_INIT = false;
-  for (int x = 0; x < 8; ++x) for (int y = 0; y < YT; ++y) acc[x][y] = Tr<T>::zero();
-#else
   constexpr bool T_INIT = true;
-#endif
   if (xt && T_INIT) {
     // -B[i][j] = -L_t[J0 + j][I0 + i]: sixteen lanes read sixteen consecutive columns of one row of L_t (one 128-byte
     // piece of a chunk): accumulator layout as it stands.  On the diagonal tile (I0 == J0) the entries above L_t's
@@ -858,21 +817,12 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
     }
   }
 
-  PSTAMP(1);
-#ifdef LSSPA_T_NOKLOOP
-  for (int it = 0, c = c_first; it < 0; ++it, c += c_step) {
-#else
   for (int it = 0, c = c_first; it < nch; ++it, c += c_step) {
-#endif
     __syncthreads();
     rk_store<T, 128, NT>(rj, s_rkj, tid);
     rk_store<T, 128, NT>(ri, s_rki, tid);
     __syncthreads();
-#ifdef LSSPA_T_NOLOADS
-    if (false) {
-#else
     if (it + 1 < nch) {
-#endif
       rk_load_full<T, 128, NT>(rj, srcJ + (c + c_step) * chunk, CM_LD, tid);
       rk_load_full_nt<T, 128, NT>(ri, srcI + (c + c_step) * chunk, CM_LD, tid);
     }
@@ -888,17 +838,12 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
         if (c >= cstart[y]) {
 #pragma unroll
           for (int x = 0; x < 8; ++x)
-#ifdef LSSPA_T_NOMFMA
-            if (!XLAST || x < xlive) acc[x][y][0] += av[x] * bv[y];
-#else
             if (!XLAST || x < xlive) acc[x][y] = Tr<T>::mfma(av[x], bv[y], acc[x][y]);
-#endif
         }
     }
   }
 
 
-  PSTAMP(2);
   // the wave's row bases once more, from a copy of the wave index the compiler cannot see through: otherwise the store
   // loop's LDS addresses are computed ahead of the k-loop and carried -- spilled -- through it
   int ws_e = ws;
@@ -946,16 +891,13 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
   // Each 64 x 64 operand block of the solve is fetched into registers one stage ahead and put into LDS when
   // the previous stage is done with the region.
   const T* Dg = Dm + (int64_t)(2 * Jo) * 4096;
-#ifndef LSSPA_T_NOSOLVE
   DenseBlock64Regs<T, NT> nb;
   block64_fetch<T, NT>(nb, Dg, tid);
   __syncthreads();  // every wave is done with the operand tiles that region A now loses
   block64_put<T, NT>(nb, s_dinv, tid);
   __syncthreads();
-  PSTAMP(12);
   block64_fetch_cm<T, NT>(nb, MJ, p_pad, J0 + NB, J0, tid);
   tri_mult(0);
-  PSTAMP(13);
   __syncthreads();
   block64_put<T, NT>(nb, s_dinv, tid);
   __syncthreads();
@@ -974,18 +916,21 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
       }
     __builtin_amdgcn_sched_barrier(0);
   }
-  PSTAMP(14);
   if (scan) {
     // the flag is polled, and the three vectors are fetched into registers, in front of the solve's last stage: its
     // matrix instructions hide the two memory round trips (the flag has been up for a long time by now: the training
     // matrices' L tiles are the first half of the grid's L tiles, the X tiles come after all of them)
     if (!XLAST && J0 + 128 < p_pad) {      // (the last launch has no L tiles: its row p came out of the launch before)
       if (tid == 0) {
-        int spins = 0;
+        // The wait ends by the CLOCK, not by a spin count (round 5): half a second of the 100 MHz wall clock -- the
+        // longest tile this engine can run (p = 32767: 256 row blocks of eight chunks) takes about ten milliseconds, and
+        // the row comes from a workgroup that was dispatched before this one.  A flag that has not come by then never
+        // will: LSSPA_INFO_SCAN_WAIT, and the batch's own sum check (LSSPA_INFO_SUM) sees what the scan then made of it.
+        const long long give_up = (long long)wall_clock64() + 50000000ll;
         while (__hip_atomic_load(tl.fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= Jo ||
                (I0 == J0 && __hip_atomic_load(tl.fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= Jo)) {
           __builtin_amdgcn_s_sleep(32);
-          if (++spins > (1 << 16)) {
+          if ((long long)wall_clock64() > give_up) {
             atomicOr(&info[0], 4);
             break;
           }
@@ -993,7 +938,6 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
       }
     }
   }
-  PSTAMP(15);
   __syncthreads();
   block64_put<T, NT>(nb, s_dinv, tid);
   __syncthreads();
@@ -1011,41 +955,6 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
     d_run = 2.0 * (yt_c - run_c);
   }
   tri_mult(1);
-#else
-  (void)Dg; (void)tri_mult;
-  if (scan) {
-    // the flag is polled, and the three vectors are fetched into registers, in front of the solve's last stage: its
-    // matrix instructions hide the two memory round trips (the flag has been up for a long time by now: the training
-    // matrices' L tiles are the first half of the grid's L tiles, the X tiles come after all of them)
-    if (!XLAST && J0 + 128 < p_pad) {      // (the last launch has no L tiles: its row p came out of the launch before)
-      if (tid == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(tl.fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= Jo ||
-               (I0 == J0 && __hip_atomic_load(tl.fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= Jo)) {
-          __builtin_amdgcn_s_sleep(32);
-          if (++spins > (1 << 16)) {
-            atomicOr(&info[0], 4);
-            break;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (scan) {
-    const int p = tl.p;
-    if (tid < 128) {
-      const int j = J0 + tid;
-      z_mine = (j < p) ? (double)__hip_atomic_load(MJ + cm_off(p_pad, p, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                       : 0.0;
-    }
-    const int c = I0 + rb_e[sy] + si;
-    yt_c = (c < p) ? (double)__hip_atomic_load(Bt + cm_off(p_pad, p, c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                   : 0.0;
-    run_c = (I0 == J0) ? 0.0 : tl.run[c];
-    d_run = 2.0 * (yt_c - run_c);
-  }
-#endif
 
   // Store L[I, panel] through the output buffer, one 16-column chunk at a time (a contiguous 128 x 16
   // block in the chunk-major layout).  (Round 4, measured and not kept: the accumulators stored straight to memory --
@@ -1070,23 +979,13 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
   // depend on nothing, and they raise a flag when their tile is stored; the X tile polls it in front of its solve's last
   // stage (above), i.e. in practice it never waits: tools/xtile_probe.hip stamps 0.04-2.2 us there, the poll's own round
   // trip (a wait that outlasts ~60 ms sets LSSPA_INFO_SCAN_WAIT and goes on: no hang).  The last launch needs no flag.
-  PSTAMP(3);
   if (scan) {
     __syncthreads();      // every wave is done with the solve's blocks in region A
     if (tid < 128) s_z[tid] = z_mine;
     __syncthreads();
   }
-#ifdef LSSPA_T_NOSTORE
-  {
-    T sum = (T)0;
-    for (int x = 0; x < 8; ++x) for (int y = 0; y < YT; ++y) for (int r = 0; r < 4; ++r) sum += acc[x][y][r];
-    if (sum == (T)1.2345e-67) M[cm_off(p_pad, I0, J0)] = sum;
-  }
-  for (int xp = 0; xp < 0; ++xp) {
-#else
 #pragma unroll
   for (int xp = 0; xp < 8; ++xp) {
-#endif
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int y = 0; y < YT; ++y)
@@ -1175,7 +1074,6 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
     if (tid == 0) __hip_atomic_store(tl.raise, Jo + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 
-  PSTAMP(4);
   // A[I,I] -= L[I,0:J0+128) L[I,0:J0+128)^T on the diagonal block that tile 0 owns and factors next: 36 lower
   // 16 x 16 tiles over the waves.  The accumulators of the solve are dead by now; the eight chunks just written are
   // staged once more (they come back from L2) instead of keeping both sets of accumulators alive through the
@@ -1213,7 +1111,6 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
     const int ndc = nch + 8;
     RKRegs<T, 128, NT> rp = {};
     __syncthreads();   // all stores above are issued and fenced
-    PSTAMP(8);
     auto products = [&](const T* buf) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -1234,13 +1131,9 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
       __syncthreads();
       rk_store<T, 128, NT>(rp, s_out, tid);
       __syncthreads();
-      if (c == 0) PSTAMP(9);
-      if (c == 1) PSTAMP(10);
-      if (c == 2) PSTAMP(11);
       if (c + 1 < ndc) rk_load_full_nt<T, 128, NT>(rp, srcP + (c + 1) * chunk, CM_LD, tid);
       products(s_out);
     }
-    PSTAMP(5);
     // the block's addresses are formed again here, from a copy of p_pad the compiler cannot see through: kept from the
     // initial loads above they are carried (five of them spilled) through the loop
     int pp_e = p_pad;
@@ -1256,11 +1149,7 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
       }
     }
   };
-#ifdef LSSPA_T_NOUPDATE
-  if (false)
-#else
   if (tile == 0 && !xt)
-#endif
   switch (ws) {     // scalar: the wave index
     case 0: diag_update(std::integral_constant<int, 0>()); break;
     case 1: diag_update(std::integral_constant<int, 1>()); break;
@@ -1271,21 +1160,15 @@ __device__ __forceinline__ void panel2_tile(T* __restrict__ M, const T* __restri
     case 6: if constexpr (NW > 4) diag_update(std::integral_constant<int, 6>()); break;
     default: if constexpr (NW > 4) diag_update(std::integral_constant<int, 7>()); break;
   }
-  PSTAMP(6);
 
 
   // Tile 0 is the next panel's diagonal block and has just received its last update: factor it here,
   // the latency-bound sweep overlaps with the other workgroups' MFMA work.
-#ifdef LSSPA_T_NOFACTOR
-  if (false) {
-#else
   if (tile == 0 && !xt) {
-#endif
     __threadfence_block();
     __syncthreads();
     factor_diag128<T, NT>(M, p_pad, I0, Dm + (int64_t)(2 * (Jo + 1)) * 4096, diag0, piv_tol, info, s_a, s_b, tid);
   }
-  PSTAMP(7);
 }
 
 // Workgroup of NT threads (NT / 64 waves): wave w owns tile rows RW w .. RW w + RW - 1 (RW = 128 / waves)
@@ -1398,7 +1281,7 @@ hipError_t launch_chol2_diag(void* A, void* Dinv, const double* diag0, double pi
 hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double piv_tol, int32_t* info, int p_pad,
                               int Jo, int n_mats, int f32, hipStream_t st, int flags, int p_live, void* X,
                               int n_ord, const PanelLift* pl) {
-  if (p_live <= 0 || p_live > p_pad || (flags & 2048)) p_live = p_pad;   // flag 2048: no padding-tile skipping
+  if (p_live <= 0 || p_live > p_pad) p_live = p_pad;
   const int n_panel = p_pad / 128 - 1;
   // with X tiles (X != null) the matrices are [n_ord training][n_ord test] and there is one more launch, Jo = n_panel
   if (p_pad % 128 != 0 || Jo < 0 || n_mats < 1 || Jo > n_panel || (Jo == n_panel && !X)) return hipErrorInvalidValue;
@@ -1437,7 +1320,7 @@ hipError_t launch_chol2_panel(void* A, void* Dinv, const double* diag0, double p
   a.mute = (flags & 4096) ? 1 : 0;
   const int64_t total = (int64_t)n_mats * a.n_lt + (int64_t)a.n_ord * a.n_x;
   if (total < 1 || total > 0x7fffffff) return hipErrorInvalidValue;
-  a.grouped = (n_mats % 8 == 0 && a.n_lt > 1 && !(flags & 64)) ? 1 : 0;
+  a.grouped = (n_mats % 8 == 0 && a.n_lt > 1) ? 1 : 0;
   const dim3 grid((unsigned)total);
   // 256 threads: 512-thread workgroups (16 rows per wave, twice the waves per SIMD) were measured
   // slower in both precisions -- the epilogue is bound by its memory traffic, not by latency
@@ -1685,8 +1568,8 @@ __global__ __launch_bounds__(NT, OCC) void strip2_kernel(StripArgs a) {
 
 hipError_t launch_strip(const StripArgs& a_in, hipStream_t st) {
   StripArgs a = a_in;
-  if (a.row_live <= 0 || a.row_live > a.p_pad || (a.flags & 2048)) a.row_live = a.p_pad;
-  if (a.col_live <= 0 || a.col_live > a.m_pad || (a.flags & 2048)) a.col_live = a.m_pad;
+  if (a.row_live <= 0 || a.row_live > a.p_pad) a.row_live = a.p_pad;
+  if (a.col_live <= 0 || a.col_live > a.m_pad) a.col_live = a.m_pad;
   if (a.p < 1 || a.p_pad % NB != 0 || a.m_pad % 128 != 0 || a.n_ord < 1) return hipErrorInvalidValue;
   if (a.tri && a.m_pad > a.p_pad + 127) return hipErrorInvalidValue;
   if (a.tri ? (a.rhs == nullptr) : (a.perms == nullptr || a.Ft == nullptr)) return hipErrorInvalidValue;

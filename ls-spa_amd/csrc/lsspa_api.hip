@@ -424,9 +424,12 @@ size_t bytes_per_ordering(const lsspa_ctx* ctx) {
   const size_t pp = ctx->p_pad, nblk = pp / NB;
   const size_t nm = ctx->tri ? 2 : 1;
   const size_t es = ctx->esz();
+  // work matrices, V / V^T, inverse diagonal blocks, initial diagonals, partial sums, lift vector; the fused scan's
+  // running sums and row flags; the two device copies of the ordering
   return nm * pp * pp * es + v_elems_per_ordering(ctx) * es +
          nm * nblk * 4096 * es + nm * pp * 8 +
-         (size_t)(ctx->m_pad / 64) * pp * 8 + (size_t)ctx->p * 8;
+         (size_t)(ctx->m_pad / 64) * pp * 8 + (size_t)ctx->p * 8 +
+         pp * 8 + 2 * sizeof(int32_t) + 2 * (size_t)ctx->p * sizeof(int32_t);
 }
 
 int ensure_workspace(lsspa_ctx* ctx, Lane& L, int want_ord, int want_samples) {
@@ -574,7 +577,7 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
     ga.A = A_s;
     ga.diag0 = diag0_s;
     ga.f32 = ctx->f32;
-    ga.paired = (per_sample == 2 && !(ctx->flags & 256)) ? 1 : 0;   // stage_and_run lays pairs out back to back
+    ga.paired = (per_sample == 2) ? 1 : 0;   // stage_and_run lays pairs out back to back
     HIPCHK(launch_gather(ga, st));
   }
   // a pivot below ~p ulps of its feature's own variance is numerically zero (collinear feature)

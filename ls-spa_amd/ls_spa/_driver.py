@@ -44,6 +44,7 @@ _NO_CAP = 2 ** 100
 # device) is not shared: that call makes its own.  The reference keeps no state between calls either way: every
 # call resets the statistics, the history and the flags it touches.
 _engine_cache = {}
+_engine_cache_lock = __import__("threading").Lock()     # guards the table itself (two threads, one new device)
 
 
 def _acquire_engine(device):
@@ -52,12 +53,13 @@ def _acquire_engine(device):
     from ._engine import HipEngine
     if os.environ.get("LSSPA_ENGINE_CACHE", "1") == "0":
         return HipEngine(device), None
-    slot = _engine_cache.get(device)
-    if slot is None:
-        if not _engine_cache:
-            import atexit
-            atexit.register(release)
-        slot = _engine_cache[device] = {"engine": None, "lock": threading.Lock()}
+    with _engine_cache_lock:
+        slot = _engine_cache.get(device)
+        if slot is None:
+            if not _engine_cache:
+                import atexit
+                atexit.register(release)
+            slot = _engine_cache[device] = {"engine": None, "lock": threading.Lock()}
     if not slot["lock"].acquire(blocking=False):
         return HipEngine(device), None
     try:
@@ -71,7 +73,9 @@ def _acquire_engine(device):
 
 def release(device=None):
     """Close the engines ls_spa() keeps between calls (all of them, or one device's): frees their HBM."""
-    for dev, slot in list(_engine_cache.items()):
+    with _engine_cache_lock:
+        slots = list(_engine_cache.items())
+    for dev, slot in slots:
         if device is not None and dev != device:
             continue
         if slot["lock"].acquire(blocking=False):
@@ -632,7 +636,10 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
     """Estimates the Shapley attribution of the out-of-sample R^2 of a least-squares fit.
 
     Positional parameters, defaults and behaviour follow cvxgrp/ls-spa
-    (``ls_spa/ls_spa.py:122-253``).  Keyword-only additions:
+    (``ls_spa/ls_spa.py:122-253``).  One difference in what stays behind: the engine of the device -- its context, stream
+    and per-batch workspace in HBM (gigabytes for large p) -- is kept alive between calls of a process, so that the
+    next call of the same shape starts at once; ``ls_spa.release()`` (or ``release(device)``) frees it, and
+    ``LSSPA_ENGINE_CACHE=0`` in the environment makes every call create and free its own.  Keyword-only additions:
 
     method:  None (reference behaviour), 'exact', 'random', 'argsort' or 'permutohedron'.
     num_batches:  if given, ``max_samples = batch_size * num_batches`` (README dialect).
@@ -750,19 +757,37 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         t0 = _time.perf_counter()
         theta, r_squared, info = engine.full_fit()
         t0 = lap("final_fit", t0)
-        attribution, feat_err, total_err, err_hist, history, _ = run_estimator(
-            engine, p, max_samples=max_samples, batch_size=batch_size, tolerance=tolerance, seed=seed,
-            perms=perms, antithetical=antithetical, return_attribution_history=return_attribution_history,
-            method=method, error_estimator=error_estimator, comm=comm, checkpoint=checkpoint, prepared=prepared,
-            lookahead=lookahead, timings=tm, defer=_defer)
+        def sampling_run(prep):
+            out = run_estimator(
+                engine, p, max_samples=max_samples, batch_size=batch_size, tolerance=tolerance, seed=seed,
+                perms=perms, antithetical=antithetical, return_attribution_history=return_attribution_history,
+                method=method, error_estimator=error_estimator, comm=comm, checkpoint=checkpoint, prepared=prep,
+                lookahead=lookahead, timings=tm, defer=_defer)
+            return out, info | (engine.info_collected() if hasattr(engine, "info_collected") else engine.info())
+
+        (attribution, feat_err, total_err, err_hist, history, _), bits = sampling_run(prepared)
         t0 = _time.perf_counter()
-        bits = info | (engine.info_collected() if hasattr(engine, "info_collected") else engine.info())
-        if bits & 4:      # LSSPA_INFO_SCAN_WAIT: a hand-over inside a panel launch timed out
-            raise LSSPANativeError("the fused lift scan gave up waiting for a row of its panel: the lift vectors of this "
-                                   "run are not valid (engine fault; the lift kernel of its own is developer flag 512)")
-        if bits & 8 and not bits & 1:      # LSSPA_INFO_SUM (with a pivot that broke down the lifts are meaningless anyway)
-            raise LSSPANativeError("a sample's lifts did not sum to the R^2 of the full model (every ordering's must, "
-                                   "ls_spa/ls_spa.py:284-285): the lift vectors of this run are not valid (engine fault)")
+        # LSSPA_INFO_SCAN_WAIT (4): a hand-over inside a panel launch timed out; LSSPA_INFO_SUM (8): a sample's lifts did
+        # not sum to the R^2 of the full model (every ordering's must, ls_spa/ls_spa.py:284-285).  Either way the lift
+        # vectors of the run are not valid (with a pivot that broke down, bit 1, they are meaningless anyway).
+        fault = bool(bits & 12) and not bits & 1
+        if fault and perms is None and checkpoint is None and hasattr(engine, "set_flags"):
+            # An ordering source that can be drawn again (seed or QMC method; not the caller's iterable): the run is
+            # repeated ONCE on the conservative path -- the lift kernel of its own reads V^T back, nothing is handed over
+            # inside a launch (developer flag 512) -- instead of being lost.
+            warnings.warn(f"engine fault in the fused lift scan (info bits {bits}): the run is repeated with the lift "
+                          "kernel of its own", RuntimeWarning, stacklevel=2)
+            engine.set_flags(512)
+            prepared[1].close() if hasattr(prepared[1], "close") else None
+            prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
+                                        antithetical=antithetical, method=method)
+            (attribution, feat_err, total_err, err_hist, history, _), bits = sampling_run(prepared)
+            fault = bool(bits & 12) and not bits & 1
+        if fault:
+            raise LSSPANativeError(
+                ("the fused lift scan gave up waiting for a row of its panel" if bits & 4 else
+                 "a sample's lifts did not sum to the R^2 of the full model")
+                + f" (info bits {bits}): the lift vectors of this run are not valid (engine fault)")
         if bits & 1:
             warnings.warn("a permuted Gram matrix was not numerically positive definite; the attribution "
                           "of collinear features is not meaningful (the reference's is not either)",

@@ -706,6 +706,21 @@ def test_feature_count_beyond_the_lds_of_a_cu():
         got = eng.run_batch(perm[None, :].astype(np.int32), False, want_lifts=True, accumulate=False)[0]
         theta, r2, info = eng.full_fit()
         assert info == 0 and eng.info() == 0
+        # the antithetical pair above the old ceiling, in both precisions (round 5: the segmented gather writes each
+        # ordering of a pair by itself while the lift finish reads them as a pair): the pair's lift vector is the mean of
+        # the ordering's and its reverse's, each evaluated alone; with the R^2 known, every batch is also sum-checked
+        rev = eng.run_batch(np.ascontiguousarray(perm[None, ::-1]).astype(np.int32), False, want_lifts=True,
+                            accumulate=False)[0]
+        pair = eng.run_batch(perm[None, :].astype(np.int32), True, want_lifts=True, accumulate=False)[0]
+        np.testing.assert_allclose(pair, 0.5 * (got + rev), rtol=0, atol=2e-6)
+        eng.set_precision("float64")
+        f64_f = eng.run_batch(perm[None, :].astype(np.int32), False, want_lifts=True, accumulate=False)[0]
+        f64_r = eng.run_batch(np.ascontiguousarray(perm[None, ::-1]).astype(np.int32), False, want_lifts=True,
+                              accumulate=False)[0]
+        f64_p = eng.run_batch(perm[None, :].astype(np.int32), True, want_lifts=True, accumulate=False)[0]
+        np.testing.assert_allclose(f64_p, 0.5 * (f64_f + f64_r), rtol=0, atol=1e-13)
+        np.testing.assert_allclose(f64_f, got, rtol=0, atol=1e-4)
+        assert eng.info() == 0 and eng.sum_deviation() < 1e-4
         G, g, H, h = eng.gram()           # the fp64 Gram reduction (pinned against numpy elsewhere) is the oracle's input
         yy = eng.y_norm_sq
     finally:
