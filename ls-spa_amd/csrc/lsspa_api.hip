@@ -90,6 +90,7 @@ struct lsspa_ctx {
   double aug_train = 0.0, y_norm_sq = 0.0;
   double r2 = 0.0;               // R^2 of the full model (lsspa_full_fit): what every lift vector must sum to
   bool r2_valid = false;
+  bool r2_f32 = false;           // ... computed while the per-ordering work was fp32 (good to 1e-4, not 1e-9)
   DevBuf<double> G, g, H, h, Ft, ytil, scal;
   DevBuf<float> Gf, Hf;        // fp32 copies of G / H for the fp32 gather, made on first use
   bool src_f32_valid = false;
@@ -698,7 +699,7 @@ int run_orderings(lsspa_ctx* ctx, Lane& L, int n_ord, int per_sample, int s_off)
   TRY(run_slice(ctx, L, 0, n_ord, per_sample, s_off, st));
   // the batch's own end-to-end check, once the full model's R^2 is known (lsspa_full_fit): every lift vector sums to it
   if (ctx->r2_valid && !ctx->general_path_once) {
-    const double tol = (ctx->f32 ? 1e-4 : 1e-9) * std::max(1.0, std::fabs(ctx->r2));
+    const double tol = ((ctx->f32 || ctx->r2_f32) ? 1e-4 : 1e-9) * std::max(1.0, std::fabs(ctx->r2));
     HIPCHK(launch_sum_check(L.lifts.ptr + (size_t)s_off * ctx->p, n_ord / per_sample, ctx->p, ctx->r2, tol,
                             ctx->info_d.ptr, st));
   }
@@ -1498,6 +1499,7 @@ int lsspa_full_fit(lsspa_ctx* ctx, double* theta, double* r_squared, int32_t* in
     // from now on every batch is checked against it (run_orderings); not after a factorisation that broke down
     ctx->r2 = s;
     ctx->r2_valid = (now == 0) && std::isfinite(s);
+    ctx->r2_f32 = ctx->f32 != 0;
   }
   return LSSPA_OK;
 } catch (...) {
