@@ -163,9 +163,7 @@ __device__ __forceinline__ void zstore(const ZRegs<T>& r, double* lds, int tid) 
 
 // What a launch is cut into (host and device agree on it through this struct).  Units come in three classes -- A:
 // off-diagonal pairs of full tiles (16 blocks a wave and k-step), B: pairs whose tile i is the ragged last tile
-// (2 xlive blocks), C: duos (18) -- each with its own slice count.  The counts are EQUAL: measured at p = 1000 and
-// p = 5000, a workgroup's time follows the rows it stages (two 128-column tiles per 16-row chunk, whatever the
-// class), not its MFMA count -- slices in proportion to the block counts (16 : 14 : 18) were no faster (round 3).
+// (2 xlive blocks), C: duos (18) -- each with its own slice count (gram_plan: 16 : 18 : 20 from six tiles on).
 struct GramPlan {
   int nt;                 // 128-column tiles of Z = [X | y]
   int xlive;              // live 16-column blocks of the last tile
@@ -517,7 +515,16 @@ static GramPlan gram_plan(int64_t n, int p, int n_split, int variant = 0) {
   g.cnt[1] = ragged ? g.nt - 1 : 0;
   g.cnt[0] = g.nt * (g.nt - 1) / 2 - g.cnt[1];
   g.cnt[2] = (g.nt + 1) / 2;
-  const int cost[3] = {16, 16, 16};   // relative time per row of the classes (see GramPlan)
+  // Relative time per row of the classes.  Round 3 measured "equal" and kept 16 : 16 : 16; round 5 measured again, after
+  // the ragged tile's loads had been fixed: a launch waits for its slowest workgroups, and from six tiles on those are
+  // the duos (18 matrix instructions a wave and k-step against a pair's 16, two of them on a CU when the class sits
+  // together) and, less so, the ragged pairs.  With 16 : 18 : 20 -- the slower classes cut into proportionally more,
+  // shorter slices -- p = 1000: 1.91-1.97 -> 1.70-1.80 ms a side, p = 1500 (60 k rows): 2.52-2.58 -> 2.27-2.42,
+  // p = 2000: 6.5-7.6 -> 6.3-6.6, p = 3000 / 5000: unchanged; below six tiles (p = 500: 0.54 -> 0.67 ms) the few units
+  // fill the chip's slots better undivided.  (Handing the work items out by first row, or the slow classes spread
+  // among the fast ones, instead of class by class: 1.80 / 1.86 against 1.72-1.75 -- measured, not kept.)
+  const bool split_slow = g.nt >= 6;
+  const int cost[3] = {16, split_slow ? 18 : 16, split_slow ? 20 : 16};
   (void)variant;
   // with no class-A unit at all (one or two tiles) the knob applies to the classes that exist, undivided
   const int64_t max_s = std::max<int64_t>(1, (n + 15) / 16);
@@ -534,8 +541,8 @@ static GramPlan gram_plan(int64_t n, int p, int n_split, int variant = 0) {
 }
 
 size_t gram_workspace_bytes(int p, int n_split) {
-  // the largest per-class slice count is that of the duos: ceil(18 / 16 n_split)
-  const size_t s_max = (size_t)(((int64_t)n_split * 18 + 8) / 16) + 1;
+  // the largest per-class slice count is that of the duos: round(20 / 16 n_split)
+  const size_t s_max = (size_t)(((int64_t)n_split * 20 + 8) / 16) + 1;
   return (size_t)n_pairs_of(p) * std::max<size_t>(s_max, (size_t)n_split) * 128 * 128 * sizeof(double);
 }
 
