@@ -165,7 +165,8 @@ int lsspa_stats_set(lsspa_ctx* ctx, int64_t n, const double* mean, const double*
  * 1024 draws x = Xi (L - 1 mean^T) / sqrt(n (n - 1)) with L the [n][p] lift vectors of all samples so far, which
  * has the covariance C_unbiased / n the reference samples from, without any p x p factorisation.
  *   lsspa_history_enable : keep every accumulated sample's lift vector in HBM (capacity = rows allocated up front,
- *                          grown geometrically when exceeded; 0 switches the history off and frees it).
+ *                          grown geometrically when exceeded; 0 switches the history -- and the running form below -- off
+ *                          and gives a history of more than 64 MB back; smaller buffers stay for the next call).
  *                          lsspa_stats_reset / lsspa_reduce / lsspa_set_reduced empty the history.
  *   lsspa_history_get    : copy it out ([count][p], host); lifts may be NULL to query the count
  *   lsspa_history_append : push rows back in (resume)

@@ -1741,9 +1741,9 @@ int lsspa_history_enable(lsspa_ctx* ctx, int64_t capacity) try {
   ctx->hist_cap = 0;
   ctx->run_on = false;
   if (capacity == 0) {
-    dev_free(ctx->hist);
-    dev_free(ctx->Dacc);
-    dev_free(ctx->sacc);
+    // switched off; small buffers stay (a kept engine's next call of the same shape finds them in place -- three hipFree
+    // calls, each a device synchronisation, were 1.2 ms of a 46 ms call); a long history is given back
+    if (ctx->hist.count * sizeof(double) > ((size_t)64 << 20)) dev_free(ctx->hist);
     return LSSPA_OK;
   }
   const int64_t rows = ((capacity + KCH - 1) / KCH) * KCH;   // the draws kernel reads whole 16-row chunks
