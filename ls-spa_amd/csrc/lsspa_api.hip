@@ -137,6 +137,11 @@ struct lsspa_ctx {
   // collectives (RCCL), see comm.h
   Comm* comm = nullptr;
   DevBuf<double> pack, xfer;     // packed moments; staging of host-side all-gathers
+  DevBuf<double> theta_d;        // lsspa_full_fit's back-substitution
+  // the streamed reduction's staging (two row chunks in flight), its copy stream and events: kept between calls
+  DevBuf<char> red_x[2], red_y[2];
+  hipStream_t red_cs = nullptr;
+  hipEvent_t red_copied[2] = {nullptr, nullptr}, red_consumed[2] = {nullptr, nullptr};
   DevBuf<int64_t> ibuf;
   int pack_from_p = 2048;        // the moments travel as an upper triangle from this p on
   std::vector<int32_t> perm_mark;   // scratch of the ordering validation
@@ -1027,7 +1032,14 @@ int lsspa_destroy(lsspa_ctx* ctx) try {
   if (ctx->ev_problem) (void)hipEventDestroy(ctx->ev_problem);
   comm_destroy(ctx->comm);
   ctx->comm = nullptr;
-  dev_free(ctx->pack); dev_free(ctx->xfer); dev_free(ctx->ibuf);
+  dev_free(ctx->pack); dev_free(ctx->xfer); dev_free(ctx->ibuf); dev_free(ctx->theta_d);
+  for (int b = 0; b < 2; ++b) {
+    dev_free(ctx->red_x[b]);
+    dev_free(ctx->red_y[b]);
+    if (ctx->red_copied[b]) (void)hipEventDestroy(ctx->red_copied[b]);
+    if (ctx->red_consumed[b]) (void)hipEventDestroy(ctx->red_consumed[b]);
+  }
+  if (ctx->red_cs) (void)hipStreamDestroy(ctx->red_cs);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return LSSPA_OK;
@@ -1133,14 +1145,22 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
   int rc = dev_alloc(ctx, slabs, gram_workspace_bytes(p, n_split) / sizeof(double));
   hipError_t e = hipSuccess;
   if (rc == LSSPA_OK) {
-    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
-      e = hipMalloc(&dX[b], (size_t)rows * p * es);
-      if (e == hipSuccess) e = hipMalloc(&dy[b], (size_t)rows * es);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&copied[b], hipEventDisableTiming);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming);
+    // the staging buffers, the copy stream and the events live with the context: made on first use, found in place by
+    // the second side of this reduction and by the next call (four hipMalloc / hipFree pairs of ~100 MB per call before)
+    for (int b = 0; b < 2 && rc == LSSPA_OK; ++b) {
+      rc = dev_alloc(ctx, ctx->red_x[b], (size_t)rows * p * es);
+      if (rc == LSSPA_OK) rc = dev_alloc(ctx, ctx->red_y[b], (size_t)rows * es);
+      if (rc == LSSPA_OK && !ctx->red_copied[b]) e = hipEventCreateWithFlags(&ctx->red_copied[b], hipEventDisableTiming);
+      if (rc == LSSPA_OK && e == hipSuccess && !ctx->red_consumed[b])
+        e = hipEventCreateWithFlags(&ctx->red_consumed[b], hipEventDisableTiming);
+      dX[b] = ctx->red_x[b].ptr;
+      dy[b] = ctx->red_y[b].ptr;
+      copied[b] = ctx->red_copied[b];
+      consumed[b] = ctx->red_consumed[b];
     }
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
-    if (e != hipSuccess) rc = ctx->fail(LSSPA_ERR_NOMEM, "streamed reduction buffers", e);
+    if (rc == LSSPA_OK && e == hipSuccess && !ctx->red_cs) e = hipStreamCreateWithFlags(&ctx->red_cs, hipStreamNonBlocking);
+    cs = ctx->red_cs;
+    if (rc == LSSPA_OK && e != hipSuccess) rc = ctx->fail(LSSPA_ERR_NOMEM, "streamed reduction buffers", e);
   }
   const auto t_stream0 = std::chrono::steady_clock::now();
   auto seconds_since = [](std::chrono::steady_clock::time_point t0) {
@@ -1188,20 +1208,10 @@ static int gram_side_streamed(lsspa_ctx* ctx, const void* X, const void* y, int6
   // Both streams are idle before the buffers go -- on the error paths too: every copy
   // that reads the caller's pages was enqueued on cs, every kernel that reads dX / dy on the context's stream.
   hipError_t es1 = hipStreamSynchronize(ctx->stream);
-  hipError_t es2 = hipSuccess;
-  if (cs) {
-    es2 = hipStreamSynchronize(cs);
-    (void)hipStreamDestroy(cs);
-  }
+  hipError_t es2 = cs ? hipStreamSynchronize(cs) : hipSuccess;
   if (rc == LSSPA_OK && es1 != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "streamed gram sync", es1);
   if (rc == LSSPA_OK && es2 != hipSuccess) rc = ctx->fail(LSSPA_ERR_HIP, "streamed gram copy sync", es2);
   ctx->red_stream_s += seconds_since(t_stream0);
-  for (int b = 0; b < 2; ++b) {
-    if (dX[b]) (void)hipFree(dX[b]);
-    if (dy[b]) (void)hipFree(dy[b]);
-    if (copied[b]) (void)hipEventDestroy(copied[b]);
-    if (consumed[b]) (void)hipEventDestroy(consumed[b]);
-  }
   dev_free(slabs);
   return rc;
 }
@@ -1482,12 +1492,11 @@ int lsspa_full_fit(lsspa_ctx* ctx, double* theta, double* r_squared, int32_t* in
   HIPCHK(hipMemcpy(ctx->info_d.ptr, &saved, 4, hipMemcpyHostToDevice));
   if (info) *info = now;
   if (theta) {
-    DevBuf<double> th;
+    DevBuf<double>& th = ctx->theta_d;          // kept with the context (a hipMalloc / hipFree pair per call otherwise)
     TRY(dev_alloc(ctx, th, (size_t)2 * p));     // theta, and the running right-hand side when p exceeds the LDS
     hipError_t e = launch_backsolve(ctx->lanes[0].A.ptr, th.ptr, p, ctx->p_pad, ctx->f32, ctx->stream, th.ptr + p);
     if (e == hipSuccess) e = hipMemcpyAsync(theta, th.ptr, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    dev_free(th);
     if (e != hipSuccess) return ctx->fail(LSSPA_ERR_HIP, "backsolve", e);
   }
   if (r_squared) {
