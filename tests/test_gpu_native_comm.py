@@ -91,3 +91,48 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
     g = np.load(os.path.join(ROOT, "tests", "golden", "p12.npz"))
     np.testing.assert_allclose(np.load(tmp_path / "attr.npy"), g["drv_anti1_attribution"], rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("p,n,m", [(40, 400, 300), (150, 900, 800)])
+def test_group_collect_through_the_native_communicator(p, n, m):
+    """lsspa_group_collect with a communicator on the context (world of one, collectives forced): per chunk collect,
+    lsspa_stats_allreduce + merge, fold into the running estimator, lsspa_error_running_draws + lsspa_error_allreduce +
+    quantiles -- the per-chunk tail a rank of an 8-GPU run executes in ONE library call -- against the plain one-GPU
+    run (accumulate = 2, no collective, the draws never written): the same orderings, the same sample ids, the same
+    normals, so every number agrees to round-off; also when the stop rule fires on the deferred path."""
+    from ls_spa import ls_spa
+    from ls_spa._engine import HipEngine
+    from ls_spa._rccl import NativeComm
+    rng = np.random.default_rng(200 + p)
+    Xa, Xe = rng.standard_normal((n, p)), rng.standard_normal((m, p))
+    th = rng.standard_normal(p)
+    ya, ye = Xa @ th + rng.standard_normal(n), Xe @ th + rng.standard_normal(m)
+    kw = dict(reg=1e-3, method="argsort", seed=11, batch_size=16, max_samples=96, lookahead=3)
+
+    class Counting(HipEngine):
+        groups = 0
+
+        def group_collect(self, *a, **k):
+            self.groups += 1
+            return super().group_collect(*a, **k)
+
+    plain_e, comm_e = Counting(0), Counting(0)
+    cm = NativeComm(0, 1, force_collective=True)     # bound to comm_e by the first call, used again by the second
+    try:
+        plain = ls_spa(Xa, Xe, ya, ye, tolerance=0.0, _engine=plain_e, **kw)
+        via = ls_spa(Xa, Xe, ya, ye, tolerance=0.0, _engine=comm_e, comm=cm, **kw)
+        assert plain_e.groups == 3 and comm_e.groups == 3          # 7 chunks in groups of 3, 3, 1: the one-call path, both
+        assert len(plain.error_history) == len(via.error_history) == 7
+        np.testing.assert_allclose(via.attribution, plain.attribution, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(via.error_history, plain.error_history, rtol=1e-9)
+        np.testing.assert_allclose(via.attribution_errors, plain.attribution_errors, rtol=1e-9)
+        tol = float(plain.error_history[2]) * 1.0000001
+        if all(e > tol for e in plain.error_history[:2]):
+            a = ls_spa(Xa, Xe, ya, ye, tolerance=tol, _engine=plain_e, **kw)
+            b = ls_spa(Xa, Xe, ya, ye, tolerance=tol, _engine=comm_e, comm=cm, **kw)
+            assert len(a.error_history) == len(b.error_history) == 3
+            np.testing.assert_allclose(b.attribution, a.attribution, rtol=0, atol=1e-13)
+    finally:
+        cm.close()
+        plain_e.close()
+        comm_e.close()
