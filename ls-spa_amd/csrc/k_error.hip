@@ -201,21 +201,26 @@ __global__ __launch_bounds__(512) void quantile_kernel(DrawSrc src, const double
   const int a = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < ND; i += 512) s[i] = (a < p) ? fabs(src.at(i, a)) : norms[i];
   __syncthreads();
-  for (int k = 2; k <= ND; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < ND; i += 512) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const double x = s[i], y = s[ixj];
-          const bool up = (i & k) == 0;
-          if ((x > y) == up) {
-            s[i] = y;
-            s[ixj] = x;
-          }
-        }
+  // Bitonic sort, one compare-exchange per thread and stage (512 pairs).  A stage of distance j works inside blocks of
+  // 2 j elements; a wave's 64 pairs cover elements [128 w, 128 w + 128), so every stage with j <= 64 stays inside the
+  // wave's own elements -- LDS operations of one wave execute in order -- and needs no workgroup barrier: 6 of the 55
+  // stages (j = 128, 256, 512) have one on either side, the other 49 none (20.5 -> measured in DESIGN.md).
+  for (int lk = 1; (1 << lk) <= ND; ++lk)
+    for (int lj = lk - 1; lj >= 0; --lj) {
+      const int k = 1 << lk, j = 1 << lj;
+      const bool wide = j >= 128;
+      if (wide) __syncthreads();
+      const int i = ((tid >> lj) << (lj + 1)) + (tid & (j - 1)), ixj = i + j;
+      const double x = s[i], y = s[ixj];
+      const bool up = (i & k) == 0;
+      if ((x > y) == up) {
+        s[i] = y;
+        s[ixj] = x;
       }
-      __syncthreads();
+      if (wide) __syncthreads();
+      else __builtin_amdgcn_wave_barrier();
     }
+  __syncthreads();
   if (tid == 0) {
     const double pos = q * (ND - 1);
     const int lo = (int)floor(pos);
@@ -251,19 +256,28 @@ __global__ __launch_bounds__(256) void acc_small_kernel(const double* __restrict
   double rs = 0.0;
   const int kq = n_pad / 4;                  // this wave's samples: [w kq, (w + 1) kq), kq a multiple of 4
   const double* arow = Xi + (int64_t)(d0 + l15) * n_pad + w * kq + l4;
-#pragma unroll 2
-  for (int st = 0; st < kq / 4; ++st) {
-    const int k = w * kq + 4 * st + l4;
-    const double a = arow[4 * st];
-    rs += a;
-    double b[8];
+  // four k-steps a turn, all 36 loads of a turn issued before its first product (the loop is a chain of memory round
+  // trips otherwise: 10 us at 128 samples with two steps in flight)
+  for (int st0 = 0; st0 < kq / 4; st0 += 4) {
+    double a[4], b[4][8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int c = c0 + 16 * t + l15;
-      b[t] = (k < k_valid && c < c_valid) ? L[(int64_t)k * ldl + c] : 0.0;
+    for (int u = 0; u < 4; ++u) {
+      const int st = st0 + u;
+      const bool live = st < kq / 4;
+      const int k = w * kq + 4 * st + l4;
+      a[u] = live ? arow[4 * st] : 0.0;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int c = c0 + 16 * t + l15;
+        b[u][t] = (live && k < k_valid && c < c_valid) ? L[(int64_t)k * ldl + c] : 0.0;
+      }
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = mfma(a, b[t], acc[t]);
+    for (int u = 0; u < 4; ++u) {
+      rs += a[u];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = mfma(a[u], b[u][t], acc[t]);
+    }
   }
 #pragma unroll
   for (int t = 0; t < 8; ++t)
