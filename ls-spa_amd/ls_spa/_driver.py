@@ -226,7 +226,7 @@ def _data_fingerprint(engine):
     return f"{float(np.trace(G))!r}/{float(g @ g)!r}/{float(engine.y_norm_sq)!r}"
 
 
-def prepare_sampling(p, *, max_samples, batch_size, seed, perms, antithetical, method):
+def prepare_sampling(p, *, max_samples, batch_size, seed, perms, antithetical, method, rank=0, world=1):
     """Generator and ordering source of a run, with the reference's overrides for small p applied
     (ls_spa/ls_spa.py:169-177).  Split from run_estimator so that ls_spa() can start it -- the QMC
     constructors work on a helper thread -- before the data reduction instead of after it."""
@@ -257,7 +257,7 @@ def prepare_sampling(p, *, max_samples, batch_size, seed, perms, antithetical, m
     if source.independent:
         # the QMC samplers draw ahead of the loop on a helper thread (their stream is nobody else's), from now on --
         # in ls_spa() that is under the data reduction
-        source = S.PrefetchedSource(source, block=1024 if p <= 126 else 256)
+        source = S.PrefetchedSource(source, block=1024 if p <= 126 else 256, rank=rank, world=world)
     return rng, source, batch_size, antithetical, max_samples, never_stop
 
 
@@ -279,7 +279,7 @@ def run_estimator(engine, p, *, max_samples, batch_size, tolerance, seed, perms,
     comm = comm or _Comm()
     if prepared is None:
         prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
-                                    antithetical=antithetical, method=method)
+                                    antithetical=antithetical, method=method, rank=comm.rank, world=comm.world)
     rng, source, batch_size, antithetical, max_samples, never_stop = prepared
     if batch_size < 1:
         raise ValueError("batch_size must be positive")
@@ -453,13 +453,15 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
             if sub_cap:
                 want = min(want, sub_cap)
             t_s0 = _time.perf_counter()
-            chunk = source.take(want)
+            # sample number g of the run belongs to rank g mod world (round 5; up to round 4 the dealing restarted with
+            # every chunk): a QMC source then draws -- ahead of the loop -- this rank's orderings only
+            n_got, mine_rows = source.take_share(want, cursor, comm.rank, comm.world)
             t_sampler += _time.perf_counter() - t_s0
-            if len(chunk) == 0:
+            if n_got == 0:
                 break
-            entries.append([chunk, chunk[comm.rank::comm.world], want])   # dealt round-robin over the ranks
-            cursor += len(chunk)
-            if len(chunk) < want:
+            entries.append([n_got, mine_rows, want])
+            cursor += n_got
+            if n_got < want:
                 break
         ticket = None
         if (group > 1 or prefetch) and entries:
@@ -503,27 +505,26 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
             refill(i)
         if not queue:
             break
-        chunk, mine, want, ticket, first = queue.pop(0)
-        n_new = len(chunk)
+        n_new, mine, want, ticket, first = queue.pop(0)
         if fast_group and ticket is not None:
             # every chunk of the launched group in ONE call into the library (lsspa_group_collect): collect, all-reduce
             # and merge, fold into the estimator, enqueue the check -- per chunk, in the reference's order; at p = 100 a
             # chunk is 37 us of GPU work and this loop's own calls were what a run waited for
-            members = [(chunk, mine, want, ticket, first)]
+            members = [(n_new, mine, want, ticket, first)]
             while queue and queue[0][3] is ticket:
                 members.append(tuple(queue.pop(0)))
-            if (all(len(m[0]) == m[2] for m in members)
+            if (all(m[0] == m[2] for m in members)
                     and len(outstanding) + len(members) < engine.RESULT_SLOTS):
                 t_g0 = _time.perf_counter()
                 cursor = i
                 if prefetch and not queue:
-                    refill(i + sum(len(m[0]) for m in members))      # the next group, on the other lane
+                    refill(i + sum(m[0] for m in members))      # the next group, on the other lane
                 firsts, counts, ids, n_after, slots = [], [], [], [], []
-                for ch, mn, _, _, fs in members:
+                for n_ch, mn, _, _, fs in members:
                     firsts.append(fs)
                     counts.append(len(mn))
-                    ids.append(cursor + comm.rank)
-                    cursor += len(ch)
+                    ids.append(cursor + (comm.rank - cursor) % comm.world)      # this rank's first sample of the chunk
+                    cursor += n_ch
                     due = estimate and (cursor % batch_size == 0 or cursor == max_samples - 1)
                     n_after.append(cursor if due else 0)
                     slots.append(slot_turn[0] if due else 0)
@@ -541,7 +542,7 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
                 continue
             for m in reversed(members[1:]):      # a chunk cut short by a dry source: chunk by chunk below
                 queue.insert(0, list(m))
-        if prefetch and not queue and ticket is not None and len(chunk) == want:
+        if prefetch and not queue and ticket is not None and n_new == want:
             refill(i + n_new)      # the next group, on the other lane
         local = None
         if len(mine):
@@ -551,18 +552,19 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
             else:
                 local = engine.run_batch(mine, antithetical, want_lifts=keep_lifts, accumulate=acc_mode)
             if on_device:
-                # this rank's samples of the chunk are samples i + rank, i + rank + world, ... of the run
-                engine.error_advance(i + comm.rank, comm.world)
+                # this rank's samples of the chunk: every world-th sample of the run from its first one at or after i
+                engine.error_advance(i + (comm.rank - i) % comm.world, comm.world)
         if not single:
             comm.allreduce_pending(engine)
             engine.merge()
         if keep_lifts:
-            counts = [len(chunk[r::comm.world]) for r in range(comm.world)]
+            offs = [(r - i) % comm.world for r in range(comm.world)]      # rank r's first position in this chunk
+            counts = [len(range(offs[r], n_new, comm.world)) for r in range(comm.world)]
             parts = comm.gather_lifts(local if local is not None else np.empty((0, p)), counts)
             if comm.world > 1:
                 full = np.empty((n_new, p))
                 for r in range(comm.world):
-                    full[r::comm.world] = parts[r]
+                    full[offs[r]::comm.world] = parts[r]
             else:
                 full = parts
             if return_attribution_history:
@@ -675,8 +677,8 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         kernel gains nothing from it), else 1.
     comm:  several GPUs, one process each: the communicator every rank passes -- ``NativeComm.from_env()``
         (RCCL through the C ABI, no PyTorch) or ``TorchComm()`` (torch.distributed: RCCL, or gloo on CPU in
-        the tests).  The orderings of every chunk are dealt round-robin over the ranks; the only data-path
-        collective is one all-reduce of the packed batch moments per chunk.
+        the tests).  Sample number g of the run belongs to rank g mod world (a QMC method then draws a rank's own
+        orderings only); the only data-path collective is one all-reduce of the packed batch moments per chunk.
     row_sharded:  several ranks only (``comm``).  False: every rank passes the whole data set.
         True: the four arrays are this rank's ROWS of the training and test sets; the ranks reduce
         their rows and sum the Gram matrices with one all-reduce.  'train': only the training rows are
@@ -735,8 +737,9 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         if hasattr(engine, "set_lanes") and getattr(engine, "lanes", 1) != int(lanes):
             engine.set_lanes(int(lanes))
         t0 = lap("setup", t0)
+        share = dict(rank=comm.rank, world=comm.world) if comm is not None else {}
         prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
-                                    antithetical=antithetical, method=method)
+                                    antithetical=antithetical, method=method, **share)
         t0 = lap("sampler_start", t0)
         if row_sharded:
             engine.load_data_sharded(X_train, X_test, y_train, y_test, reg, comm or _Comm(),
@@ -780,7 +783,7 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
             engine.set_flags(512)
             prepared[1].close() if hasattr(prepared[1], "close") else None
             prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
-                                        antithetical=antithetical, method=method)
+                                        antithetical=antithetical, method=method, **share)
             (attribution, feat_err, total_err, err_hist, history, _), bits = sampling_run(prepared)
             fault = bool(bits & 12) and not bits & 1
         if fault:

@@ -37,6 +37,15 @@ class OrderingSource:
     def take(self, count):  # pragma: no cover - interface
         raise NotImplementedError
 
+    def take_share(self, count, first, rank, world):
+        """(n, own): the next ``count`` orderings of the run are taken -- n of them exist --; ``own`` are those a rank
+        evaluates: ordering number g of the run (``first`` is the number of the first one taken here) belongs to rank
+        g mod world.  Default: draw them all, hand back the share (a caller's iterable and the shared generator are
+        consumed in full on every rank, as the one-process run consumes them); the QMC sources do only their share's
+        work."""
+        rows = self.take(count)
+        return len(rows), rows[(rank - first) % world::world]
+
     def skip(self, count):
         """Advance past ``count`` orderings already consumed before a checkpoint.  Default: draw and
         discard (exact for every deterministic source); subclasses do better where they can."""
@@ -130,20 +139,72 @@ def _argsort_rows(a):
     return out
 
 
+class _DirectSobol:
+    """Point number i of a SciPy Sobol' engine without drawing the points before it: the engine's state after i steps is
+    its initial state XOR the direction numbers of the bits set in the Gray code of i (what its draw loop accumulates
+    one lowest-zero-bit at a time).  With several GPUs a rank needs every world-th ordering only; drawing all of them
+    on every rank made the sampler, not the GPUs, the bound of a dealt batch (p = 1000: 1.06 ms of points + 1.86 ms of
+    argsort per 128 orderings against ~1 ms of kernels for a rank's 16).  Reads private attributes of the engine
+    (``_sv``, ``_quasi``, ``_scale``): ``make`` checks the result against the engine's own output on a copy -- near the
+    start and far into the sequence -- and returns None (the caller then draws everything and keeps its share) if
+    anything differs or is missing."""
+
+    def __init__(self, engine):
+        self.sv = np.array(engine._sv)                  # (d, bits) direction numbers (scrambled)
+        self.q0 = np.array(engine._quasi)               # state before the first step (the scramble's shift)
+        self.scale = float(engine._scale)
+        self.bits = int(self.sv.shape[1])
+
+    def points(self, idx):
+        idx = np.asarray(idx, dtype=np.uint64)
+        gray = idx ^ (idx >> np.uint64(1))
+        q = np.broadcast_to(self.q0, (len(idx), len(self.q0))).copy()
+        for b in range(self.bits):
+            rows = np.nonzero((gray >> np.uint64(b)) & np.uint64(1))[0]
+            if len(rows):
+                q[rows] ^= self.sv[:, b]
+        return q * self.scale
+
+    @classmethod
+    def make(cls, engine):
+        import copy
+        try:
+            if engine.num_generated != 0:
+                return None
+            me = cls(engine)
+            probe = copy.deepcopy(engine)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                head = probe.random(67)
+                probe.fast_forward(100003 - 67)
+                far = probe.random(5)
+            if not (np.array_equal(me.points(np.arange(67)), head)
+                    and np.array_equal(me.points(np.arange(100003, 100008)), far)):
+                return None
+            return me
+        except Exception:
+            return None
+
+
 class ArgsortSource(OrderingSource):
     independent = True
 
     def __init__(self, p, seed, limit):
         from scipy.stats.qmc import Sobol
-        self._build, self._p, self._left = _BackgroundBuild(lambda: Sobol(p, seed=seed)), p, limit
+
+        def build():
+            engine = Sobol(p, seed=seed)
+            return engine, _DirectSobol.make(engine)
+        self._build, self._p, self._left, self._pos = _BackgroundBuild(build), p, limit, 0
 
     @property
     def _qmc(self):
-        return self._build.get()
+        return self._build.get()[0]
 
     def _points(self, n):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")  # Sobol balance warning for n not a power of two
+            self._pos += n
             return self._qmc.random(n)
 
     def take(self, count):
@@ -153,11 +214,31 @@ class ArgsortSource(OrderingSource):
             return np.empty((0, self._p), dtype=np.int64)
         return _argsort_rows(self._points(n))
 
+    def take_share(self, count, first, rank, world):
+        if world == 1:
+            rows = self.take(count)
+            return len(rows), rows
+        n = int(min(count, self._left))
+        self._left -= n
+        if n <= 0:
+            return 0, np.empty((0, self._p), dtype=np.int64)
+        off = (rank - first) % world
+        direct = self._build.get()[1]
+        if direct is None:
+            return n, _argsort_rows(self._points(n)[off::world])
+        own = np.arange(self._pos + off, self._pos + n, world)
+        self._fast_forward(n)
+        self._pos += n
+        if len(own) == 0:
+            return n, np.empty((0, self._p), dtype=np.int64)
+        return n, _argsort_rows(direct.points(own))
+
     def skip(self, count):
         n = int(min(count, self._left))
         self._left -= n
         if n > 0:
             self._fast_forward(n)
+            self._pos += n
 
     def _fast_forward(self, n):
         self._qmc.fast_forward(n)
@@ -170,7 +251,7 @@ class PermutohedronSource(ArgsortSource):
             raise ValueError("permutohedron sampling needs p >= 2")
         self._build = _BackgroundBuild(
             lambda: (MultivariateNormalQMC(np.zeros(p - 1), seed=seed, inv_transform=False), helmert_rows(p)))
-        self._p, self._left = p, limit
+        self._p, self._left, self._pos = p, limit, 0
 
     @property
     def _qmc(self):
@@ -181,13 +262,20 @@ class PermutohedronSource(ArgsortSource):
         return self._build.get()[1]
 
     def take(self, count):
+        return self.take_share(count, 0, 0, 1)[1]
+
+    def take_share(self, count, first, rank, world):
         n = int(min(count, self._left))
         self._left -= n
         if n <= 0:
-            return np.empty((0, self._p), dtype=np.int64)
-        pts = self._points(n)
+            return 0, np.empty((0, self._p), dtype=np.int64)
+        # the QMC normals of every ordering are drawn (the generator pairs its Sobol' coordinates: no skipping); the
+        # projection on the basis and the argsort -- most of the cost -- only for this rank's share
+        pts = self._points(n)[(rank - first) % world::world]
+        if len(pts) == 0:
+            return n, np.empty((0, self._p), dtype=np.int64)
         pts = pts / np.linalg.norm(pts, axis=1, keepdims=True)
-        return _argsort_rows(pts @ self._basis)
+        return n, _argsort_rows(pts @ self._basis)
 
     def _fast_forward(self, n):
         # MultivariateNormalQMC has no fast_forward of its own: drawing n points advances the underlying
@@ -195,6 +283,7 @@ class PermutohedronSource(ArgsortSource):
         left = n
         while left > 0:
             left -= len(self._points(min(left, 4096)))
+        self._pos -= n      # (_points counted them; skip adds them again)
 
 
 class PrefetchedSource(OrderingSource):
@@ -204,27 +293,31 @@ class PrefetchedSource(OrderingSource):
     the GPU (p = 1000: 2.9 ms per 128 orderings against 6 ms; p = 100: 25 ms for the 8192 orderings the GPU evaluates
     in 2.4 ms), and between them the driver's thread is inside GIL-free library calls.  The helper starts when the
     source is made -- in ls_spa() that is before the data reduction -- and keeps up to ``ahead`` orderings ready, drawn
-    ``block`` at a time (SciPy's generators and ``argsort`` release the GIL for most of their time).  `take` hands out
-    exactly what the inner source would have: a QMC sequence continues across calls whatever their sizes
+    ``block`` at a time (SciPy's generators and ``argsort`` release the GIL for most of their time).  With several
+    ranks it draws this rank's share only (``take_share`` of the inner source; ordering number g of the run belongs to
+    rank g mod world), so the blocks it draws need not line up with the chunks the loop asks for.  `take_share` hands
+    out exactly what the inner source would have: a QMC sequence continues across calls whatever their sizes
     (tests/test_host_logic.py::test_samplers_match_fixtures).  Only for sources whose stream nobody else reads
     (``independent``)."""
     independent = True
 
-    def __init__(self, inner, block=256, ahead=None):
-        assert inner.independent
+    def __init__(self, inner, block=256, ahead=None, rank=0, world=1):
+        assert inner.independent and 0 <= rank < world
         p = max(1, int(getattr(inner, "_p", 1)))
         if ahead is None:
             ahead = max(2 * block, min(8192, (64 << 20) // (8 * p)))     # at most 64 MB of orderings waiting
         self._inner, self._block, self._ahead, self._p = inner, int(block), int(ahead), p
+        self._rank, self._world = int(rank), int(world)
+        self._cv = threading.Condition()
+        self._parts, self._ready = [], 0       # [first number, count, own rows] drawn and not yet handed out
+        self._drawn = self._taken = 0          # orderings of the run drawn by the helper / handed to the consumer
+        self._done = self._stop = False
+        self._error = None
         # until the consumer has asked for the first time -- in ls_spa() that is while the data reduction streams the
         # caller's arrays through the host's memory system -- the helper stops at ONE block: a run that ends at its first
         # check needs no more, and drawing 8192 orderings beside the reduction cost it 12 ms of a 47 ms call (measured)
         # (small problems draw everything at once: a megabyte a block, no contention to speak of)
         self._asked = (8 * p * self._block) <= (1 << 20)
-        self._cv = threading.Condition()
-        self._parts, self._ready = [], 0       # blocks drawn and not yet handed out
-        self._done = self._stop = False
-        self._error = None
         self._thread = threading.Thread(target=self._work, daemon=True)
         self._thread.start()
 
@@ -232,7 +325,7 @@ class PrefetchedSource(OrderingSource):
         # the helper is already drawing: the orderings before a checkpoint's position are taken and dropped
         left = int(count)
         while left > 0:
-            got = len(self.take(min(left, 4096)))
+            got = self.take_share(min(left, 4096), self._taken, self._rank, self._world)[0]
             if got == 0:
                 break
             left -= got
@@ -245,12 +338,13 @@ class PrefetchedSource(OrderingSource):
                         self._cv.wait()
                     if self._stop:
                         return
-                got = self._inner.take(self._block)
+                n, own = self._inner.take_share(self._block, self._drawn, self._rank, self._world)
                 with self._cv:
-                    if len(got):
-                        self._parts.append(got)
-                        self._ready += len(got)
-                    if len(got) < self._block:
+                    if n:
+                        self._parts.append([self._drawn, n, own])
+                        self._ready += n
+                        self._drawn += n
+                    if n < self._block:
                         self._done = True
                     self._cv.notify_all()
                     if self._done:
@@ -260,8 +354,15 @@ class PrefetchedSource(OrderingSource):
                 self._error, self._done = exc, True
                 self._cv.notify_all()
 
-    def take(self, count):
-        out, need = [], int(count)
+    def _own_in(self, lo, hi):
+        """How many orderings numbered lo <= g < hi belong to this rank."""
+        first = lo + (self._rank - lo) % self._world
+        return 0 if first >= hi else (hi - 1 - first) // self._world + 1
+
+    def take_share(self, count, first, rank, world):
+        if (rank, world) != (self._rank, self._world) or first != self._taken:
+            raise ValueError("the prefetching source was made for another rank, or orderings were taken out of turn")
+        out, need, got = [], int(count), 0
         with self._cv:
             if not self._asked:
                 self._asked = True
@@ -273,18 +374,27 @@ class PrefetchedSource(OrderingSource):
                     raise self._error
                 if not self._parts:
                     break
-                head = self._parts[0]
-                if len(head) <= need:
-                    out.append(self._parts.pop(0))
+                lo, n, rows = self._parts[0]
+                use = min(n, need)
+                k = self._own_in(lo, lo + use)
+                out.append(rows[:k])
+                if use == n:
+                    self._parts.pop(0)
                 else:
-                    out.append(head[:need])
-                    self._parts[0] = head[need:]
-                need -= len(out[-1])
-                self._ready -= len(out[-1])
+                    self._parts[0] = [lo + use, n - use, rows[k:]]
+                need -= use
+                got += use
+                self._ready -= use
                 self._cv.notify_all()
+            self._taken += got
         if not out:
-            return np.empty((0, self._p), dtype=np.int64)
-        return out[0] if len(out) == 1 else np.concatenate(out)
+            return 0, np.empty((0, self._p), dtype=np.int64)
+        return got, (out[0] if len(out) == 1 else np.concatenate(out))
+
+    def take(self, count):
+        if self._world != 1:
+            raise ValueError("a rank's prefetching source hands out shares: use take_share")
+        return self.take_share(count, self._taken, 0, 1)[1]
 
     def close(self):
         with self._cv:

@@ -153,8 +153,10 @@ def test_two_ranks_match_single_process(tmp_path):
         l = np.load(tmp_path / f"l{rk}.npz")
         np.testing.assert_allclose(l["attribution"], la1.attribution, rtol=0, atol=1e-13)
         np.testing.assert_allclose(l["err"], la1.error_history, rtol=1e-9)
-        # chunks of 16, 16, 16, 16, 16, 15, 1 samples dealt over two ranks (a rank with nothing in a chunk makes no call)
-        assert list(l["calls"]) == ([8, 8, 8, 8, 8, 8, 1] if rk == 0 else [8, 8, 8, 8, 8, 7]) and int(l["launched"]) == 3 - rk
+        # chunks of 16, 16, 16, 16, 16, 15, 1 samples; sample number g of the run belongs to rank g mod 2 (round 5: dealt by
+        # the sample's number, not by its place in the chunk), so the last sample, number 95, is rank 1's (a rank with
+        # nothing in a chunk makes no call, and no launch for a group it has nothing in)
+        assert list(l["calls"]) == ([8, 8, 8, 8, 8, 8] if rk == 0 else [8, 8, 8, 8, 8, 7, 1]) and int(l["launched"]) == 2 + rk
         np.testing.assert_allclose(l["stop_attr"], la1_stop.attribution, rtol=0, atol=1e-13)
         assert int(l["stop_checks"]) == len(la1_stop.error_history) == 2
         assert int(l["stop_discarded"]) == 1 and list(l["stop_calls"]) == [8, 8]

@@ -273,6 +273,40 @@ def test_samplers_match_fixtures(golden):
     assert len(src.take(4)) == 0
 
 
+def test_sources_hand_out_a_ranks_share():
+    """With several ranks ordering number g of the run belongs to rank g mod world (take_share).  The QMC sources do
+    only their share's work -- the Sobol' points of a rank's orderings are computed directly from the engine's direction
+    numbers (checked against SciPy's own output when the source is made) -- and must hand out exactly the rows of the
+    full sequence, whatever the chunk sizes; the prefetching wrapper draws a rank's share in blocks of its own and must
+    cut them at the consumer's chunk boundaries; every other source draws everything and keeps its share."""
+    for cls in (S.ArgsortSource, S.PermutohedronSource):
+        full = cls(23, 5, 1000).take(300)
+        for world in (2, 3, 8):
+            for rank in range(world):
+                plain = cls(23, 5, 300)
+                ahead = S.PrefetchedSource(cls(23, 5, 300), block=64, ahead=128, rank=rank, world=world)
+                for src in (plain, ahead):
+                    pos, rows, idx = 0, [], []
+                    for cnt in (10, 100, 7, 120, 50, 50):
+                        n, own = src.take_share(cnt, pos, rank, world)
+                        idx.append(np.arange(pos + (rank - pos) % world, pos + n, world))
+                        rows.append(own)
+                        pos += n
+                    assert pos == 300
+                    np.testing.assert_array_equal(np.concatenate(rows), full[np.concatenate(idx)])
+                ahead.close()
+    direct = S.ArgsortSource(23, 5, 10)._build.get()[1]
+    assert direct is not None, "the direct Sobol' points no longer match this SciPy: the source fell back to drawing all"
+    # a caller's iterable is consumed in full on every rank, as the one-process run consumes it
+    src = S.IterableSource(iter(np.array([np.roll(np.arange(9), k) for k in range(20)])), 9)
+    n, own = src.take_share(7, 0, 1, 3)
+    assert n == 7 and [int(r[0]) for r in own] == [8, 5]           # orderings 1 and 4 of the first seven
+    n, own = src.take_share(7, 7, 1, 3)
+    assert n == 7 and [int(r[0]) for r in own] == [2, 8, 5]        # orderings 7, 10 and 13: dealt by number, not by place
+    with pytest.raises(ValueError, match="out of turn"):
+        S.PrefetchedSource(S.ArgsortSource(9, 1, 50), rank=0, world=2).take_share(4, 3, 0, 2)
+
+
 def test_iterable_source_is_lazy():
     pulled = []
 
