@@ -145,8 +145,8 @@ class _DirectSobol:
     one lowest-zero-bit at a time).  With several GPUs a rank needs every world-th ordering only; drawing all of them
     on every rank made the sampler, not the GPUs, the bound of a dealt batch (p = 1000: 1.06 ms of points + 1.86 ms of
     argsort per 128 orderings against ~1 ms of kernels for a rank's 16).  Reads private attributes of the engine
-    (``_sv``, ``_quasi``, ``_scale``): ``make`` checks the result against the engine's own output on a copy -- near the
-    start and far into the sequence -- and returns None (the caller then draws everything and keeps its share) if
+    (``_sv``, ``_quasi``, ``_scale``): ``make`` checks the result against the engine's own output on a copy -- the first
+    67 points and five beyond number 4096 -- and returns None (the caller then draws everything and keeps its share) if
     anything differs or is missing."""
 
     def __init__(self, engine):
@@ -176,10 +176,10 @@ class _DirectSobol:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 head = probe.random(67)
-                probe.fast_forward(100003 - 67)
+                probe.fast_forward(4099 - 67)       # (a microsecond a point and dimension: kept short)
                 far = probe.random(5)
             if not (np.array_equal(me.points(np.arange(67)), head)
-                    and np.array_equal(me.points(np.arange(100003, 100008)), far)):
+                    and np.array_equal(me.points(np.arange(4099, 4104)), far)):
                 return None
             return me
         except Exception:
@@ -192,14 +192,17 @@ class ArgsortSource(OrderingSource):
     def __init__(self, p, seed, limit):
         from scipy.stats.qmc import Sobol
 
-        def build():
-            engine = Sobol(p, seed=seed)
-            return engine, _DirectSobol.make(engine)
-        self._build, self._p, self._left, self._pos = _BackgroundBuild(build), p, limit, 0
+        self._build, self._p, self._left, self._pos = _BackgroundBuild(lambda: Sobol(p, seed=seed)), p, limit, 0
+        self._direct = False      # False: not made yet (only a run with several ranks needs it); None: unavailable
 
     @property
     def _qmc(self):
-        return self._build.get()[0]
+        return self._build.get()
+
+    def _direct_points(self):
+        if self._direct is False:
+            self._direct = _DirectSobol.make(self._qmc) if self._pos == 0 else None
+        return self._direct
 
     def _points(self, n):
         with warnings.catch_warnings():
@@ -223,7 +226,7 @@ class ArgsortSource(OrderingSource):
         if n <= 0:
             return 0, np.empty((0, self._p), dtype=np.int64)
         off = (rank - first) % world
-        direct = self._build.get()[1]
+        direct = self._direct_points()
         if direct is None:
             return n, _argsort_rows(self._points(n)[off::world])
         own = np.arange(self._pos + off, self._pos + n, world)

@@ -295,7 +295,7 @@ def test_sources_hand_out_a_ranks_share():
                     assert pos == 300
                     np.testing.assert_array_equal(np.concatenate(rows), full[np.concatenate(idx)])
                 ahead.close()
-    direct = S.ArgsortSource(23, 5, 10)._build.get()[1]
+    direct = S.ArgsortSource(23, 5, 10)._direct_points()
     assert direct is not None, "the direct Sobol' points no longer match this SciPy: the source fell back to drawing all"
     # a caller's iterable is consumed in full on every rank, as the one-process run consumes it
     src = S.IterableSource(iter(np.array([np.roll(np.arange(9), k) for k in range(20)])), 9)
