@@ -712,13 +712,19 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
     engine = _engine
     owns = engine is None          # this call made (or borrowed) the engine: it also ends the communicator bound to it
     kept = None                    # the lock of a borrowed, kept engine
+    # The ordering source first: a QMC source starts its helper thread here -- the first `import scipy.stats` of a process
+    # (0.26 s; 1.3 s on a cold box), the Sobol' constructor (18 ms at p = 1000) and the first block of orderings then run
+    # under the engine's creation and the data reduction instead of in front of the sampling loop.
     t0 = _time.perf_counter()
-    if owns:
-        engine, kept = _acquire_engine(device)
-    t0 = lap("engine_create", t0)
+    share = dict(rank=comm.rank, world=comm.world) if comm is not None else {}
+    prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
+                                antithetical=antithetical, method=method, **share)
+    t0 = lap("sampler_start", t0)
     ok = False
-    prepared = None
     try:
+        if owns:
+            engine, kept = _acquire_engine(device)
+        t0 = lap("engine_create", t0)
         if comm is not None and hasattr(comm, "bind"):
             comm.bind(engine)      # RCCL communicator on this engine's GPU and stream (collective)
         if precision != "float64" or getattr(engine, "precision", "float64") != "float64":
@@ -737,10 +743,6 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         if hasattr(engine, "set_lanes") and getattr(engine, "lanes", 1) != int(lanes):
             engine.set_lanes(int(lanes))
         t0 = lap("setup", t0)
-        share = dict(rank=comm.rank, world=comm.world) if comm is not None else {}
-        prepared = prepare_sampling(p, max_samples=max_samples, batch_size=batch_size, seed=seed, perms=perms,
-                                    antithetical=antithetical, method=method, **share)
-        t0 = lap("sampler_start", t0)
         if row_sharded:
             engine.load_data_sharded(X_train, X_test, y_train, y_test, reg, comm or _Comm(),
                                      shard_test=row_sharded != "train")
@@ -811,7 +813,7 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         t0 = _time.perf_counter()
         if prepared is not None and hasattr(prepared[1], "close"):
             prepared[1].close()      # the sampler's helper thread (already ended by a run that got as far as its loop)
-        if owns:
+        if owns and engine is not None:
             try:
                 if comm is not None and hasattr(comm, "close"):
                     comm.close()       # the communicator lives on the engine's context

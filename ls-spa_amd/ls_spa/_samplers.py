@@ -190,9 +190,12 @@ class ArgsortSource(OrderingSource):
     independent = True
 
     def __init__(self, p, seed, limit):
-        from scipy.stats.qmc import Sobol
-
-        self._build, self._p, self._left, self._pos = _BackgroundBuild(lambda: Sobol(p, seed=seed)), p, limit, 0
+        def build():
+            # the import belongs to the helper thread as well: the first `import scipy.stats` of a process takes 0.26 s
+            # (1.3 s on a cold box) -- of the caller's time, while it could be inside the data reduction
+            from scipy.stats.qmc import Sobol
+            return Sobol(p, seed=seed)
+        self._build, self._p, self._left, self._pos = _BackgroundBuild(build), p, limit, 0
         self._direct = False      # False: not made yet (only a run with several ranks needs it); None: unavailable
 
     @property
@@ -249,11 +252,13 @@ class ArgsortSource(OrderingSource):
 
 class PermutohedronSource(ArgsortSource):
     def __init__(self, p, seed, limit):
-        from scipy.stats.qmc import MultivariateNormalQMC
         if p < 2:
             raise ValueError("permutohedron sampling needs p >= 2")
-        self._build = _BackgroundBuild(
-            lambda: (MultivariateNormalQMC(np.zeros(p - 1), seed=seed, inv_transform=False), helmert_rows(p)))
+
+        def build():
+            from scipy.stats.qmc import MultivariateNormalQMC
+            return MultivariateNormalQMC(np.zeros(p - 1), seed=seed, inv_transform=False), helmert_rows(p)
+        self._build = _BackgroundBuild(build)
         self._p, self._left, self._pos = p, limit, 0
 
     @property
