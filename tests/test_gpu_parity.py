@@ -337,7 +337,7 @@ def test_device_error_estimator_end_to_end():
 @pytest.mark.parametrize("estimator", ["reference", "device"])
 def test_checkpoint_resume_on_the_product_path(tmp_path, estimator):
     """Interrupt the HIP-backed run in its third batch and resume from the state file: the result is the
-    uninterrupted run's (lsspa_stats_set / lsspa_history_append restore the device state)."""
+    uninterrupted run's (lsspa_stats_set / lsspa_error_state_set restore the device state)."""
     from ls_spa._engine import HipEngine
 
     class Dies(HipEngine):

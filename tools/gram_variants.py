@@ -1,4 +1,4 @@
-"""Gram reduction at the C3 shape under the temporary knobs LSSPA_GRAM_COST / LSSPA_GRAM_SPLIT (developer tool)."""
+"""The Gram reduction at any shape: python3 tools/gram_variants.py [p rows | c5]  (developer tool)."""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ls-spa_amd"))
 import torch, numpy as np
@@ -18,5 +18,5 @@ for rnd in range(6):
     eng.load_device_data(Xa.data_ptr(), p, ya.data_ptr(), N, Xa.data_ptr(), p, ya.data_ptr(), N, p, 0.0, f32=f32)
     eng.synchronize()
 ms, cnt = eng.profile_read()["gram"]
-print(p, N, os.environ.get("LSSPA_GRAM_COST"), os.environ.get("LSSPA_GRAM_SPLIT"), "gram ms per side", ms / cnt,
+print(p, N, "gram ms per side", ms / cnt,
       "TFLOP/s", N * (p + 1) * (p + 2) / (ms / cnt * 1e-3) / 1e12)
