@@ -295,6 +295,11 @@ def test_sources_hand_out_a_ranks_share():
                     assert pos == 300
                     np.testing.assert_array_equal(np.concatenate(rows), full[np.concatenate(idx)])
                 ahead.close()
+    rng = np.random.default_rng(3)
+    for q in (2, 3, 12, 200):                       # the O(p) projection a rank's share goes through == the matrix product
+        u = rng.standard_normal((5, q - 1))
+        np.testing.assert_allclose(S.helmert_project(u), u @ S.helmert_rows(q), rtol=0, atol=1e-14)
+    assert S.PermutohedronSource(23, 5, 10)._direct_normals() is not None, "direct QMC normals no longer match this SciPy"
     direct = S.ArgsortSource(23, 5, 10)._direct_points()
     assert direct is not None, "the direct Sobol' points no longer match this SciPy: the source fell back to drawing all"
     # a caller's iterable is consumed in full on every rank, as the one-process run consumes it
