@@ -1026,7 +1026,7 @@ def main():
                         "orderings_per_s": 2 * n_done / loop_s, "orderings_per_s_whole_call": 2 * n_done / secs,
                         "fraction_of_value": None, "tolerance": 0.0, "error_estimator": "device (default of the method)",
                         "host_seconds": {k: round(v, 6) for k, v in tm.items()},
-                        "estimator_host_ms_per_check": {
+                        "loop_ms_per_check": {
                             "first": per_check[0] if per_check else None, "last": per_check[-1] if per_check else None,
                             "median": float(np.median(per_check)) if per_check else None,
                             "max": max(per_check) if per_check else None},
@@ -1035,8 +1035,9 @@ def main():
                                 "through sampler (SciPy Sobol + argsort on a helper thread), driver, device estimator "
                                 "(running form, checks deferred by one) and statistics; orderings_per_s is over the "
                                 "sampling loop (host_seconds sampler + estimator + sampling), seconds the whole call "
-                                "(one GPU: engine, reduction over PCIe, final fit included); estimator_host_ms_per_check = "
-                                "host time inside the estimator calls of each check (enqueue + reading the deferred result)"}
+                                "(one GPU: engine, reduction over PCIe, final fit included); loop_ms_per_check = host "
+                                "wall time per check of the loop -- its period, the wait for the GPU included: the same at "
+                                "the first check and the last (what the estimator's kernels cost a check is estimator_gpu)"}
             got = guarded("full_run", full_run)
             if got is not None:
                 legs["full_run"] = got

@@ -373,7 +373,13 @@ __device__ __forceinline__ void wave_factor16(T* s_blk, T* s_inv, T* s_dd, const
     t[r] = (l15 <= row) ? s_blk[row * DI_LD + l15] : s_blk[l15 * DI_LD + row];
     y[r] = (row == l15) ? (T)1 : (T)0;
   }
-  factor16_acc<T>(t, y, tol_lane, lane, bad);
+  // The one-pivot-a-step sweep here (SEQ), although the four-pivot form (tiles.h: factor16_acc_b4) is 1.5 x faster in
+  // isolation and what the small-problem kernels use: measured in this file's kernels (round 5, alternating processes on
+  // one box, C3) it makes the diagonal launch 0.0817 against 0.0925 ms and the panel launches 5.80 against 5.875 ms a
+  // step when each kernel runs alone -- and the two-lane step 5.938-5.962 against 5.928-5.934 ms: beside a
+  // neighbour's k-loop a phase costs its fp64 VECTOR instruction count (they share the matrix pipe), and the four-pivot
+  // form trades matrix instructions for vector ones (about 13 a pivot against 9).
+  factor16_acc<T, true>(t, y, tol_lane, lane, bad);
   // 1 / L[j][j] = 1 / sqrt(pivot j): the pivot sits on the diagonal of t.  One reciprocal square root per lane (the
   // square-root-then-divide form, evaluated for every register under a predicate, cost as much as the sweep itself)
   T dj;

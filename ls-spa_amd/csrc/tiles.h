@@ -392,11 +392,21 @@ __device__ __forceinline__ T bperm(int addr, T v) {
 // 1 for the multipliers at once and on the block's diagonal after the sweep.
 // A two-pivots-per-step form (2 x 2 pivot blocks: half the matrix instructions and reciprocals, one lane-pair exchange
 // per step) was written against the old chain and measured slower, 755 against 674 cycles per pair, and not kept.
-template <typename T>
+__device__ __forceinline__ void factor16_acc_b4(d4& t, d4& y, const double tol_lane, const int lane, int& bad);
+
+// SEQ: the one-pivot-a-step sweep also for fp64 (the panel kernels of k_factor.hip, see there; tools/factor16_probe.hip);
+// default for fp64: the four-pivot form below (the small-problem kernels)
+template <typename T, bool SEQ = false>
 __device__ __forceinline__ void factor16_acc(typename Tr<T>::acc_t& t, typename Tr<T>::acc_t& y, const double tol_lane,
                                              const int lane, int& bad) {
-  const int l15 = lane & 15, l4 = lane >> 4;
   constexpr bool F64 = sizeof(T) == 8;
+  if constexpr (F64 && !SEQ) {
+    // round 5: four pivots a step (factor16_acc_b4): 3844 against 5686 ticks a block alone on its SIMD, 4120 against
+    // 7184 with every SIMD of the chip at it (tools/factor16_probe.hip)
+    factor16_acc_b4(t, y, tol_lane, lane, bad);
+    return;
+  }
+  const int l15 = lane & 15, l4 = lane >> 4;
   unsigned replaced = 0;      // bit k: pivot k was not positive (or NaN)
   auto accept = [&](T d, const int k) -> T {      // pivot k against its threshold; 1 / pivot
     const double tol = bcast_lane<double>(tol_lane, k);
@@ -455,6 +465,94 @@ __device__ __forceinline__ void factor16_acc(typename Tr<T>::acc_t& t, typename 
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (Tr<T>::acc_row(l4, r) == l15 && ((replaced >> l15) & 1u)) t[r] = (T)1;
+  }
+}
+
+// ---- the same elimination four pivots at a time (fp64 result layout; round 5) -----------------------------------------
+// In the f64 result layout the four rows 4 q .. 4 q + 3 are the four lane groups of register q: as it stands the B operand
+// of a matrix instruction whose four k-slots are those rows.  With S the 4 x 4 diagonal block of those rows, S = M D M^T
+// (M unit lower triangular) and W = M^-1, the four sequential steps are
+//     P = W T[R, :]      the four pivot rows as the sequential sweep leaves them      (one instruction: A = W, B = t[q])
+//     Q = W Y[R, :]                                                                   (one instruction)
+//     T[m, :] -= sum_i (P_i[m] / d_i) P_i[:],   Y[m, :] -= sum_i (P_i[m] / d_i) Q_i[:]   for the rows m beyond the block
+// -- two more instructions whose A operand is -P / d read off the result registers of the first (an accumulator tile
+// read as an A operand is its own transpose) and whose B operands are P and Q as they stand.  Four instructions per four
+// pivots instead of eight, and -- what the chain is made of -- the 4 x 4 factorisation runs on ten values every lane
+// holds (read off the accumulators once per block), four reciprocals and ~35 dependent vector instructions per FOUR
+// pivots instead of nine per pivot behind a matrix instruction each.  Same contract as factor16_acc (what t and y hold
+// afterwards, thresholds, replaced pivots); the results differ from the sequential sweep's by rounding only.
+__device__ __forceinline__ void factor16_acc_b4(d4& t, d4& y, const double tol_lane, const int lane, int& bad) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+  unsigned replaced = 0;
+  auto block = [&](auto q_tag, auto last_tag) {
+    constexpr int q = decltype(q_tag)::value, c0 = 4 * q;
+    constexpr bool last = decltype(last_tag)::value;
+    double s[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) s[i][j] = bcast_lane<double>(t[q], (c0 + j) + 16 * i);
+    double rinv[4], m[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double d = s[j][j];
+      const double tol = bcast_lane<double>(tol_lane, c0 + j);
+      if (!(d > tol)) {
+        d = 1.0;
+        replaced |= 1u << (c0 + j);
+      }
+      rinv[j] = fast_recip<double>(d);
+#pragma unroll
+      for (int i = j + 1; i < 4; ++i) m[i][j] = s[i][j] * rinv[j];
+#pragma unroll
+      for (int i = j + 1; i < 4; ++i)
+#pragma unroll
+        for (int k = j + 1; k <= i; ++k) s[i][k] = fma(-m[i][j], s[k][j], s[i][k]);
+    }
+    // W = M^-1 (unit lower triangular): w[i][j] = -sum_{k = j .. i-1} m[i][k] w[k][j]
+    double w[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w[i][i] = 1.0;
+#pragma unroll
+      for (int j = i - 1; j >= 0; --j) {
+        double v = -m[i][j];
+#pragma unroll
+        for (int k = j + 1; k < i; ++k) v = fma(-m[i][k], w[k][j], v);
+        w[i][j] = v;
+      }
+    }
+    // A operand of the two transforms: lane (l15 = row i of the result, l4 = k-slot) = W[i][l4] for i < 4, k <= i
+    double aw = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k <= i; ++k)
+        if (l15 == i && l4 == k) aw = w[i][k];
+    const double bt = (l15 >= c0) ? t[q] : 0.0;      // columns left of the block are never read again (and may be anything)
+    const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+    const d4 pa = Tr<double>::mfma(aw, bt, z4);       // pa[0]: lane (l15 = n, l4 = i) = P_i[n]
+    const d4 qa = Tr<double>::mfma(aw, y[q], z4);     // qa[0]: Q_i[n]
+    if (l15 >= c0) t[q] = pa[0];
+    y[q] = qa[0];
+    if constexpr (!last) {
+      const double ri = (l4 == 0) ? rinv[0] : (l4 == 1) ? rinv[1] : (l4 == 2) ? rinv[2] : rinv[3];
+      const double a2 = (l15 > c0 + 3) ? -pa[0] * ri : 0.0;           // -P_i[m] / d_i for the rows m beyond the block
+      const double b2 = (l15 > c0 + l4) ? pa[0] : 0.0;                // P_i[n] right of its own diagonal
+      t = Tr<double>::mfma(a2, b2, t);
+      y = Tr<double>::mfma(a2, qa[0], y);
+    }
+  };
+  using std::integral_constant;
+  block(integral_constant<int, 0>(), integral_constant<bool, false>());
+  block(integral_constant<int, 1>(), integral_constant<bool, false>());
+  block(integral_constant<int, 2>(), integral_constant<bool, false>());
+  block(integral_constant<int, 3>(), integral_constant<bool, true>());
+  if (replaced) {             // numerically not positive definite: flagged, unit pivots on the diagonal
+    bad = 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (Tr<double>::acc_row(l4, r) == l15 && ((replaced >> l15) & 1u)) t[r] = 1.0;
   }
 }
 
