@@ -57,7 +57,7 @@ def parse():
                     help="transport of the all-reduce with several ranks: RCCL through the C ABI, or torch.distributed")
     ap.add_argument("--lookahead", type=int, default=0,
                     help="steps whose orderings are launched as one GPU batch and then accumulated / all-reduced / merged "
-                         "step by step (what ls_spa(lookahead=k) does); 0 = auto: 8 for p <= 126, 4 when a rank's step "
+                         "step by step (what ls_spa(lookahead=k) does); 0 = auto: 16 for p <= 126, 4 when a rank's step "
                          "has <= 32 samples, else 1")
     ap.add_argument("--lanes", type=int, choices=(0, 1, 2), default=0,
                     help="batches in flight on the engine (lsspa_set_lanes): 2 = the next step's kernels start when this "
@@ -511,7 +511,7 @@ def main():
 
     # auto: a step that fills a fraction of the GPU (few samples per rank, or the one-workgroup-per-ordering kernel
     # of small problems) is launched in groups
-    D = args.lookahead if args.lookahead > 0 else (8 if p + 1 <= 128 else (4 if B_rank <= 32 else 1))
+    D = args.lookahead if args.lookahead > 0 else (16 if p + 1 <= 128 else (4 if B_rank <= 32 else 1))
 
     class Steps:
         """step(k) = one batch of b_rank samples into the statistics.  With d > 1 the kernels of d consecutive steps
@@ -548,10 +548,17 @@ def main():
                     if eng.lanes == 2:
                         self.launch(g + 1)       # the second lane holds the next group: its upload and kernels run
                                                  # while this group is accumulated step by step
-                eng.collect_batch(self.tickets[g], want_lifts=False, accumulate=acc, first=j * self.b_rank,
-                                  count=self.b_rank)
-                if j == self.d - 1 or k == self.end - 1:
-                    del self.tickets[g]
+                if not multi:
+                    # one rank: the group's steps are folded by ONE library call at its first step -- every step's
+                    # batch still merged by itself, in order (lsspa_lift_collect_chunks; at p <= 128 one launch)
+                    if j == 0:
+                        n_g = min(self.d, self.end - (self.base + g * self.d))
+                        eng.collect_chunks(self.tickets.pop(g), 0, self.b_rank, n_g, accumulate=2)
+                else:
+                    eng.collect_batch(self.tickets[g], want_lifts=False, accumulate=acc, first=j * self.b_rank,
+                                      count=self.b_rank)
+                    if j == self.d - 1 or k == self.end - 1:
+                        del self.tickets[g]
             if multi:
                 comm.allreduce_pending(eng)
                 eng.merge()
@@ -560,6 +567,10 @@ def main():
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; returns this rank's
         seconds, the max and the min over the ranks."""
         eng.reset_stats()
+        if step.d > 1:
+            # the workspace of a whole look-ahead group before anything is timed (the warm-up steps may be fewer than a
+            # group: a first full group inside the timed region would allocate there)
+            eng.discard_batch(eng.launch_batch(step.perms[0:step.d].reshape(-1, p), True))
         step.region(0, n_warm)
         for k in range(n_warm):
             step(k)

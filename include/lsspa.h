@@ -130,6 +130,13 @@ int lsspa_lift_batch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t an
 int lsspa_lift_launch(lsspa_ctx* ctx, const int32_t* perms, int32_t B, int32_t antithetical, int32_t* ticket);
 int lsspa_lift_collect(lsspa_ctx* ctx, int32_t ticket, int32_t first, int32_t count, double* lifts_out,
                        int32_t accumulate);
+/* n_chunks consecutive parts of `chunk` samples each, from sample `first` on, folded one after the other: the effect of
+ * n_chunks calls of lsspa_lift_collect(ticket, first + c chunk, chunk, NULL, accumulate).  With accumulate = 2 on a small
+ * problem (p <= 128, chunks of up to 512 samples, at most 32 of them, one rank) the parts' statistics are ONE launch
+ * (every part still merged by itself, in order: the same numbers to the last bit) -- at p = 100 a part's own launch is
+ * a fifth of its step and cannot hide behind the next batch's kernel. */
+int lsspa_lift_collect_chunks(lsspa_ctx* ctx, int32_t ticket, int32_t first, int32_t chunk, int32_t n_chunks,
+                              int32_t accumulate);
 int lsspa_lift_discard(lsspa_ctx* ctx, int32_t ticket);
 /* 1 (default): every batch runs on the context's stream, one after the other.  2: successive batches alternate
  * between two workspaces on two streams, staggered by half a batch, so that the memory-bound stages (gather, lifts)
@@ -204,7 +211,7 @@ int lsspa_error_quantiles(lsspa_ctx* ctx, double* feature_errors, double* overal
  *   lsspa_error_running_draws   : x of this context's samples into the draws buffer (lsspa_error_buffer): with
  *                                 several ranks all-reduce it (lsspa_error_allreduce) -- x is linear in (D, s)
  *   lsspa_error_quantiles_enqueue / lsspa_error_result : the quantile kernels, then feature errors, overall error, the
- *                                 running mean and n copied into pinned slot `slot` (0 .. 31) behind an event -- nothing
+ *                                 running mean and n copied into pinned slot `slot` (0 .. 63) behind an event -- nothing
  *                                 waits.  lsspa_error_result reads a slot: wait != 0 blocks on its event, wait == 0
  *                                 polls (*ready = 0: not yet).  This is what lets the driver evaluate the stop rule of
  *                                 check k while the samples of check k + 1 are already running (they are dropped on a
@@ -297,6 +304,13 @@ int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);
 int lsspa_debug_fail_alloc(lsspa_ctx* ctx, int32_t nth);
 /* use the packed (upper-triangle) form of lsspa_stats_allreduce from this p on (default 2048) */
 int lsspa_debug_pack_from(lsspa_ctx* ctx, int32_t p_min);
+/* overwrite the R^2 the batches' sums are checked against (LSSPA_INFO_SUM; set by lsspa_full_fit): a test makes the
+ * check fire on a healthy engine with it */
+int lsspa_debug_set_r2(lsspa_ctx* ctx, double r2);
+/* 1 if every row of perms [B][p] is a permutation of 0..p-1, else 0 -- the check every batch launch makes on the host
+ * (csrc/host_perms.cpp: 128-bit sets by AVX2 for 8 <= p <= 128, a stamp array otherwise); plain != 0: the stamp loop
+ * alone.  No context, no GPU: host code only. */
+int lsspa_debug_check_perms(const int32_t* perms, int32_t B, int32_t p, int32_t plain);
 int lsspa_mfma_probe(lsspa_ctx* ctx, const double* A16x4, const double* B4x16, double* D16x16, int32_t dtype);
 /* factor one ordering and copy the padded factor(s) out: L [p_pad][p_pad] (train),
  * Lt [p_pad][p_pad] (test, tri mode only, else untouched), V [n_iblk*64][m_pad] */

@@ -18,7 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIBNAME = "liblsspa_hip.so"
-SOURCES = ["k_factor.hip", "k_small.hip", "k_lift.hip", "k_gram.hip", "k_error.hip", "lsspa_comm.hip", "lsspa_api.hip"]
+SOURCES = ["k_factor.hip", "k_small.hip", "k_lift.hip", "k_gram.hip", "k_error.hip", "lsspa_comm.hip", "lsspa_api.hip",
+           "host_perms.cpp"]
 HEADERS = ["tiles.h", "kernels.h", "comm.h", os.path.join("..", "..", "include", "lsspa.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # developer A/B builds: LSSPA_CXXFLAGS="-DSOMETHING" python ls-spa_amd/build.py --force --out ls-spa_amd/lib/ab/new.so
@@ -55,8 +56,11 @@ def build_native(force: bool = False, verbose: bool = True, out: str | None = No
     hipcc = _hipcc()
 
     def compile_one(src: str) -> str:
-        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".o").replace(".cpp", ".o"))
+        if src.endswith(".cpp"):      # host-only C++ (no device pass: x86 intrinsics inside)
+            cmd = [hipcc, "-x", "c++", "-O3", "-std=c++17", "-fPIC", "-Wall", "-c", os.path.join(CSRC, src), "-o", obj]
+        else:
+            cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void draws_kernel(const double* __restrict_
 }
 
 // Xi [1024][n_pad] for sample ids first_id + k * stride, k < count; columns k >= count are zero
-__global__ __launch_bounds__(256) void xi_fill_kernel(uint64_t seed, int64_t first_id, int64_t stride, int count,
-                                                      int n_pad, double* __restrict__ Xi) {
+__device__ __forceinline__ void xi_fill_body(uint64_t seed, int64_t first_id, int64_t stride, int count, int n_pad,
+                                             double* __restrict__ Xi) {
   const int k = blockIdx.x * 256 + threadIdx.x;   // column (sample)
   const int j = blockIdx.y;                       // Philox call of the sample
   if (k >= n_pad) return;
@@ -153,6 +153,24 @@ __global__ __launch_bounds__(256) void xi_fill_kernel(uint64_t seed, int64_t fir
   Xi[(int64_t)(d + 32) * n_pad + k] = z1;
 }
 
+__global__ __launch_bounds__(256) void xi_fill_kernel(uint64_t seed, int64_t first_id, int64_t stride, int count,
+                                                      int n_pad, double* __restrict__ Xi) {
+  xi_fill_body(seed, first_id, stride, count, n_pad, Xi);
+}
+
+// the same for the chunks of a group (blockIdx.z), every chunk with its own [1024][n_pad] block of the workspace
+__global__ __launch_bounds__(256) void xi_fill_group_kernel(uint64_t seed, int64_t stride, EstChunks ch,
+                                                            double* __restrict__ Xi) {
+  const int c = blockIdx.z;
+  xi_fill_body(seed, ch.first_id[c], stride, ch.count[c], ch.n_pad[c], Xi + ch.xi_off[c]);
+}
+
+// One draw's entry from the running sums; the fused multiply-add spelled out, so that every kernel that forms it
+// (one check or a group's) rounds it the same way whatever the compiler would have contracted.
+__device__ __forceinline__ double draw_value(double D, double s, double mean, double scale) {
+  return __builtin_fma(-s, mean, D) * scale;
+}
+
 // x[d][a] = (D[d][a] - s[d] mean[a]) * scale; padding columns zero
 __global__ __launch_bounds__(256) void running_draws_kernel(const double* __restrict__ D, const double* __restrict__ s,
                                                             const double* __restrict__ mean, double scale, int p,
@@ -160,7 +178,7 @@ __global__ __launch_bounds__(256) void running_draws_kernel(const double* __rest
   const int d = blockIdx.y;
   const int a = blockIdx.x * 256 + threadIdx.x;
   if (a >= ld) return;
-  draws[(int64_t)d * ld + a] = (a < p) ? (D[(int64_t)d * ld + a] - s[d] * mean[a]) * scale : 0.0;
+  draws[(int64_t)d * ld + a] = (a < p) ? draw_value(D[(int64_t)d * ld + a], s[d], mean[a], scale) : 0.0;
 }
 
 // Where the quantile kernels take the draws from: the draws buffer (after lsspa_error_draws / _running_draws and, with
@@ -174,7 +192,7 @@ struct DrawSrc {
   double scale;
   int ld;
   __device__ __forceinline__ double at(int d, int a) const {
-    return draws ? draws[(int64_t)d * ld + a] : (D[(int64_t)d * ld + a] - s[d] * mean[a]) * scale;
+    return draws ? draws[(int64_t)d * ld + a] : draw_value(D[(int64_t)d * ld + a], s[d], mean[a], scale);
   }
 };
 
@@ -184,7 +202,7 @@ __global__ __launch_bounds__(256) void row_norms_kernel(DrawSrc src, int p, doub
   double v = 0.0;
   for (int a = lane; a < p; a += 64) {
     const double x = src.at(d, a);
-    v += x * x;
+    v = __builtin_fma(x, x, v);
   }
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
@@ -193,10 +211,10 @@ __global__ __launch_bounds__(256) void row_norms_kernel(DrawSrc src, int p, doub
 
 // numpy.quantile(v, q) with the default 'linear' method on ND values.  out = [feature errors (p), overall error] and,
 // with pack_mean, behind them [running mean (p), n]: one copy then brings a whole check to the host.
-__global__ __launch_bounds__(512) void quantile_kernel(DrawSrc src, const double* __restrict__ norms, int p, double q,
-                                                       double* __restrict__ out /*[p + 1] or [2 p + 2]*/,
-                                                       const double* __restrict__ pack_mean,
-                                                       const double* __restrict__ pack_n) {
+__device__ __forceinline__ void quantile_body(const DrawSrc& src, const double* __restrict__ norms, int p, double q,
+                                              double* __restrict__ out /*[p + 1] or [2 p + 2]*/,
+                                              const double* __restrict__ pack_mean,
+                                              const double* __restrict__ pack_n) {
   __shared__ double s[ND];
   const int a = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < ND; i += 512) s[i] = (a < p) ? fabs(src.at(i, a)) : norms[i];
@@ -236,15 +254,38 @@ __global__ __launch_bounds__(512) void quantile_kernel(DrawSrc src, const double
   }
 }
 
+__global__ __launch_bounds__(512) void quantile_kernel(DrawSrc src, const double* __restrict__ norms, int p, double q,
+                                                       double* __restrict__ out, const double* __restrict__ pack_mean,
+                                                       const double* __restrict__ pack_n) {
+  quantile_body(src, norms, p, q, out, pack_mean, pack_n);
+}
+
+// The checks of a group's chunks in one launch (blockIdx.y = the check): each reads the estimator's sums, the running
+// mean and n as they stood after ITS chunk (the snapshots the group kernels keep) and writes into its own result slot.
+__global__ __launch_bounds__(512) void quantile_group_kernel(EstChecks ck, const double* __restrict__ Dsnap,
+                                                             const double* __restrict__ ssnap,
+                                                             const double* __restrict__ mean_snap,
+                                                             const double* __restrict__ n_snap,
+                                                             const double* __restrict__ norms, int p, int ld, double q,
+                                                             double* __restrict__ res) {
+  const int c = ck.chunk[blockIdx.y];
+  const DrawSrc src{nullptr, Dsnap + (int64_t)c * ND * ld, ssnap + (int64_t)c * ND, mean_snap + (int64_t)c * p,
+                    ck.scale[blockIdx.y], ld};
+  quantile_body(src, norms + (int64_t)c * ND, p, q, res + (int64_t)ck.slot[blockIdx.y] * (2 * p + 2), src.mean,
+                n_snap + c);
+}
+
 // D[1024][ld] += Xi L and s += Xi 1 for ONE chunk of samples (tens to a few hundred): the 64 x 128-tile kernel above
 // has 16 workgroups per feature tile and walks the samples 16 at a time between two barriers -- 22 us at p = 100, 128
 // samples, all of it latency.  Here a workgroup owns 16 draws x 128 features (64 workgroups per feature tile), its four
 // waves split the samples among them, every lane fetches its own matrix-instruction operands straight from memory (no
 // staging, no barrier in the loop), and the four partial tiles meet once in LDS.
-__global__ __launch_bounds__(256) void acc_small_kernel(const double* __restrict__ Xi, int n_pad,
-                                                        const double* __restrict__ L, int ldl, int k_valid, int c_valid,
-                                                        int p, double* __restrict__ D, int ld,
-                                                        double* __restrict__ rowsum_acc) {
+// PARTS: the chunk's own product and row sums are stored (a group's chunks side by side, prefix_norms_kernel adds them
+// up in order) instead of added to D and s -- the same numbers either way: D + v here, D + P there.
+template <bool PARTS>
+__device__ __forceinline__ void acc_small_body(const double* __restrict__ Xi, int n_pad, const double* __restrict__ L,
+                                               int ldl, int k_valid, int c_valid, int p, double* __restrict__ D, int ld,
+                                               double* __restrict__ rowsum_acc) {
   __shared__ double part[4 * 8 * 4 * 64];   // [wave][feature tile][r][lane]
   __shared__ double s_rs[4][16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -297,10 +338,79 @@ __global__ __launch_bounds__(256) void acc_small_kernel(const double* __restrict
       double v = 0.0;
 #pragma unroll
       for (int ww = 0; ww < 4; ++ww) v += part[((ww * 8 + t) * 4 + r) * 64 + lane];
-      if (c < p) D[(int64_t)(d0 + acc_row(l4, r)) * ld + c] += v;
+      if (c < p) {
+        double* dst = D + (int64_t)(d0 + acc_row(l4, r)) * ld + c;
+        *dst = PARTS ? v : *dst + v;
+      }
     }
   }
-  if (blockIdx.y == 0 && tid < 16) rowsum_acc[d0 + tid] += (s_rs[0][tid] + s_rs[1][tid]) + (s_rs[2][tid] + s_rs[3][tid]);
+  if (blockIdx.y == 0 && tid < 16) {
+    const double rsum = (s_rs[0][tid] + s_rs[1][tid]) + (s_rs[2][tid] + s_rs[3][tid]);
+    rowsum_acc[d0 + tid] = PARTS ? rsum : rowsum_acc[d0 + tid] + rsum;
+  }
+}
+
+__global__ __launch_bounds__(256) void acc_small_kernel(const double* __restrict__ Xi, int n_pad,
+                                                        const double* __restrict__ L, int ldl, int k_valid, int c_valid,
+                                                        int p, double* __restrict__ D, int ld,
+                                                        double* __restrict__ rowsum_acc) {
+  acc_small_body<false>(Xi, n_pad, L, ldl, k_valid, c_valid, p, D, ld, rowsum_acc);
+}
+
+// the products of a group's chunks side by side (blockIdx.z = chunk): P[c] = Xi_c L_c [1024][ld], S[c] = Xi_c 1
+__global__ __launch_bounds__(256) void acc_group_kernel(EstChunks ch, const double* __restrict__ Xi,
+                                                        const double* __restrict__ lifts, int p, int ld,
+                                                        double* __restrict__ P, double* __restrict__ S) {
+  const int c = blockIdx.z;
+  acc_small_body<true>(Xi + ch.xi_off[c], ch.n_pad[c], lifts + (int64_t)ch.first[c] * p, p, ch.count[c], p, p,
+                       P + (int64_t)c * ND * ld, ld, S + (int64_t)c * ND);
+}
+
+// D and s advanced chunk by chunk from the group's products, in order (D_c = D_{c-1} + P_c, what acc_small_kernel does
+// chunk after chunk), every state kept for the check that belongs to it, and the draws' row norms of every state that
+// has a check (scale != 0) as row_norms_kernel forms them: one wave per draw, lanes over the features (p <= 128).
+__global__ __launch_bounds__(256) void prefix_norms_kernel(EstChunks ch, const double* __restrict__ P,
+                                                           const double* __restrict__ S, double* __restrict__ D,
+                                                           double* __restrict__ s, double* __restrict__ Dsnap,
+                                                           double* __restrict__ ssnap,
+                                                           const double* __restrict__ mean_snap, int p, int ld,
+                                                           double* __restrict__ norms) {
+  const int lane = threadIdx.x & 63, d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int a0 = lane, a1 = lane + 64;
+  double r0 = a0 < p ? D[(int64_t)d * ld + a0] : 0.0, r1 = a1 < p ? D[(int64_t)d * ld + a1] : 0.0;
+  double sr = s[d];
+  for (int c = 0; c < ch.n; ++c) {
+    const int64_t o = ((int64_t)c * ND + d) * ld;
+    if (a0 < p) {
+      r0 = r0 + P[o + a0];
+      Dsnap[o + a0] = r0;
+    }
+    if (a1 < p) {
+      r1 = r1 + P[o + a1];
+      Dsnap[o + a1] = r1;
+    }
+    sr = sr + S[(int64_t)c * ND + d];
+    if (lane == 0) ssnap[(int64_t)c * ND + d] = sr;
+    const double scale = ch.scale[c];
+    if (scale != 0.0) {
+      const double* mean = mean_snap + (int64_t)c * p;
+      double v = 0.0;
+      if (a0 < p) {
+        const double x = draw_value(r0, sr, mean[a0], scale);
+        v = __builtin_fma(x, x, v);
+      }
+      if (a1 < p) {
+        const double x = draw_value(r1, sr, mean[a1], scale);
+        v = __builtin_fma(x, x, v);
+      }
+#pragma unroll
+      for (int o2 = 1; o2 < 64; o2 <<= 1) v += __shfl_xor(v, o2, 64);
+      if (lane == 0) norms[(int64_t)c * ND + d] = sqrt(v);
+    }
+  }
+  if (a0 < p) D[(int64_t)d * ld + a0] = r0;
+  if (a1 < p) D[(int64_t)d * ld + a1] = r1;
+  if (lane == 0) s[d] = sr;
 }
 
 hipError_t launch_error_draws(const double* Xi, int ldxi, const double* H, int ldh, int n_pad,
@@ -373,6 +483,39 @@ hipError_t launch_error_quantiles_running(const double* D, const double* s, cons
                                           int p, double* norms, double* out, const double* pack_n, hipStream_t st) {
   if (p < 1 || ld < p) return hipErrorInvalidValue;
   return launch_quantiles(DrawSrc{nullptr, D, s, mean, scale, ld}, p, norms, out, mean, pack_n, st);
+}
+
+// A group's chunks into the running estimator and their checks, five launches whatever the number of chunks (p <= 128):
+// the normals of every chunk, the chunks' products side by side, the ordered sums with a snapshot per chunk and the
+// row norms, then all the checks' quantiles.  Xi: the workspace (sum over the chunks of 1024 x n_pad doubles); P, Dsnap:
+// [n][1024][ld]; S, ssnap, norms: [n][1024]; mean_snap [n][p] / n_snap [n]: the statistics after every chunk
+// (launch_stats_small_multi); res: the result slots ([2 p + 2] each).
+hipError_t launch_error_group(uint64_t seed, int64_t stride, const EstChunks& ch, const EstChecks& ck, double* Xi,
+                              const double* lifts, int p, int ld, double* P, double* S, double* D, double* s,
+                              double* Dsnap, double* ssnap, const double* mean_snap, const double* n_snap,
+                              double* norms, double* res, hipStream_t st) {
+  if (p < 1 || p > 128 || ld != 128 || ch.n < 1 || ch.n > EstChunks::MAX || ck.n < 0 || ck.n > ch.n || stride < 1)
+    return hipErrorInvalidValue;
+  int pad_max = 0;
+  for (int c = 0; c < ch.n; ++c) {
+    if (ch.count[c] < 1 || ch.n_pad[c] < KCH || ch.n_pad[c] % KCH != 0 || ch.count[c] > ch.n_pad[c] ||
+        ch.first_id[c] < 0 || ch.first[c] < 0 || ch.xi_off[c] < 0)
+      return hipErrorInvalidValue;
+    pad_max = ch.n_pad[c] > pad_max ? ch.n_pad[c] : pad_max;
+  }
+  for (int k = 0; k < ck.n; ++k)
+    if (ck.chunk[k] < 0 || ck.chunk[k] >= ch.n || ck.slot[k] < 0 || ch.scale[ck.chunk[k]] != ck.scale[k])
+      return hipErrorInvalidValue;
+  hipLaunchKernelGGL(xi_fill_group_kernel, dim3((pad_max + 255) / 256, ND / 2, ch.n), dim3(256), 0, st, seed, stride, ch,
+                     Xi);
+  hipLaunchKernelGGL(acc_group_kernel, dim3(ND / 16, 1, ch.n), dim3(256), 0, st, ch, (const double*)Xi, lifts, p, ld, P,
+                     S);
+  hipLaunchKernelGGL(prefix_norms_kernel, dim3(ND / 4), dim3(256), 0, st, ch, (const double*)P, (const double*)S, D, s,
+                     Dsnap, ssnap, mean_snap, p, ld, norms);
+  if (ck.n > 0)
+    hipLaunchKernelGGL(quantile_group_kernel, dim3(p + 1, ck.n), dim3(512), 0, st, ck, (const double*)Dsnap,
+                       (const double*)ssnap, mean_snap, n_snap, (const double*)norms, p, ld, 0.95, res);
+  return hipGetLastError();
 }
 
 }  // namespace lsspa

@@ -346,15 +346,16 @@ __global__ __launch_bounds__(256) void stats_reduce_kernel(const double* __restr
 struct TileMoments {
   double q, sa, sb;
 };
-__device__ __forceinline__ TileMoments small_tile_moments(const double* __restrict__ lifts,
-                                                          const double* __restrict__ mean, int n_samples, int p,
-                                                          int ti, int tj) {
+// (lane_sa / lane_sb, optional: the tile's column sums once more, indexed by the lane's own column l15 -- what a
+// workgroup needs to advance the means it holds per lane, stats_small_multi_kernel)
+__device__ __forceinline__ TileMoments small_tile_moments_mu(const double* __restrict__ lifts, const double mua,
+                                                             const double mub, int n_samples, int p, int ti, int tj,
+                                                             double* lane_sa = nullptr, double* lane_sb = nullptr) {
   __shared__ double s_acc[4][256];
   __shared__ double s_sa[4][16], s_sb[4][16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int a = 16 * ti + l15, b = 16 * tj + l15;
   const int ac = a < p ? a : p - 1, bc = b < p ? b : p - 1;     // clamped addresses, value selected afterwards
-  const double mua = mean[ac], mub = mean[bc];
   // samples of this wave: a contiguous quarter, a multiple of four long
   const int per = ((n_samples + 15) / 16) * 4;
   const int s_lo = wv * per, s_hi = min(n_samples, s_lo + per);
@@ -397,7 +398,17 @@ __device__ __forceinline__ TileMoments small_tile_moments(const double* __restri
   m.q = ((s_acc[0][tid] + s_acc[1][tid]) + s_acc[2][tid]) + s_acc[3][tid];
   m.sa = ((s_sa[0][er] + s_sa[1][er]) + s_sa[2][er]) + s_sa[3][er];
   m.sb = ((s_sb[0][ec] + s_sb[1][ec]) + s_sb[2][ec]) + s_sb[3][ec];
+  if (lane_sa) *lane_sa = ((s_sa[0][l15] + s_sa[1][l15]) + s_sa[2][l15]) + s_sa[3][l15];
+  if (lane_sb) *lane_sb = ((s_sb[0][l15] + s_sb[1][l15]) + s_sb[2][l15]) + s_sb[3][l15];
   return m;
+}
+
+__device__ __forceinline__ TileMoments small_tile_moments(const double* __restrict__ lifts,
+                                                          const double* __restrict__ mean, int n_samples, int p,
+                                                          int ti, int tj) {
+  const int l15 = threadIdx.x & 15;
+  const int a = 16 * ti + l15, b = 16 * tj + l15;
+  return small_tile_moments_mu(lifts, mean[a < p ? a : p - 1], mean[b < p ? b : p - 1], n_samples, p, ti, tj);
 }
 
 __device__ __forceinline__ void tile_of(int t, int& ti, int& tj) {   // lower tiles, row by row
@@ -478,6 +489,73 @@ hipError_t launch_stats_small_fused(const double* lifts, const double* mean, con
   const int t16 = (p + 15) / 16, n_tiles = t16 * (t16 + 1) / 2;
   hipLaunchKernelGGL(stats_small_fused_kernel, dim3(n_tiles), dim3(256), 0, st, lifts, mean, state, mean_out, state_out,
                      M2, n_samples, p);
+  return hipGetLastError();
+}
+
+// SEVERAL chunks of samples folded and merged one after the other in ONE launch (round 5): at p = 100 a chunk is 25 us
+// of lift kernel and its statistics launch 4.4 us plus the gap of a dependent launch -- a fifth of the step, and not to
+// be hidden behind the next group's kernel (a small_reg workgroup pair leaves no room on its CU).  Nothing has to meet
+// between two chunks except the running mean and n, and every tile's workgroup can advance those itself: it sums the
+// columns of its own two blocks anyway, with the same operands in the same order as the diagonal tiles do, so the means it
+// carries per lane are bit for bit the ones the one-chunk kernel would have read back from memory.  The result -- M2, mean,
+// n after the last chunk -- is that of the one-chunk launches in sequence, to the last bit (tests).  mean_snap / n_snap:
+// the running mean and n after every chunk ([n_chunks][p], [n_chunks]): what the check of that chunk reads.
+__global__ __launch_bounds__(256) void stats_small_multi_kernel(const double* __restrict__ lifts,
+                                                                const double* __restrict__ mean,
+                                                                const double* __restrict__ state,
+                                                                double* __restrict__ mean_out,
+                                                                double* __restrict__ state_out, double* __restrict__ M2,
+                                                                StatsChunks ch, int p, double* __restrict__ mean_snap,
+                                                                double* __restrict__ n_snap) {
+  int ti, tj;
+  tile_of(blockIdx.x, ti, tj);
+  const bool diag = ti == tj;
+  const int tid = threadIdx.x, er = tid >> 4, ec = tid & 15, l15 = tid & 15;
+  const int ai = 16 * ti + er, bi = 16 * tj + ec;
+  const bool live = ai < p && bi < p;
+  const int64_t o = live ? (int64_t)ai * p + bi : 0;
+  double m2 = M2[o];
+  double n = state[0];
+  const int a = 16 * ti + l15, b = 16 * tj + l15;
+  double mua = mean[a < p ? a : p - 1], mub = mean[b < p ? b : p - 1];     // per lane: the columns it subtracts from
+  double mu_row = mean[ai < p ? ai : p - 1];                               // per thread: the mean a diagonal tile writes
+  for (int c = 0; c < ch.n; ++c) {
+    const double nb = (double)ch.count[c];
+    double lsa, lsb;
+    const TileMoments m = small_tile_moments_mu(lifts + (int64_t)ch.first[c] * p, mua, mub, ch.count[c], p, ti, tj, &lsa,
+                                                &lsb);
+    const double coef = n * nb / (n + nb) - nb;
+    const double inv = 1.0 / nb;
+    m2 = m2 + (m.q + coef * ((m.sa * inv) * (m.sb * inv)));       // as stats_small_fused_kernel rounds it
+    const double wgt = 1.0 / (n + nb);
+    mua = mua + lsa * wgt;
+    mub = mub + lsb * wgt;
+    mu_row = mu_row + m.sa * wgt;
+    n = n + nb;
+    if (mean_snap && diag && ec == 0 && ai < p) mean_snap[(int64_t)c * p + ai] = mu_row;
+    if (n_snap && blockIdx.x == 0 && tid == 0) n_snap[c] = n;
+    __syncthreads();      // the moments' LDS tiles are written again by the next chunk
+  }
+  if (live) {
+    M2[o] = m2;
+    if (!diag) M2[(int64_t)bi * p + ai] = m2;
+  }
+  if (diag && ec == 0 && ai < p) mean_out[ai] = mu_row;
+  if (blockIdx.x == 0 && tid == 0) {
+    state_out[0] = n;
+    state_out[1] = 0.0;
+  }
+}
+
+hipError_t launch_stats_small_multi(const double* lifts, const double* mean, const double* state, double* mean_out,
+                                    double* state_out, double* M2, const StatsChunks& ch, int p, double* mean_snap,
+                                    double* n_snap, hipStream_t st) {
+  if (ch.n < 1 || ch.n > StatsChunks::MAX) return hipErrorInvalidValue;
+  for (int c = 0; c < ch.n; ++c)
+    if (!stats_small_fusable(ch.count[c], p) || ch.first[c] < 0) return hipErrorInvalidValue;
+  const int t16 = (p + 15) / 16, n_tiles = t16 * (t16 + 1) / 2;
+  hipLaunchKernelGGL(stats_small_multi_kernel, dim3(n_tiles), dim3(256), 0, st, lifts, mean, state, mean_out, state_out,
+                     M2, ch, p, mean_snap, n_snap);
   return hipGetLastError();
 }
 

@@ -153,10 +153,11 @@ __global__ __launch_bounds__(512) void small_p_kernel(SmallArgs a) {
   const int half = wv >> 2, w = wv & 3, t2 = tid & 255;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int ord = blockIdx.x;
-  const int32_t* perm = a.perms + (int64_t)ord * p;
+  const int32_t* perm = a.perms + (int64_t)(a.fwd_only ? ord >> 1 : ord) * p;
+  const bool backwards = a.fwd_only && (ord & 1);
 
   SSTAMP(0);
-  if (tid < 128) s_perm[tid] = (tid < p) ? perm[tid] : 0;
+  if (tid < 128) s_perm[tid] = (tid < p) ? perm[backwards ? p - 1 - tid : tid] : 0;
   if (tid == 0) s_bad = 0;
   __syncthreads();
   SSTAMP(1);
@@ -442,10 +443,11 @@ void small_reg_kernel(SmallArgs a) {
   const int l15 = lane & 15, l4 = lane >> 4;
   const int p = a.p, pr = p & 15;                   // p = 16 (NB - 1) + pr: the augmented row sits in the last block row
   const int ord = blockIdx.x;
-  const int32_t* perm = a.perms + (int64_t)ord * p;
+  const int32_t* perm = a.perms + (int64_t)(a.fwd_only ? ord >> 1 : ord) * p;
+  const bool backwards = a.fwd_only && (ord & 1);
   RSTAMP(0);
   {
-    const int src = (tid < p) ? perm[tid] : 0;
+    const int src = (tid < p) ? perm[backwards ? p - 1 - tid : tid] : 0;
     s_perm[tid] = src;
     s_z[tid] = a.s[0][src];          // the permuted right-hand sides g_pi, h_pi (row p of the two matrices) until the
     s_y[tid] = a.s[1][src];          // factorisations have produced z and y~, which take their place
@@ -729,6 +731,7 @@ void small_reg_kernel(SmallArgs a) {
       __builtin_amdgcn_wave_barrier();
     }
     RSTAMP(4);
+    double lsum = 0.0;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int j = lane + 64 * pass;
@@ -737,6 +740,20 @@ void small_reg_kernel(SmallArgs a) {
         double* dst = a.lifts + (int64_t)(ord / a.per_sample) * p + s_perm[j];
         if (a.per_sample == 2) atomicAdd(dst, 0.5 * lift);   // the pair's two terms commute: order-independent sum
         else *dst = lift;
+        lsum += lift;
+      }
+    }
+    // the ordering's lifts telescope to the full model's R^2 (sum_check_kernel in k_lift.hip makes this check per
+    // sample by a launch of its own; here the wave holds all p lifts, and a dependent launch is 4 % of a p = 100 group)
+    if (a.sum_tol >= 0.0) {
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) lsum += __shfl_xor(lsum, o, 64);
+      if (lane == 0) {
+        double dev = fabs(lsum - a.r2);
+        if (!(dev == dev)) dev = __longlong_as_double(0x7ff0000000000000ll);
+        if (!(dev <= a.sum_tol)) atomicOr(a.info, 8);                  // LSSPA_INFO_SUM
+        if (dev > a.sum_quiet)       // non-negative doubles order like their bit patterns
+          atomicMax(reinterpret_cast<unsigned long long*>(a.info + 2), (unsigned long long)__double_as_longlong(dev));
       }
     }
   }
@@ -751,6 +768,9 @@ size_t small_p_lds_bytes(int nb) {
 
 bool small_p_eligible(int p) { return p >= 1 && p + 1 <= 128; }
 
+// does the kernel launch_small_p picks check the orderings' sums itself (a.sum_tol >= 0)?
+bool small_p_checks_sum(const SmallArgs& a) { return a.variant == 0 && a.nb <= 7; }
+
 template <int NB>
 static hipError_t launch_small_reg(const SmallArgs& a, hipStream_t st) {
   const size_t bytes = (size_t)small_reg_lds_doubles(NB) * sizeof(double) + 128 * sizeof(int32_t);
@@ -763,7 +783,7 @@ static hipError_t launch_small_reg(const SmallArgs& a, hipStream_t st) {
 
 hipError_t launch_small_p(const SmallArgs& a, hipStream_t st) {
   if (!small_p_eligible(a.p) || a.nb != (a.p + 1 + 15) / 16 || a.n_ord < 1 || (a.per_sample != 1 && a.per_sample != 2) ||
-      (a.n_ord % a.per_sample) != 0 || !a.S[0] || !a.S[1] || !a.perms || !a.lifts)
+      (a.n_ord % a.per_sample) != 0 || !a.S[0] || !a.S[1] || !a.perms || !a.lifts || (a.fwd_only && a.per_sample != 2))
     return hipErrorInvalidValue;
   if (a.variant == 0) {       // the register-resident form wherever the matrix fits its wave (see small_reg_kernel)
     switch (a.nb) {

@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <vector>
 
 namespace lsspa {
 
@@ -62,14 +63,23 @@ struct SmallArgs {
   const double* s[2];      // source right-hand sides (g, h)
   double aug[2];           // diagonal value of the augmented row
   int64_t ld_src;
-  const int32_t* perms;    // [n_ord][p]
+  const int32_t* perms;    // [n_ord][p]; with fwd_only [n_ord / 2][p]: ordering 2 s + 1 is sample s's read backwards
+  int fwd_only;            // (per_sample == 2 only) the host stages and uploads half as much
   int p, nb, n_ord, per_sample;   // nb = ceil((p + 1) / 16)
   double* lifts;           // [n_ord / per_sample][p]
   double y_norm_sq;
   double piv_tol;
   int32_t* info;
   int variant;             // 0: the register-resident kernel where it applies (nb <= 7); 1: the LDS-resident kernel
+  // the register-resident kernel checks every ordering's sum of lifts against the full model's R^2 itself (sum_tol >= 0;
+  // off: -1): LSSPA_INFO_SUM into info[0] beyond sum_tol, the largest deviation above sum_quiet into info[2..3]
+  double r2, sum_tol, sum_quiet;
 };
+bool small_p_checks_sum(const SmallArgs& a);
+// host_perms.cpp: every row of perms [B][p] a permutation of 0..p-1?  (sets by AVX2 for 8 <= p <= 128, stamps otherwise;
+// _plain: the stamp loop alone, the test's comparison)
+bool all_permutations(const int32_t* perms, int B, int p, std::vector<int32_t>& mark);
+bool all_permutations_plain(const int32_t* perms, int B, int p, std::vector<int32_t>& mark);
 bool small_p_eligible(int p);
 size_t small_p_lds_bytes(int nb);
 hipError_t launch_small_p(const SmallArgs& a, hipStream_t st);
@@ -145,6 +155,16 @@ hipError_t launch_stats_batch(const double* lifts, const double* mean, double* b
 // single GPU, small p: batch moments AND merge in one launch (no pending buffer): reads (mean, state[0] = n), writes
 // the advanced ones to (mean_out, state_out) -- the caller swaps the buffers -- and updates M2 in place
 bool stats_small_fusable(int n_samples, int p);
+// the same for up to 32 chunks of samples (first sample and count of each, in `lifts`), folded and merged one after the
+// other in one launch; mean_snap [n][p] / n_snap [n] (may be null): mean and n after every chunk
+struct StatsChunks {
+  static constexpr int MAX = 32;
+  int n;
+  int first[MAX], count[MAX];
+};
+hipError_t launch_stats_small_multi(const double* lifts, const double* mean, const double* state, double* mean_out,
+                                    double* state_out, double* M2, const StatsChunks& ch, int p, double* mean_snap,
+                                    double* n_snap, hipStream_t st);
 hipError_t launch_stats_small_fused(const double* lifts, const double* mean, const double* state, double* mean_out,
                                     double* state_out, double* M2, int n_samples, int p, hipStream_t st);
 // Chan merge of the pending batch into (n, mean, M2); n lives in state[0] (state[1] is the fused kernel's ticket and
@@ -201,6 +221,24 @@ hipError_t launch_error_quantiles_running(const double* D, const double* s, cons
 // (also the test hook); launch_error_accumulate does that into the workspace Xi [1024][n_pad] and adds
 // D[1024][ldh] += Xi L, s[1024] += Xi 1 for the chunk's lift vectors L; launch_error_running_draws:
 // x = (D - s mean^T) * scale.
+// the chunks of a group folded into the running estimator by launch_error_group, and the checks that belong to them
+struct EstChunks {
+  static constexpr int MAX = 32;
+  int n;
+  int first[MAX], count[MAX], n_pad[MAX];   // first sample in the lane's lift buffer, samples, samples padded to 16
+  long long xi_off[MAX];                    // the chunk's normals in the workspace (doubles)
+  long long first_id[MAX];                  // global sample number of the chunk's first sample
+  double scale[MAX];                        // 1 / sqrt(n (n - 1)) of the chunk's check, 0 = no check
+};
+struct EstChecks {
+  int n;
+  int chunk[EstChunks::MAX], slot[EstChunks::MAX];
+  double scale[EstChunks::MAX];
+};
+hipError_t launch_error_group(uint64_t seed, int64_t stride, const EstChunks& ch, const EstChecks& ck, double* Xi,
+                              const double* lifts, int p, int ld, double* P, double* S, double* D, double* s,
+                              double* Dsnap, double* ssnap, const double* mean_snap, const double* n_snap,
+                              double* norms, double* res, hipStream_t st);
 hipError_t launch_error_xi(uint64_t seed, int64_t first_id, int64_t stride, int count, int n_pad, double* Xi,
                            hipStream_t st);
 // L: raw == 0: [n_pad][ldl = ldh], padded and zero-filled; raw != 0: [count][ldl >= p] as the lift kernels wrote it

@@ -67,6 +67,8 @@ struct Lane {
   hipEvent_t perms_used[2] = {nullptr, nullptr};   // the kernels that read device slot b have run
   bool perms_used_valid[2] = {false, false};
   const int32_t* perms_cur = nullptr;              // device slot of the batch being launched
+  bool sum_checked = false;                        // the batch's kernel checked the orderings' sums itself
+  bool perms_fwd_only = false;                     // ... which holds the samples' orderings only, not their reverses
   // second stream for the two-slice schedule of a batch (developer flag 32)
   // two-lane hand-offs
   hipEvent_t ev_mid = nullptr, ev_done = nullptr, ev_consumed = nullptr, ev_main = nullptr;
@@ -125,7 +127,7 @@ struct lsspa_ctx {
   bool run_on = false;
   uint64_t run_seed = 0;
   DevBuf<double> Dacc, sacc;
-  static constexpr int RES_SLOTS = 32;
+  static constexpr int RES_SLOTS = 64;
   double* res_h = nullptr;            // pinned [RES_SLOTS][2 p + 2]: feature errors, overall error, mean, n
   double* res_hd = nullptr;           // the same memory as the device sees it: the quantile kernel writes a check's
                                       // results there itself (no copy in the chain of a check)
@@ -138,6 +140,8 @@ struct lsspa_ctx {
   Comm* comm = nullptr;
   DevBuf<double> pack, xfer;     // packed moments; staging of host-side all-gathers
   DevBuf<double> theta_d;        // lsspa_full_fit's back-substitution
+  DevBuf<double> mean_snap, n_snap;   // running mean / n after every chunk of a group folded in one launch (small p)
+  DevBuf<double> grp_P, grp_S, grp_D, grp_s, grp_norms;   // launch_error_group: products, sums and their snapshots
   // the streamed reduction's staging (two row chunks in flight), its copy stream and events: kept between calls
   DevBuf<char> red_x[2], red_y[2];
   hipStream_t red_cs = nullptr;
@@ -515,6 +519,16 @@ int ensure_lane(lsspa_ctx* ctx, Lane& L) {
   return LSSPA_OK;
 }
 
+// small problems take the fused kernel (developer flag 1024 forces the general path, which full_fit, get_factors and
+// debug_factor also need: they read the factors back from the work matrices)
+static double sum_check_tol(const lsspa_ctx* ctx) {
+  return ((ctx->f32 || ctx->r2_f32) ? 1e-4 : 1e-9) * std::max(1.0, std::fabs(ctx->r2));
+}
+
+static bool small_path(const lsspa_ctx* ctx) {
+  return ctx->tri && !ctx->f32 && small_p_eligible(ctx->p) && !(ctx->flags & 1024) && !ctx->general_path_once;
+}
+
 // Run gather -> factorisation -> strip -> lift for n_ord orderings already resident in perms_d.
 // lifts for sample s land in lifts_d[(s_off + s)][p].
 // Orderings [ord_off, ord_off + n_ord) of the staged batch on stream st.  Each slice owns its part of every
@@ -535,7 +549,7 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
   const bool timed = (st == ctx->lane_stream(L));   // the profiling events live on the lane's main stream
   // a1: small problems take the fused kernel (developer flag 1024 forces the general path, which full_fit,
   // get_factors and debug_factor also need: they read the factors back from the work matrices)
-  if (ctx->tri && !ctx->f32 && small_p_eligible(p) && !(ctx->flags & 1024) && !ctx->general_path_once) {
+  if (small_path(ctx)) {
     ProfScope ps(timed ? ctx : nullptr, LSSPA_K_SMALL, st);
     SmallArgs sa;
     sa.S[0] = ctx->G.ptr;
@@ -545,7 +559,8 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
     sa.aug[0] = 2.0 * ctx->aug_train + 1.0;
     sa.aug[1] = 2.0 * ctx->y_norm_sq + 1.0;
     sa.ld_src = p_pad;
-    sa.perms = perms_s;
+    sa.fwd_only = (L.perms_fwd_only && per_sample == 2) ? 1 : 0;
+    sa.perms = sa.fwd_only ? L.perms_cur + (size_t)(ord_off / 2) * p : perms_s;
     sa.p = p;
     sa.nb = (p + 1 + 15) / 16;
     sa.n_ord = n_ord;
@@ -555,6 +570,15 @@ int run_slice(lsspa_ctx* ctx, Lane& L, int ord_off, int n_ord, int per_sample, i
     sa.piv_tol = 16.0 * (double)p * 2.220446049250313e-16;
     sa.info = ctx->info_d.ptr;
     sa.variant = (ctx->flags & 16384) ? 1 : 0;
+    // the batch's own end-to-end check (run_orderings) inside the kernel where the kernel can make it
+    sa.r2 = ctx->r2;
+    sa.sum_tol = -1.0;
+    sa.sum_quiet = 0.0;
+    L.sum_checked = false;
+    if (ctx->r2_valid && small_p_checks_sum(sa)) {
+      sa.sum_tol = sum_check_tol(ctx);
+      L.sum_checked = true;
+    }
     if (per_sample == 2)
       HIPCHK(hipMemsetAsync(sa.lifts, 0, sizeof(double) * (size_t)(n_ord / 2) * p, st));
     HIPCHK(launch_small_p(sa, st));
@@ -701,13 +725,13 @@ int ensure_f32_sources(lsspa_ctx* ctx) {
 // ONE lane, developer flag 32, +0.8 %; the two lanes of round 4 do that across batches and better -- removed.)
 int run_orderings(lsspa_ctx* ctx, Lane& L, int n_ord, int per_sample, int s_off) {
   const hipStream_t st = ctx->lane_stream(L);
+  L.sum_checked = false;
   TRY(run_slice(ctx, L, 0, n_ord, per_sample, s_off, st));
   // the batch's own end-to-end check, once the full model's R^2 is known (lsspa_full_fit): every lift vector sums to it
-  if (ctx->r2_valid && !ctx->general_path_once) {
-    const double tol = ((ctx->f32 || ctx->r2_f32) ? 1e-4 : 1e-9) * std::max(1.0, std::fabs(ctx->r2));
-    HIPCHK(launch_sum_check(L.lifts.ptr + (size_t)s_off * ctx->p, n_ord / per_sample, ctx->p, ctx->r2, tol,
+  // (the register-resident small-problem kernel has made it per ordering already)
+  if (ctx->r2_valid && !ctx->general_path_once && !L.sum_checked)
+    HIPCHK(launch_sum_check(L.lifts.ptr + (size_t)s_off * ctx->p, n_ord / per_sample, ctx->p, ctx->r2, sum_check_tol(ctx),
                             ctx->info_d.ptr, st));
-  }
   return LSSPA_OK;
 }
 
@@ -723,17 +747,22 @@ int stage_and_run(lsspa_ctx* ctx, Lane& L, const int32_t* perms, int n_samples, 
     L.perms_busy[turn] = false;
   }
   int32_t* hp = L.perms_h[turn];
-  for (int s = 0; s < n_samples; ++s) {
-    const int32_t* src = perms + (size_t)s * p;
-    int32_t* d0 = hp + (size_t)s * per_sample * p;
-    std::memcpy(d0, src, sizeof(int32_t) * (size_t)p);   // validated by the caller (all_permutations)
-    if (per_sample == 2) {
+  // the small-problem kernels read a sample's reverse ordering out of the forward one themselves: half the staging, half
+  // the upload (the host's share of a 2048-ordering group at p = 100 was longer than the GPU's)
+  L.perms_fwd_only = per_sample == 2 && small_path(ctx);
+  if (L.perms_fwd_only || per_sample == 1) {
+    std::memcpy(hp, perms, sizeof(int32_t) * (size_t)n_samples * p);   // validated by the caller
+  } else {
+    for (int s = 0; s < n_samples; ++s) {
+      const int32_t* src = perms + (size_t)s * p;
+      int32_t* d0 = hp + (size_t)s * 2 * p;
+      std::memcpy(d0, src, sizeof(int32_t) * (size_t)p);
       int32_t* d1 = d0 + p;
       for (int j = 0; j < p; ++j) d1[j] = src[p - 1 - j];
     }
   }
   int32_t* dp = L.perms_d.ptr + (size_t)turn * L.cap_ord * p;
-  const size_t bytes = sizeof(int32_t) * (size_t)n_ord * p;
+  const size_t bytes = sizeof(int32_t) * (size_t)(L.perms_fwd_only ? n_samples : n_ord) * p;
   if (bytes <= ((size_t)1 << 20)) {
     // a small upload rides on the lane's own stream: one copy and one event (the pinned buffer's reuse guard)
     // instead of a hand-off to the copy stream and back -- four stream operations that cost the host more than
@@ -847,6 +876,8 @@ int keep_lifts(lsspa_ctx* ctx, const double* src, int count, const int64_t* ids 
   return LSSPA_OK;
 }
 
+int lane_taken(lsspa_ctx* ctx, Lane& L, int upto);
+
 int lift_collect(lsspa_ctx* ctx, Lane& L, int first, int count, double* lifts_out, int accumulate,
                  const int64_t* est_ids = nullptr) {
   if (!L.in_flight) return ctx->fail(LSSPA_ERR_STATE, "no launched batch on this lane");
@@ -882,7 +913,52 @@ int lift_collect(lsspa_ctx* ctx, Lane& L, int first, int count, double* lifts_ou
     HIPCHK(hipMemcpyAsync(lifts_out, src, sizeof(double) * (size_t)count * p, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
-  L.taken = first + count;
+  return lane_taken(ctx, L, first + count);
+}
+
+// Small problems, one rank: the statistics of SEVERAL chunks of a launched batch in one launch (stats_small_multi_kernel),
+// chunk by chunk in order -- bit for bit what lift_collect(accumulate = 2) does chunk after chunk.  The chunks follow
+// each other in the batch (first[c + 1] = first[c] + count[c]).  snap: keep the running mean and n after every chunk
+// (ctx->mean_snap / n_snap) for the checks that belong to them.  The caller has checked fusability (chunks_fusable).
+bool chunks_fusable(const lsspa_ctx* ctx, const Lane& L, int n_chunks, const int32_t* first, const int32_t* count) {
+  if (ctx->comm || ctx->pend_dirty || n_chunks < 2 || n_chunks > StatsChunks::MAX || !L.in_flight) return false;
+  if (first[0] != L.taken) return false;
+  int next = first[0];
+  for (int c = 0; c < n_chunks; ++c) {
+    if (first[c] != next || !stats_small_fusable(count[c], ctx->p)) return false;
+    next += count[c];
+  }
+  return next <= L.B;
+}
+
+int collect_chunks_small(lsspa_ctx* ctx, Lane& L, int n_chunks, const int32_t* first, const int32_t* count,
+                                bool snap) {
+  const int p = ctx->p;
+  if (ctx->n_lanes == 2 && first[0] == 0) HIPCHK(hipStreamWaitEvent(ctx->stream, L.ev_done, 0));
+  StatsChunks ch;
+  ch.n = n_chunks;
+  for (int c = 0; c < n_chunks; ++c) {
+    ch.first[c] = first[c];
+    ch.count[c] = count[c];
+  }
+  if (snap) {
+    TRY(dev_alloc(ctx, ctx->mean_snap, (size_t)StatsChunks::MAX * p));
+    TRY(dev_alloc(ctx, ctx->n_snap, (size_t)StatsChunks::MAX));
+  }
+  {
+    ProfScope ps(ctx, LSSPA_K_STATS);
+    HIPCHK(launch_stats_small_multi(L.lifts.ptr, ctx->mean.ptr, ctx->state_n.ptr, ctx->mean_alt.ptr, ctx->state_alt.ptr,
+                                    ctx->M2.ptr, ch, p, snap ? ctx->mean_snap.ptr : nullptr,
+                                    snap ? ctx->n_snap.ptr : nullptr, ctx->stream));
+  }
+  std::swap(ctx->mean, ctx->mean_alt);
+  std::swap(ctx->state_n, ctx->state_alt);
+  return LSSPA_OK;
+}
+
+// what lift_collect does to the lane when the last sample of its batch has been taken
+int lane_taken(lsspa_ctx* ctx, Lane& L, int upto) {
+  L.taken = upto;
   if (L.taken == L.B) {
     if (ctx->n_lanes == 2) {
       HIPCHK(hipEventRecord(L.ev_consumed, ctx->stream));
@@ -899,21 +975,6 @@ bool is_permutation(const int32_t* perm, int p, std::vector<char>& seen) {
     const int32_t f = perm[j];
     if (f < 0 || f >= p || seen[f]) return false;
     seen[f] = 1;
-  }
-  return true;
-}
-
-// the same for B rows with one scratch array: row s marks its entries with the stamp s + 1
-bool all_permutations(const int32_t* perms, int B, int p, std::vector<int32_t>& mark) {
-  mark.assign(p, 0);
-  for (int s = 0; s < B; ++s) {
-    const int32_t* row = perms + (size_t)s * p;
-    const int32_t stamp = s + 1;
-    for (int j = 0; j < p; ++j) {
-      const uint32_t f = (uint32_t)row[j];
-      if (f >= (uint32_t)p || mark[f] == stamp) return false;
-      mark[f] = stamp;
-    }
   }
   return true;
 }
@@ -1033,6 +1094,8 @@ int lsspa_destroy(lsspa_ctx* ctx) try {
   comm_destroy(ctx->comm);
   ctx->comm = nullptr;
   dev_free(ctx->pack); dev_free(ctx->xfer); dev_free(ctx->ibuf); dev_free(ctx->theta_d);
+  dev_free(ctx->mean_snap); dev_free(ctx->n_snap);
+  dev_free(ctx->grp_P); dev_free(ctx->grp_S); dev_free(ctx->grp_D); dev_free(ctx->grp_s); dev_free(ctx->grp_norms);
   for (int b = 0; b < 2; ++b) {
     dev_free(ctx->red_x[b]);
     dev_free(ctx->red_y[b]);
@@ -1608,6 +1671,31 @@ int lsspa_lift_collect(lsspa_ctx* ctx, int32_t ticket, int32_t first, int32_t co
   return abi_caught(ctx);
 }
 
+int lsspa_lift_collect_chunks(lsspa_ctx* ctx, int32_t ticket, int32_t first, int32_t chunk, int32_t n_chunks,
+                              int32_t accumulate) try {
+  if (!ctx || ticket < 0 || ticket > 1 || first < 0 || chunk < 1 || n_chunks < 1) return LSSPA_ERR_ARG;
+  if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  Lane& L = ctx->lanes[ticket];
+  if (accumulate == 2 && n_chunks <= StatsChunks::MAX) {
+    int32_t f[StatsChunks::MAX], k[StatsChunks::MAX];
+    for (int c = 0; c < n_chunks; ++c) {
+      f[c] = first + c * chunk;
+      k[c] = chunk;
+    }
+    if (chunks_fusable(ctx, L, n_chunks, f, k)) {
+      TRY(check_accumulate(ctx, 2));
+      TRY(collect_chunks_small(ctx, L, n_chunks, f, k, false));
+      TRY(keep_lifts(ctx, L.lifts.ptr + (size_t)first * ctx->p, n_chunks * chunk, nullptr));
+      return lane_taken(ctx, L, first + n_chunks * chunk);
+    }
+  }
+  for (int c = 0; c < n_chunks; ++c) TRY(lift_collect(ctx, L, first + c * chunk, chunk, nullptr, accumulate));
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
+}
+
 int lsspa_lift_discard(lsspa_ctx* ctx, int32_t ticket) try {
   if (!ctx || ticket < 0 || ticket > 1) return LSSPA_ERR_ARG;
   Lane& L = ctx->lanes[ticket];
@@ -1966,14 +2054,18 @@ static int quantiles_enqueue(lsspa_ctx* ctx, int32_t slot, bool record) {
   return finish_check(ctx, slot, record);
 }
 
-static int check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot, bool record);
+static int check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot, bool record, const double* mean_at = nullptr,
+                         const double* n_at = nullptr);
 int lsspa_error_check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot) try {
   return check_enqueue(ctx, n_total, slot, true);
 } catch (...) {
   return abi_caught(ctx);
 }
 
-static int check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot, bool record) {
+// mean_at / n_at: the running mean and n the check belongs to, when they are not the context's current ones (a group of
+// chunks folded in one launch: the snapshots after the check's own chunk)
+static int check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot, bool record, const double* mean_at,
+                         const double* n_at) {
   if (!ctx || n_total < 0 || slot < 0 || slot >= lsspa_ctx::RES_SLOTS) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   if (!ctx->run_on) return ctx->fail(LSSPA_ERR_STATE, "the running estimator is not enabled");
@@ -1985,9 +2077,10 @@ static int check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot, bool rec
   const double scale = 1.0 / sqrt(nt * (nt - 1.0));
   {
     ProfScope ps(ctx, LSSPA_K_ERROR);
-    HIPCHK(launch_error_quantiles_running(ctx->Dacc.ptr, ctx->sacc.ptr, ctx->mean.ptr, scale, ctx->ldh(), (int)p,
-                                          ctx->err_out.ptr + 2 * p + 2, ctx->res_hd + (size_t)slot * (2 * p + 2),
-                                          ctx->state_n.ptr, ctx->stream));
+    HIPCHK(launch_error_quantiles_running(ctx->Dacc.ptr, ctx->sacc.ptr, mean_at ? mean_at : ctx->mean.ptr, scale,
+                                          ctx->ldh(), (int)p, ctx->err_out.ptr + 2 * p + 2,
+                                          ctx->res_hd + (size_t)slot * (2 * p + 2), n_at ? n_at : ctx->state_n.ptr,
+                                          ctx->stream));
   }
   return finish_check(ctx, slot, record);
 }
@@ -2083,6 +2176,55 @@ int lsspa_group_collect(lsspa_ctx* ctx, int32_t ticket, int32_t n_chunks, const 
   int last_check = -1;
   for (int c = 0; c < n_chunks; ++c)
     if (n_after[c] > 0) last_check = c;
+  Lane& Lg = ctx->lanes[ticket];
+  if (chunks_fusable(ctx, Lg, n_chunks, first, count)) {
+    // small problem, one rank: the group's statistics in one launch; every check reads the mean and n after ITS chunk
+    // ... and the estimator likewise: the chunks' products side by side, summed in order with a snapshot per chunk, all
+    // the checks' quantiles in one launch (launch_error_group) -- 6 launches a group instead of 5 a chunk
+    TRY(collect_chunks_small(ctx, Lg, n_chunks, first, count, true));
+    EstChunks ch;
+    EstChecks ck;
+    ch.n = n_chunks;
+    ck.n = 0;
+    long long off = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+      ch.first[c] = first[c];
+      ch.count[c] = count[c];
+      ch.n_pad[c] = ((count[c] + KCH - 1) / KCH) * KCH;
+      ch.xi_off[c] = off;
+      off += (long long)ERR_DRAWS * ch.n_pad[c];
+      ch.first_id[c] = first_id[c];
+      ch.scale[c] = 0.0;
+      if (n_after[c] > 0) {
+        const double nt = (double)n_after[c];
+        ch.scale[c] = 1.0 / sqrt(nt * (nt - 1.0));
+        ck.chunk[ck.n] = c;
+        ck.slot[ck.n] = slot[c];
+        ck.scale[ck.n] = ch.scale[c];
+        ++ck.n;
+      }
+    }
+    const size_t ld = ctx->ldh();
+    TRY(dev_alloc(ctx, ctx->xi_d, (size_t)off));
+    TRY(dev_alloc(ctx, ctx->grp_P, (size_t)n_chunks * ERR_DRAWS * ld));
+    TRY(dev_alloc(ctx, ctx->grp_D, (size_t)n_chunks * ERR_DRAWS * ld));
+    TRY(dev_alloc(ctx, ctx->grp_S, (size_t)n_chunks * ERR_DRAWS));
+    TRY(dev_alloc(ctx, ctx->grp_s, (size_t)n_chunks * ERR_DRAWS));
+    TRY(dev_alloc(ctx, ctx->grp_norms, (size_t)n_chunks * ERR_DRAWS));
+    {
+      ProfScope ps(ctx, LSSPA_K_ERROR);
+      HIPCHK(launch_error_group(ctx->run_seed, stride, ch, ck, ctx->xi_d.ptr, Lg.lifts.ptr, ctx->p, (int)ld,
+                                ctx->grp_P.ptr, ctx->grp_S.ptr, ctx->Dacc.ptr, ctx->sacc.ptr, ctx->grp_D.ptr,
+                                ctx->grp_s.ptr, ctx->mean_snap.ptr, ctx->n_snap.ptr, ctx->grp_norms.ptr, ctx->res_hd,
+                                ctx->stream));
+    }
+    for (int c = 0; c < n_chunks; ++c)
+      if (n_after[c] > 0) TRY(finish_check(ctx, slot[c], c == last_check));
+    TRY(lane_taken(ctx, Lg, first[n_chunks - 1] + count[n_chunks - 1]));
+    for (int c = 0; c < n_chunks; ++c)
+      if (n_after[c] > 0) ctx->res_via[slot[c]] = slot[last_check];
+    return LSSPA_OK;
+  }
   for (int c = 0; c < n_chunks; ++c) {
     if (count[c] > 0) {
       const int64_t ids[2] = {first_id[c], stride};
@@ -2282,6 +2424,23 @@ int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags) try {
   return LSSPA_OK;
 } catch (...) {
   return abi_caught(ctx);
+}
+
+int lsspa_debug_set_r2(lsspa_ctx* ctx, double r2) try {
+  if (!ctx) return LSSPA_ERR_ARG;
+  if (!ctx->r2_valid) return ctx->fail(LSSPA_ERR_STATE, "no R^2 yet: call lsspa_full_fit first");
+  ctx->r2 = r2;
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(ctx);
+}
+
+int lsspa_debug_check_perms(const int32_t* perms, int32_t B, int32_t p, int32_t plain) try {
+  if (!perms || B < 1 || p < 1) return 0;
+  std::vector<int32_t> mark;
+  return (plain ? all_permutations_plain(perms, B, p, mark) : all_permutations(perms, B, p, mark)) ? 1 : 0;
+} catch (...) {
+  return 0;
 }
 
 int lsspa_debug_pack_from(lsspa_ctx* ctx, int32_t p_min) try {

@@ -368,11 +368,14 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
     if lookahead == "auto":
         # automatic: a chunk of fewer than 64 samples per rank leaves most of an MI355X idle (§6 of DESIGN.md) --
         # launch as many chunks together as make up 64, eight at most.  Small problems (the one-workgroup-per-ordering
-        # kernels, p <= 126): a launch of 2048 orderings fills the chip four times over and costs the host one call --
-        # as many chunks as make up 1024 samples, eight at most.
+        # kernels, p <= 126): a group costs the host one call and the GPU ~45 us of dependent launches around its lift
+        # kernel whatever its size (statistics, estimator and checks of all its chunks are five launches), against 25 us
+        # of kernel per chunk of 128 samples at p = 100 -- as many chunks as make up 2048 samples, sixteen at most.
         per_rank = -(-int(batch_size) // comm.world)
-        want = 1024 if p <= 126 else 64
-        lookahead = max(1, min(8, want // max(per_rank, 1)))
+        small = p <= 126
+        lookahead = max(1, min(16 if small else 8, (2048 if small else 64) // max(per_rank, 1)))
+        if small and per_rank >= 1024:
+            lookahead = 1         # such a chunk fills the chip four times over by itself
     group = max(1, int(lookahead)) if (hasattr(engine, "launch_batch") and source.independent and not chunk_cap) else 1
     # The device estimator's checks are ENQUEUED, not waited for: x = (D - s mean^T) / sqrt(n (n - 1)), the all-reduce of
     # the per-rank x, the quantile kernels and a copy of (errors, running mean, n) into a pinned slot run on the context's

@@ -241,6 +241,12 @@ class HipEngine:
                                                  self._acc_mode(accumulate)))
         return out
 
+    def collect_chunks(self, ticket, first: int, chunk: int, n_chunks: int, accumulate=2):
+        """n_chunks consecutive parts of `chunk` samples of a launched batch, folded one after the other (include/lsspa.h,
+        lsspa_lift_collect_chunks: one statistics launch for a small problem's parts, each still merged by itself)."""
+        self._check(self._lib.lsspa_lift_collect_chunks(self._h, ticket[0], int(first), int(chunk), int(n_chunks),
+                                                        self._acc_mode(accumulate)))
+
     def discard_batch(self, ticket):
         self._check(self._lib.lsspa_lift_discard(self._h, ticket[0]))
 
@@ -329,7 +335,7 @@ class HipEngine:
         return feat, tot.value
 
     # ---- running form of the device-side estimator (include/lsspa.h) ---------------------
-    RESULT_SLOTS = 32
+    RESULT_SLOTS = 64
 
     def error_running_enable(self, seed: int):
         """D = Xi L and s = Xi 1 stay in HBM; Xi is a function of (seed, sample id, draw)."""

@@ -52,6 +52,7 @@ SIGNATURES = {
     "lsspa_lift_batch": (C.c_int, [_vp, _pi32, _i32, _i32, _pd, _i32]),
     "lsspa_lift_launch": (C.c_int, [_vp, _pi32, _i32, _i32, _pi32]),
     "lsspa_lift_collect": (C.c_int, [_vp, _i32, _i32, _i32, _pd, _i32]),
+    "lsspa_lift_collect_chunks": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32]),
     "lsspa_lift_discard": (C.c_int, [_vp, _i32]),
     "lsspa_set_lanes": (C.c_int, [_vp, _i32]),
     "lsspa_get_info": (C.c_int, [_vp, _pi32]),
@@ -85,6 +86,8 @@ SIGNATURES = {
     "lsspa_set_precision": (C.c_int, [_vp, _i32]),
     "lsspa_debug_fail_alloc": (C.c_int, [_vp, _i32]),
     "lsspa_debug_pack_from": (C.c_int, [_vp, _i32]),
+    "lsspa_debug_set_r2": (C.c_int, [_vp, _dbl]),
+    "lsspa_debug_check_perms": (C.c_int, [_pi32, _i32, _i32, _i32]),
     "lsspa_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "lsspa_comm_init": (C.c_int, [_vp, C.POINTER(C.c_uint8), _i32, _i32]),
     "lsspa_comm_destroy": (C.c_int, [_vp]),

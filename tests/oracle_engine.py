@@ -31,6 +31,10 @@ class OracleEngine:
         self._tickets[t] = lifts
         return t
 
+    def collect_chunks(self, ticket, first, chunk, n_chunks, accumulate=2):
+        for c in range(n_chunks):
+            self.collect_batch(ticket, want_lifts=False, accumulate=accumulate, first=first + c * chunk, count=chunk)
+
     def collect_batch(self, ticket, want_lifts=False, accumulate=True, first=0, count=None):
         assert ticket == min(self._tickets), "tickets are collected in launch order"
         done = self._taken.get(ticket, 0)
@@ -181,7 +185,7 @@ class OracleEngine:
     # running form (mirrors lsspa_error_running_* / _advance / _quantiles_enqueue / _result): D = Xi L, s = Xi 1 with the
     # counter-based normals of tests/philox_ref.py; a check's results are computed when it is enqueued and handed out
     # when its slot is read
-    RESULT_SLOTS = 32
+    RESULT_SLOTS = 64
 
     def error_running_enable(self, seed):
         self._run_on, self._run_seed = True, int(seed)

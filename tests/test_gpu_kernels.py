@@ -777,3 +777,101 @@ def test_accumulate_and_merge_at_once(p, bsz):
     finally:
         two.close()
         one.close()
+
+
+@pytest.mark.parametrize("p,chunk,n_chunks", [(7, 5, 3), (100, 16, 8), (100, 256, 8), (128, 33, 32), (61, 512, 2),
+                                               (130, 16, 4), (100, 16, 33)])
+def test_chunks_of_a_batch_folded_in_one_call(p, chunk, n_chunks):
+    """lsspa_lift_collect_chunks: the parts of a launched batch folded one after the other by one call -- at p <= 128
+    one statistics launch (stats_small_multi_kernel) that carries the running mean and n from part to part in
+    registers -- leaves n, the mean and the covariance where part-by-part lsspa_lift_collect(accumulate = 2) leaves
+    them, to the LAST BIT, with statistics already there and with the parts starting inside the batch; beyond the
+    fused form's limits (p = 130, 33 parts) the call is the loop itself."""
+    from ls_spa._engine import HipEngine
+    Xa, Xe, ya, ye = problem(77, p, 3 * p + 60, 2 * p + 50)
+    rng = np.random.default_rng(p + chunk)
+    parts, whole = HipEngine(0), HipEngine(0)
+    try:
+        for eng in (parts, whole):
+            eng.load_data(Xa, Xe, ya, ye, 1e-3)
+        for rnd in range(2):                      # the second round starts from the first one's statistics
+            lead = 0 if rnd == 0 else chunk       # ... and inside the batch: one part taken by itself first
+            perms = np.array([rng.permutation(p) for _ in range(lead + chunk * n_chunks)])
+            tp, tw = parts.launch_batch(perms, True), whole.launch_batch(perms, True)
+            if lead:
+                parts.collect_batch(tp, accumulate=2, first=0, count=lead)
+                whole.collect_batch(tw, accumulate=2, first=0, count=lead)
+            for c in range(n_chunks):
+                parts.collect_batch(tp, accumulate=2, first=lead + c * chunk, count=chunk)
+            whole.collect_chunks(tw, lead, chunk, n_chunks, accumulate=2)
+            n1, m1, c1 = parts.stats()
+            n2, m2, c2 = whole.stats()
+            assert n1 == n2 == (rnd + 1) * chunk * n_chunks + lead * rnd
+            np.testing.assert_array_equal(m2, m1)
+            np.testing.assert_array_equal(c2, c1)
+        # both lanes were given back: the engines go on
+        perms = np.array([rng.permutation(p) for _ in range(4)])
+        np.testing.assert_array_equal(whole.run_batch(perms, True, want_lifts=True, accumulate=2),
+                                      parts.run_batch(perms, True, want_lifts=True, accumulate=2))
+        np.testing.assert_array_equal(whole.stats()[2], parts.stats()[2])
+    finally:
+        parts.close()
+        whole.close()
+
+
+@pytest.mark.parametrize("p", [24, 100])
+def test_a_group_of_checks_from_one_statistics_launch(p):
+    """The public call on a small problem with the device estimator: a look-ahead group's chunks are folded by ONE
+    statistics launch inside lsspa_group_collect and every chunk's check reads the mean and n as they stood after ITS
+    chunk -- the error history, the attribution and its errors are those of the run that folds, merges and checks
+    chunk by chunk (lookahead = 1, nothing deferred), to the last bit; also when the stop rule fires inside a group."""
+    from ls_spa import ls_spa
+    Xa, Xe, ya, ye = problem(5, p, 4 * p + 30, 3 * p + 20)
+    kw = dict(reg=1e-3, method="argsort", seed=3, batch_size=16, max_samples=16 * 21, error_estimator="device")
+    ref = ls_spa(Xa, Xe, ya, ye, tolerance=0.0, lookahead=1, _defer=0, **kw)
+    grp = ls_spa(Xa, Xe, ya, ye, tolerance=0.0, lookahead=8, **kw)
+    assert len(ref.error_history) == len(grp.error_history) == 22          # 21 chunks and the check at max - 1
+    np.testing.assert_array_equal(grp.error_history, ref.error_history)
+    np.testing.assert_array_equal(grp.attribution, ref.attribution)
+    np.testing.assert_array_equal(grp.attribution_errors, ref.attribution_errors)
+    tol = float(ref.error_history[10]) * 1.0000001
+    if all(e > tol for e in ref.error_history[:10]):
+        a = ls_spa(Xa, Xe, ya, ye, tolerance=tol, lookahead=1, _defer=0, **kw)
+        b = ls_spa(Xa, Xe, ya, ye, tolerance=tol, lookahead=8, **kw)
+        assert len(a.error_history) == len(b.error_history) <= 12
+        np.testing.assert_array_equal(b.error_history, a.error_history)
+        np.testing.assert_array_equal(b.attribution, a.attribution)
+
+
+@pytest.mark.parametrize("p", [12, 100, 120, 300])
+def test_every_batch_checks_its_sums(p):
+    """Every ordering's lifts telescope to the full model's R^2 (ls_spa/ls_spa.py:284-285), and once that is known
+    (lsspa_full_fit) every batch is checked against it: inside the register-resident small-problem kernel per ordering
+    (p = 12, 100), by a launch of its own per sample otherwise (p = 120: the LDS-resident kernel; p = 300: the general
+    path).  A healthy engine stays silent with a deviation at round-off; with the R^2 moved by 1e-3 (test hook) every
+    form raises LSSPA_INFO_SUM and reports that deviation."""
+    from ls_spa._engine import HipEngine
+    Xa, Xe, ya, ye = problem(9, p, 3 * p + 100, 2 * p + 80)
+    rng = np.random.default_rng(p)
+    eng = HipEngine(0)
+    try:
+        eng.load_data(Xa, Xe, ya, ye, 1e-3)
+        eng.full_fit()
+        perms = np.array([rng.permutation(p) for _ in range(24)])
+        for anti in (True, False):
+            eng.reset_stats()
+            lifts = eng.run_batch(perms, anti, want_lifts=True, accumulate=2)
+            r2 = lifts.sum(1).mean()
+            assert eng.info() == 0 and eng.sum_deviation() < 1e-11
+        eng._check(eng._lib.lsspa_debug_set_r2(eng._h, float(r2) + 1e-3))
+        for anti in (True, False):
+            eng.reset_stats()
+            eng.run_batch(perms, anti, want_lifts=False, accumulate=2)
+            assert eng.info() & 8
+            assert eng.sum_deviation() == pytest.approx(1e-3, rel=1e-6)
+        eng._check(eng._lib.lsspa_debug_set_r2(eng._h, float(r2)))
+        eng.reset_stats()
+        eng.run_batch(perms, True, want_lifts=False, accumulate=2)
+        assert eng.info() == 0
+    finally:
+        eng.close()

@@ -472,6 +472,34 @@ def test_library_exports_every_declared_symbol():
     assert _native.load().lsspa_abi_version() == 1
 
 
+def test_batch_validation_fast_form_agrees_with_the_stamp_loop():
+    """Every batch launch checks on the host that its rows are permutations (csrc/host_perms.cpp; the reference's
+    orderings come from its own samplers, ls_spa/ls_spa.py:375-456, and are never checked).  The AVX2 form (a row as
+    a 128-bit set, 8 <= p <= 128) and the stamp loop give the same verdict on permutations and on rows with a
+    repeated entry, an entry just out of range, a negative one and one far out of range -- in any row, any column."""
+    from ls_spa import _native
+    lib = _native.load()
+    rng = np.random.default_rng(17)
+
+    def verdicts(q):
+        q = np.ascontiguousarray(q, dtype=np.int32)
+        return (lib.lsspa_debug_check_perms(_native.iptr(q), q.shape[0], q.shape[1], 0),
+                lib.lsspa_debug_check_perms(_native.iptr(q), q.shape[0], q.shape[1], 1))
+
+    for p in (1, 2, 7, 8, 9, 16, 23, 63, 64, 65, 100, 127, 128, 129, 300):
+        B = 37
+        perms = np.array([rng.permutation(p) for _ in range(B)], dtype=np.int32)
+        assert verdicts(perms) == (1, 1), p
+        if p == 1:
+            assert verdicts(np.array([[1]])) == (0, 0)
+            continue
+        for t in range(60):
+            q = perms.copy()
+            s, j = rng.integers(B), rng.integers(p)
+            q[s, j] = (q[s, (j + 1) % p], p, -1, p + 64 + int(rng.integers(1000)), 2 ** 31 - 1, -2 ** 31)[t % 6]
+            assert verdicts(q) == (0, 0), (p, t, s, j)
+
+
 def test_product_never_imports_oracle():
     pkg_dir = os.path.join(ROOT, "ls-spa_amd")
     for base, _, files in os.walk(pkg_dir):
@@ -597,12 +625,12 @@ def test_lookahead_keeps_the_reference_order(golden):
         assert e4.launched == 0 and e4.discarded == 0
     with pytest.raises(ValueError):
         ls_spa(*d, lookahead=0, _engine=OracleEngine())
-    # 'auto': small problems (p <= 126, one workgroup per ordering) go eight chunks to a launch up to 1024 samples,
-    # chunks of 1024 samples and more one at a time
+    # 'auto': small problems (p <= 126, one workgroup per ordering) go up to sixteen chunks to a launch up to 2048
+    # samples, chunks of 1024 samples and more one at a time
     ea, eb = OracleEngine(), OracleEngine()
     auto = ls_spa(*d, method="argsort", seed=5, max_samples=96, batch_size=16, tolerance=0.0, lookahead="auto", _engine=ea)
     np.testing.assert_array_equal(auto.attribution, first.attribution)
-    assert ea.launched == 1                       # 7 chunks in one group of (up to) 8
+    assert ea.launched == 1                       # 7 chunks in one group of (up to) 16
     ls_spa(*d, method="argsort", seed=5, max_samples=2048, batch_size=1024, tolerance=0.0, lookahead="auto", _engine=eb)
     assert eb.launched == 0
 
