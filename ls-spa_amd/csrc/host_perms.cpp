@@ -77,3 +77,4 @@ bool all_permutations_plain(const int32_t* perms, int B, int p, std::vector<int3
 }
 
 }  // namespace lsspa
+

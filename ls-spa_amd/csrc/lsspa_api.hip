@@ -763,10 +763,13 @@ int stage_and_run(lsspa_ctx* ctx, Lane& L, const int32_t* perms, int n_samples, 
   }
   int32_t* dp = L.perms_d.ptr + (size_t)turn * L.cap_ord * p;
   const size_t bytes = sizeof(int32_t) * (size_t)(L.perms_fwd_only ? n_samples : n_ord) * p;
-  if (bytes <= ((size_t)1 << 20)) {
+  if (bytes <= ((size_t)256 << 10) || (ctx->n_lanes == 2 && bytes <= ((size_t)1 << 20))) {
     // a small upload rides on the lane's own stream: one copy and one event (the pinned buffer's reuse guard)
     // instead of a hand-off to the copy stream and back -- four stream operations that cost the host more than
-    // the copy costs the GPU
+    // the copy costs the GPU.  With two lanes that holds up to 1 MB (the other lane's kernels run meanwhile, and copy
+    // streams beside two lanes and the context's stream are more streams than hardware queues: C3 6.70 against 5.92 ms
+    // a step, measured).  With one lane only up to 256 KB: a group of 4096 orderings at p = 100 waited 36 us for its
+    // own 0.8 MB between two 400 us kernels -- on the copy stream it arrives while the previous group runs.
     HIPCHK(hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(L.perms_ev[turn], st));
     L.perms_busy[turn] = true;

@@ -67,7 +67,7 @@ class IterableSource(OrderingSource):
     def take(self, count):
         rows = list(itertools.islice(self._it, count))
         if not rows:
-            return np.empty((0, self._p), dtype=np.int64)
+            return np.empty((0, self._p), dtype=np.int32)
         out = np.asarray([np.asarray(r) for r in rows])
         if out.ndim != 2 or out.shape[1] != self._p:
             raise ValueError(f"every ordering must have length p = {self._p}")
@@ -85,7 +85,7 @@ class RandomSource(OrderingSource):
         n = int(min(count, self._left))
         self._left -= n
         if n <= 0:
-            return np.empty((0, self._p), dtype=np.int64)
+            return np.empty((0, self._p), dtype=np.int32)
         return np.stack([self._rng.permutation(self._p) for _ in range(n)])
 
     def skip(self, count):
@@ -118,24 +118,40 @@ class _BackgroundBuild:
         return self._value
 
 
+_sort_pool = None
+_sort_pool_lock = threading.Lock()
+
+
+def _pool():
+    """A few sorting threads kept for the life of the process (making them costs 0.2-0.3 ms, a block's sort 0.2-2 ms)."""
+    global _sort_pool
+    if _sort_pool is None:
+        with _sort_pool_lock:
+            if _sort_pool is None:
+                import os
+                from concurrent.futures import ThreadPoolExecutor
+                _sort_pool = ThreadPoolExecutor(max(1, min(4, (os.cpu_count() or 2) // 2)),
+                                                thread_name_prefix="lsspa-argsort")
+    return _sort_pool
+
+
 def _argsort_rows(a):
-    """np.argsort(a, axis=1); large blocks are cut into row ranges sorted on a few threads (the sort releases the
-    GIL) -- same result, row by row."""
+    """np.argsort(a, axis=1) as int32 (what the engine uploads); large blocks are cut into row ranges sorted on a few
+    threads (the sort releases the GIL) -- same result, row by row.  (Not the 1024 x 100 blocks of a small problem:
+    threads there took the driver's own thread 1.6 ms of a 4 ms run -- measured, round 5.)"""
     n = len(a)
     if a.size < (1 << 17) or n < 64:
-        return np.argsort(a, axis=1)
-    import os
-    from concurrent.futures import ThreadPoolExecutor
-    workers = max(1, min(4, (os.cpu_count() or 2) // 2, n // 32))
+        return np.argsort(a, axis=1).astype(np.int32)
+    pool = _pool()
+    workers = max(1, min(pool._max_workers, n // 32))
     if workers == 1:
-        return np.argsort(a, axis=1)
-    out = np.empty(a.shape, dtype=np.intp)
+        return np.argsort(a, axis=1).astype(np.int32)
+    out = np.empty(a.shape, dtype=np.int32)
     cuts = np.linspace(0, n, workers + 1).astype(int)
 
     def one(k):
         out[cuts[k]:cuts[k + 1]] = np.argsort(a[cuts[k]:cuts[k + 1]], axis=1)
-    with ThreadPoolExecutor(workers) as ex:
-        list(ex.map(one, range(workers)))
+    list(pool.map(one, range(workers)))
     return out
 
 
@@ -217,7 +233,7 @@ class ArgsortSource(OrderingSource):
         n = int(min(count, self._left))
         self._left -= n
         if n <= 0:
-            return np.empty((0, self._p), dtype=np.int64)
+            return np.empty((0, self._p), dtype=np.int32)
         return _argsort_rows(self._points(n))
 
     def take_share(self, count, first, rank, world):
@@ -227,7 +243,7 @@ class ArgsortSource(OrderingSource):
         n = int(min(count, self._left))
         self._left -= n
         if n <= 0:
-            return 0, np.empty((0, self._p), dtype=np.int64)
+            return 0, np.empty((0, self._p), dtype=np.int32)
         off = (rank - first) % world
         direct = self._direct_points()
         if direct is None:
@@ -236,7 +252,7 @@ class ArgsortSource(OrderingSource):
         self._fast_forward(n)
         self._pos += n
         if len(own) == 0:
-            return n, np.empty((0, self._p), dtype=np.int64)
+            return n, np.empty((0, self._p), dtype=np.int32)
         return n, _argsort_rows(direct.points(own))
 
     def skip(self, count):
@@ -314,7 +330,7 @@ class PermutohedronSource(ArgsortSource):
         n = int(min(count, self._left))
         self._left -= n
         if n <= 0:
-            return 0, np.empty((0, self._p), dtype=np.int64)
+            return 0, np.empty((0, self._p), dtype=np.int32)
         off = (rank - first) % world
         direct = self._direct_normals() if world > 1 else None
         if direct is None:
@@ -327,7 +343,7 @@ class PermutohedronSource(ArgsortSource):
             self._pos += n
             pts = self._normals_from(direct.points(own), self._qmc) if len(own) else np.empty((0, self._p - 1))
         if len(pts) == 0:
-            return n, np.empty((0, self._p), dtype=np.int64)
+            return n, np.empty((0, self._p), dtype=np.int32)
         pts = pts / np.linalg.norm(pts, axis=1, keepdims=True)
         if world == 1:
             return n, _argsort_rows(pts @ self._basis)       # the reference's own expression (its fixture pins it)
@@ -461,7 +477,7 @@ class PrefetchedSource(OrderingSource):
                 self._cv.notify_all()
             self._taken += got
         if not out:
-            return 0, np.empty((0, self._p), dtype=np.int64)
+            return 0, np.empty((0, self._p), dtype=np.int32)
         return got, (out[0] if len(out) == 1 else np.concatenate(out))
 
     def take(self, count):

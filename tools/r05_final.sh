@@ -16,7 +16,7 @@ echo probes done
 # the driver's command, in full (time to tolerance, CPU baseline)
 python3 bench.py --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err
 python3 bench.py --steps 20 --warmup 5 --data correlated --no-cpu-baseline --no-correlated-leg > $O/bench_c3_correlated.json 2> $O/bench_c3_correlated.err
-python3 bench.py --steps 64 --warmup 8 --p 100 --rows 10000 > $O/bench_c2.json 2> $O/bench_c2.err
+python3 bench.py --steps 256 --warmup 16 --p 100 --rows 10000 > $O/bench_c2.json 2> $O/bench_c2.err
 python3 bench.py --steps 5 --warmup 2 --p 5000 --rows 200000 --dtype f32 > $O/bench_c5.json 2> $O/bench_c5.err
 python3 bench.py --steps 20 --warmup 5 --dtype f32 --reg 0 --no-cpu-baseline > $O/bench_c3_f32.json 2> $O/bench_c3_f32.err
 python3 bench.py --steps 20 --warmup 5 --lanes 1 --no-cpu-baseline --no-ttt --no-probe > $O/bench_c3_one_lane.json 2> $O/bench_c3_one_lane.err
@@ -32,7 +32,7 @@ if [ "$PART" = "all" ] || [ "$PART" = "a" ] || [ "$PART" = "s" ]; then
 # the same command under the profiler (program directly after --), without the legs that launch other shapes
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -o c3 -- python3 bench.py --steps 20 --warmup 5 $P > $O/stats_c3.json 2> $O/stats_c3.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3l1 -o c3l1 -- python3 bench.py --steps 20 --warmup 5 --lanes 1 $P > $O/stats_c3l1.json 2> $O/stats_c3l1.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -o c2 -- python3 bench.py --steps 64 --warmup 8 --p 100 --rows 10000 $P > $O/stats_c2.json 2> $O/stats_c2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -o c2 -- python3 bench.py --steps 256 --warmup 16 --p 100 --rows 10000 $P > $O/stats_c2.json 2> $O/stats_c2.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -o c5 -- python3 bench.py --steps 5 --warmup 2 --p 5000 --rows 200000 --dtype f32 $P > $O/stats_c5.json 2> $O/stats_c5.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fr2 -o fr2 -- python3 tools/full_run_probe.py 100 10000 64 > $O/stats_fr2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fr3 -o fr3 -- python3 tools/full_run_probe.py 1000 100000 128 > $O/stats_fr3.log 2>&1
