@@ -25,7 +25,7 @@ kw = dict(method="argsort", batch_size=128, num_batches=nb, tolerance=0.0, seed=
           lanes=lanes if lanes == "auto" else int(lanes))
 if look is not None:
     kw["lookahead"] = look if look == "auto" else int(look)
-for rep in range(3):
+for rep in range(int(os.environ.get("LSSPA_PROBE_REPS", "3"))):
     tm = {}
     t0 = time.perf_counter()
     r = ls_spa(Xa, Xe, ya, ye, _timings=tm, **kw)
