@@ -746,6 +746,11 @@ int stage_and_run(lsspa_ctx* ctx, Lane& L, const int32_t* perms, int n_samples, 
     HIPCHK(hipEventSynchronize(L.perms_ev[turn]));
     L.perms_busy[turn] = false;
   }
+  // ... and, where uploads go by the copy stream, the kernels that read the device slot two batches ago must have
+  // finished: the host's lead over the GPU stays at two batches a lane.  (A copy on its own stream is done long before
+  // its batch starts, so the wait above no longer holds the host back -- and a host five groups ahead of a one-lane
+  // C2 run met a 7 ms stall inside the runtime at its fifth launch: 128 steps 0.075 ms each against 0.029 for 64.)
+  if (L.perms_used_valid[turn]) HIPCHK(hipEventSynchronize(L.perms_used[turn]));
   int32_t* hp = L.perms_h[turn];
   // the small-problem kernels read a sample's reverse ordering out of the forward one themselves: half the staging, half
   // the upload (the host's share of a 2048-ordering group at p = 100 was longer than the GPU's)

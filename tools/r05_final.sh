@@ -43,12 +43,23 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_c3 -o c3 -- python3 b
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_c3 -o c3 -- python3 bench.py --steps 6 --warmup 2 $P > $O/write_c3.json 2> $O/write_c3.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_c5 -o c5 -- python3 bench.py --steps 3 --warmup 1 --p 5000 --rows 200000 --dtype f32 $P > $O/fetch_c5.json 2> $O/fetch_c5.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_c5 -o c5 -- python3 bench.py --steps 3 --warmup 1 --p 5000 --rows 200000 --dtype f32 $P > $O/write_c5.json 2> $O/write_c5.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_c2 -o c2 -- python3 bench.py --steps 16 --warmup 8 --p 100 --rows 10000 $P > $O/fetch_c2.json 2> $O/fetch_c2.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_c2 -o c2 -- python3 bench.py --steps 16 --warmup 8 --p 100 --rows 10000 $P > $O/write_c2.json 2> $O/write_c2.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_c2 -o c2 -- python3 bench.py --steps 16 --warmup 16 --p 100 --rows 10000 $P > $O/fetch_c2.json 2> $O/fetch_c2.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_c2 -o c2 -- python3 bench.py --steps 16 --warmup 16 --p 100 --rows 10000 $P > $O/write_c2.json 2> $O/write_c2.err
 echo pmc done
 # the Gram kernels' fabric traffic, XCD-contiguous unit map against the natural one
 bash tools/gram_pmc.sh > $O/gram_pmc.log 2>&1
 # per-dispatch hardware counters of a few C3 steps (matrix-pipe busy, clock, waits)
 bash tools/pmc_diag.sh > $O/pmc_diag.log 2>&1 && python3 tools/pmc_diag_summary.py > $O/pmc_diag_summary.txt 2>&1
+fi
+
+if [ "$PART" = "c2" ]; then
+# the C2 lines alone (after a change that touches only the small-problem path)
+python3 bench.py --steps 256 --warmup 16 --p 100 --rows 10000 > $O/bench_c2.json 2> $O/bench_c2.err
+python3 tools/full_run_probe.py 100 10000 64 > $O/full_run_c2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -o c2 -- python3 bench.py --steps 256 --warmup 16 --p 100 --rows 10000 $P > $O/stats_c2.json 2> $O/stats_c2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fr2 -o fr2 -- python3 tools/full_run_probe.py 100 10000 64 > $O/stats_fr2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_c2 -o c2 -- python3 bench.py --steps 16 --warmup 16 --p 100 --rows 10000 $P > $O/fetch_c2.json 2> $O/fetch_c2.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_c2 -o c2 -- python3 bench.py --steps 16 --warmup 16 --p 100 --rows 10000 $P > $O/write_c2.json 2> $O/write_c2.err
+echo c2 done
 fi
 echo all done
