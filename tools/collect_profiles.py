@@ -41,7 +41,10 @@ if os.path.exists(os.path.join(SRC, "pmc_diag_summary.txt")):
     print(f"profiles/{TAG}_c3_pmc_diag.txt")
 # (config, p, batch, dtype, steps executed by the PMC runs = warm-up + timed + event pass)
 for cfg, p, b, dt, steps in (("c3", 1000, 128, "f64", 2 + 6 + 6), ("c5", 5000, 128, "f32", 1 + 3 + 3),
-                             ("c2", 100, 128, "f64", 8 + 16 + 16)):   # (warm-up + timed + event pass; no sustained region: $P)
+                             ("c2", 100, 128, "f64", 64)):   # (warm-up + timed + event pass; no sustained region: $P;
+                                                             #  c2: four launches of a 16-step group -- a priming launch
+                                                             #  (bench.py: the group's workspace before anything is timed),
+                                                             #  warm-up, timed region, event pass)
     if not os.path.exists(os.path.join(SRC, f"stats_{cfg}", f"{cfg}_kernel_stats.csv")):
         print(f"(no {cfg} artefacts in {SRC})")
         continue
@@ -56,3 +59,17 @@ for cfg, p, b, dt, steps in (("c3", 1000, 128, "f64", 2 + 6 + 6), ("c5", 5000, 1
                     os.path.join(DST, f"{TAG}_{cfg}_pmc_fetch_size.csv"), os.path.join(DST, f"{TAG}_{cfg}_pmc_write_size.csv"),
                     "--label", cfg, "--p", str(p), "--batch-size", str(b), "--dtype", dt, "--steps", str(steps), "--tag", TAG],
                    check=True)
+
+# the public call over a many-check run (tools/full_run_probe.py), alone and under rocprofv3 --kernel-trace --stats
+with open(os.path.join(DST, f"{TAG}_full_run_probe.log"), "w") as out:
+    for title, f in (("tools/full_run_probe.py 100 10000 64 (C2: the public call over 65 checks)", "full_run_c2.log"),
+                     ("tools/full_run_probe.py 1000 100000 128 (C3: 129 checks)", "full_run_c3.log"),
+                     (f"the same under rocprofv3 --kernel-trace --stats (profiles/{TAG}_full_run_c2_kernel_stats.csv)", "stats_fr2.log"),
+                     (f"the same under rocprofv3 --kernel-trace --stats (profiles/{TAG}_full_run_c3_kernel_stats.csv)", "stats_fr3.log")):
+        if os.path.exists(os.path.join(SRC, f)):
+            out.write(f"## {title}\n" + "".join(l for l in open(os.path.join(SRC, f)) if l.startswith("{")) + "\n")
+print(f"profiles/{TAG}_full_run_probe.log")
+for cfg in ("fr2", "fr3"):
+    f = os.path.join(SRC, f"stats_{cfg}", f"{cfg}_kernel_stats.csv")
+    if os.path.exists(f):
+        cp(f"stats_{cfg}/{cfg}_kernel_stats.csv", f"{TAG}_full_run_c{cfg[-1]}_kernel_stats.csv")
