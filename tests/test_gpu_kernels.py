@@ -819,18 +819,22 @@ def test_chunks_of_a_batch_folded_in_one_call(p, chunk, n_chunks):
         whole.close()
 
 
-@pytest.mark.parametrize("p", [24, 100])
-def test_a_group_of_checks_from_one_statistics_launch(p):
+@pytest.mark.parametrize("p,bs", [(24, 16), (100, 16), (126, 10), (12, 3), (13, 5), (61, 40)])
+def test_a_group_of_checks_from_one_statistics_launch(p, bs):
     """The public call on a small problem with the device estimator: a look-ahead group's chunks are folded by ONE
     statistics launch inside lsspa_group_collect and every chunk's check reads the mean and n as they stood after ITS
     chunk -- the error history, the attribution and its errors are those of the run that folds, merges and checks
     chunk by chunk (lookahead = 1, nothing deferred), to the last bit; also when the stop rule fires inside a group."""
     from ls_spa import ls_spa
     Xa, Xe, ya, ye = problem(5, p, 4 * p + 30, 3 * p + 20)
-    kw = dict(reg=1e-3, method="argsort", seed=3, batch_size=16, max_samples=16 * 21, error_estimator="device")
+    # (chunks of 10, 3, 5 and 40 samples: the normals' blocks are padded to 16 columns; 21 chunks in groups of 8, 8, 5)
+    kw = dict(reg=1e-3, method="argsort", seed=3, batch_size=bs, max_samples=bs * 21, error_estimator="device")
     ref = ls_spa(Xa, Xe, ya, ye, tolerance=0.0, lookahead=1, _defer=0, **kw)
     grp = ls_spa(Xa, Xe, ya, ye, tolerance=0.0, lookahead=8, **kw)
     assert len(ref.error_history) == len(grp.error_history) == 22          # 21 chunks and the check at max - 1
+    auto = ls_spa(Xa, Xe, ya, ye, tolerance=0.0, **kw)                       # the default: groups of up to 16
+    np.testing.assert_array_equal(auto.error_history, ref.error_history)
+    np.testing.assert_array_equal(auto.attribution, ref.attribution)
     np.testing.assert_array_equal(grp.error_history, ref.error_history)
     np.testing.assert_array_equal(grp.attribution, ref.attribution)
     np.testing.assert_array_equal(grp.attribution_errors, ref.attribution_errors)
