@@ -233,7 +233,10 @@ int lsspa_error_result(lsspa_ctx* ctx, int32_t slot, int32_t wait, int32_t* read
  * of several ranks lsspa_stats_allreduce + lsspa_stats_merge; lsspa_error_advance(first_id[c], stride); and, where
  * n_after[c] > 0, the check of that global sample count into slot[c] (one rank: lsspa_error_check_enqueue; several:
  * lsspa_error_running_draws + lsspa_error_allreduce + lsspa_error_quantiles_enqueue).  Nothing waits; the results are
- * read with lsspa_error_result.  Order and arithmetic are those of the separate calls (ls_spa/ls_spa.py:203-230). */
+ * read with lsspa_error_result.  Order and arithmetic are those of the separate calls (ls_spa/ls_spa.py:203-230).
+ * One rank, p <= 128, 2 .. 32 chunks of up to 512 samples that follow each other in the batch: the statistics, the
+ * estimator's sums and all the checks of the call are five launches (the state after every chunk is kept for the check
+ * that belongs to it) -- the numbers are those of the chunk-by-chunk calls to the last bit. */
 int lsspa_group_collect(lsspa_ctx* ctx, int32_t ticket, int32_t n_chunks, const int32_t* first, const int32_t* count,
                         const int64_t* first_id, int64_t stride, const int64_t* n_after, const int32_t* slot);
 int lsspa_error_state_get(lsspa_ctx* ctx, double* D, double* s);
