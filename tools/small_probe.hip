@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
   hipMemcpy(dG, G.data(), G.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dg, g.data(), g.size() * 8, hipMemcpyHostToDevice);
   hipMemcpy(dp, perms.data(), perms.size() * 4, hipMemcpyHostToDevice); hipMemset(di, 0, 32); hipMemset(dl, 0, (size_t)n_ord * p * 8);
   SmallArgs a; a.S[0] = a.S[1] = dG; a.s[0] = a.s[1] = dg; a.aug[0] = a.aug[1] = 10.0; a.ld_src = ld; a.perms = dp; a.p = p; a.nb = (p + 16) / 16;
-  a.variant = argc > 3 ? atoi(argv[3]) : 0;
+  a.variant = argc > 3 ? atoi(argv[3]) : 0; a.fwd_only = 0; a.r2 = 0.0; a.sum_tol = -1.0; a.sum_quiet = 0.0;
   a.n_ord = n_ord; a.per_sample = 1; a.lifts = dl; a.y_norm_sq = 5.0; a.piv_tol = 1e-12; a.info = di;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
