@@ -57,12 +57,13 @@ def parse():
                     help="transport of the all-reduce with several ranks: RCCL through the C ABI, or torch.distributed")
     ap.add_argument("--lookahead", type=int, default=0,
                     help="steps whose orderings are launched as one GPU batch and then accumulated / all-reduced / merged "
-                         "step by step (what ls_spa(lookahead=k) does); 0 = auto: 16 for p <= 126, 4 when a rank's step "
-                         "has <= 32 samples, else 1")
+                         "step by step (what ls_spa(lookahead=k) does); 0 = auto: up to p = 800 what ls_spa(lookahead='auto') "
+                         "takes (at 128 samples a step: 16 steps for p <= 127, 8 up to p = 250, 4 up to 800), beyond 4 when a "
+                         "rank's step has <= 32 samples, else 1")
     ap.add_argument("--lanes", type=int, choices=(0, 1, 2), default=0,
                     help="batches in flight on the engine (lsspa_set_lanes): 2 = the next step's kernels start when this "
                          "step's are half way (two workspaces, two streams; statistics stay in batch order); 0 = auto: 2 on "
-                         "the general path (p > 126), 1 for the fused small-p kernel")
+                         "the general path (p > 127), 1 for the fused small-p kernel")
     ap.add_argument("--split", type=int, default=0,
                     help="with two lanes: a step's batch goes to the engine as this many consecutive sub-batches (each its own "
                          "launch sequence, alternating lanes): a shorter pipeline, so less fill / drain inside a K-step region; "
@@ -79,7 +80,7 @@ def parse():
     ap.add_argument("--full-run-batches", type=int, default=0,
                     help="checks of the full_run leg: ls_spa(method='argsort', batch_size=B, num_batches=this, tolerance=0); "
                          "0 = auto: 128 (BASELINE config 4's num_batches) up to p = 2000, 64 (the reference's default "
-                         "max_samples = 8192 at batch 128) for p <= 126, 16 beyond p = 2000")
+                         "max_samples = 8192 at batch 128) for p <= 127, 16 beyond p = 2000")
     ap.add_argument("--data", choices=("gaussian", "correlated"), default="gaussian",
                     help="gaussian: BASELINE.md section 3 (default_rng(0)), the data the metric is quoted on; correlated: "
                          "the reference's own generator (experiments/ground_truth_medium.py:74-106, seed 42) at the same "
@@ -365,7 +366,7 @@ def main():
     import torch.distributed as dist
     from ls_spa import ls_spa
     from ls_spa._engine import HipEngine
-    from ls_spa._driver import run_estimator, _Comm
+    from ls_spa._driver import run_estimator, _Comm, SMALL_P_MAX, auto_lookahead
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -386,7 +387,7 @@ def main():
 
     p, rows, B = args.p, args.rows, args.batch_size
     if args.lanes == 0:
-        args.lanes = 2 if p > 126 else 1
+        args.lanes = 2 if p > SMALL_P_MAX else 1
     reg = args.reg if args.reg is not None else (1e-2 if args.dtype == "f32" else 0.0)
     label = config_label(p, rows, args.dtype)
     if args.scaling == "strong" and B % world:
@@ -511,7 +512,7 @@ def main():
 
     # auto: a step that fills a fraction of the GPU (few samples per rank, or the one-workgroup-per-ordering kernel
     # of small problems) is launched in groups
-    D = args.lookahead if args.lookahead > 0 else (16 if p + 1 <= 128 else (4 if B_rank <= 32 else 1))
+    D = args.lookahead if args.lookahead > 0 else (auto_lookahead(p, B_rank) if p <= 800 else (4 if B_rank <= 32 else 1))
 
     class Steps:
         """step(k) = one batch of b_rank samples into the statistics.  With d > 1 the kernels of d consecutive steps
@@ -680,7 +681,7 @@ def main():
     strong = None
     if world > 1 and args.scaling == "weak" and B % world == 0:
         b_s = B // world
-        d_s = args.lookahead if args.lookahead > 0 else (8 if p + 1 <= 128 else max(1, min(8, 64 // b_s)))
+        d_s = args.lookahead if args.lookahead > 0 else (8 if p <= SMALL_P_MAX else max(1, min(8, 64 // b_s)))
         src_s = S.ArgsortSource(p, 42, 2 ** 62)
         perms_s = np.ascontiguousarray(src_s.take(total_steps * B).astype(np.int32)
                                        .reshape(total_steps, B, p)[:, rank::world])
@@ -1006,7 +1007,7 @@ def main():
         # fires.  One GPU: ls_spa() on the host arrays (reduction over PCIe included in `seconds`, not in the loop's
         # rate); several ranks: the sharded loop on the resident problem.
         if not args.no_full_run:
-            nb = args.full_run_batches or (64 if p <= 126 else (128 if p <= 2000 else 16))
+            nb = args.full_run_batches or (64 if p <= SMALL_P_MAX else (128 if p <= 2000 else 16))
 
             def full_run():
                 reps = []

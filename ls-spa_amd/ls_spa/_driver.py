@@ -32,6 +32,29 @@ from ._native import LSSPANativeError
 from ._results import ShapleyResults, validate_data
 from ._stats import error_estimates, error_estimates_lowrank
 
+# problems up to this many features take the one-workgroup-per-ordering kernels (csrc/k_small.hip small_p_eligible:
+# p + 1 <= 128): one lane, look-ahead groups of up to sixteen chunks, larger sampler blocks
+SMALL_P_MAX = 127
+
+
+def auto_lookahead(p, per_rank):
+    """Chunks of `per_rank` samples launched as one batch when nobody says otherwise (lookahead='auto').
+
+    A chunk of fewer than 64 samples per rank leaves most of an MI355X idle at p = 1000 -- as many
+    chunks as make up 64, eight at most.  Smaller problems need more samples to fill the chip (the work of an ordering
+    goes with p^3, its tiles with p^2; bench.py at 128 samples a step, one against the best look-ahead: p = 150 0.67 ->
+    0.93 M orderings/s at 8, p = 200 0.65 -> 0.91 at 8, p = 300 0.39 -> 0.45 at 4, p = 500 0.21 -> 0.23 at 4, p = 700 +2 %,
+    p = 1000 -1 %): 1024 samples up to p = 250, 512 up to p = 800.  Small problems (the one-workgroup-per-ordering
+    kernels): a group costs the host one call and the GPU ~45 us of dependent launches around its lift kernel whatever
+    its size (statistics, estimator and checks of all its chunks are five launches), against 25 us of kernel per chunk
+    of 128 samples at p = 100 -- as many chunks as make up 2048 samples, sixteen at most; a chunk of 1024 samples fills
+    the chip four times over by itself."""
+    per_rank = max(int(per_rank), 1)
+    if p <= SMALL_P_MAX:
+        return 1 if per_rank >= 1024 else max(1, min(16, 2048 // per_rank))
+    want = 1024 if p <= 250 else (512 if p <= 800 else 64)
+    return max(1, min(8, want // per_rank))
+
 _NO_CAP = 2 ** 100
 
 # ---- engines kept between calls ------------------------------------------------------------------------------------
@@ -257,7 +280,7 @@ def prepare_sampling(p, *, max_samples, batch_size, seed, perms, antithetical, m
     if source.independent:
         # the QMC samplers draw ahead of the loop on a helper thread (their stream is nobody else's), from now on --
         # in ls_spa() that is under the data reduction
-        source = S.PrefetchedSource(source, block=1024 if p <= 126 else 256, rank=rank, world=world)
+        source = S.PrefetchedSource(source, block=1024 if p <= SMALL_P_MAX else 256, rank=rank, world=world)
     return rng, source, batch_size, antithetical, max_samples, never_stop
 
 
@@ -366,16 +389,7 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
     # checks are enqueued behind the chunks' statistics and read late (below): the next group is launched when the
     # current one has been taken up, whatever its checks will say.
     if lookahead == "auto":
-        # automatic: a chunk of fewer than 64 samples per rank leaves most of an MI355X idle (§6 of DESIGN.md) --
-        # launch as many chunks together as make up 64, eight at most.  Small problems (the one-workgroup-per-ordering
-        # kernels, p <= 126): a group costs the host one call and the GPU ~45 us of dependent launches around its lift
-        # kernel whatever its size (statistics, estimator and checks of all its chunks are five launches), against 25 us
-        # of kernel per chunk of 128 samples at p = 100 -- as many chunks as make up 2048 samples, sixteen at most.
-        per_rank = -(-int(batch_size) // comm.world)
-        small = p <= 126
-        lookahead = max(1, min(16 if small else 8, (2048 if small else 64) // max(per_rank, 1)))
-        if small and per_rank >= 1024:
-            lookahead = 1         # such a chunk fills the chip four times over by itself
+        lookahead = auto_lookahead(p, -(-int(batch_size) // comm.world))
     group = max(1, int(lookahead)) if (hasattr(engine, "launch_batch") and source.independent and not chunk_cap) else 1
     # The device estimator's checks are ENQUEUED, not waited for: x = (D - s mean^T) / sqrt(n (n - 1)), the all-reduce of
     # the per-rank x, the quantile kernels and a copy of (errors, running mean, n) into a pinned slot run on the context's
@@ -669,14 +683,15 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
     lookahead:  QMC samplers ('argsort', 'permutohedron') only.  k > 1 launches the orderings of k chunks as one GPU
         batch (a chunk of batch_size / n_gpus samples may fill a fraction of the GPU), accumulates and checks them
         chunk by chunk in the reference's order and drops the chunks beyond a stop.  Same results; at most k
-        chunks of wasted GPU work at the end of a run.  'auto': 1 when a rank's chunk has 64 samples or more (1024 for
-        p <= 126, the one-workgroup-per-ordering kernels), else as many chunks as make up that, eight at most.  Default:
+        chunks of wasted GPU work at the end of a run.  'auto' (auto_lookahead): as many chunks as make up 64 samples
+        per rank (512 up to p = 800, 1024 up to p = 250: smaller problems need more samples to fill the chip), eight
+        at most; 2048 and sixteen for p <= 127, the one-workgroup-per-ordering kernels.  Default:
         'auto' for the QMC methods with the device estimator (whose checks the loop does not wait for), else 1.
     lanes:  1, 2 or 'auto'.  2: successive chunk groups alternate between two workspaces on two HIP streams, the next
         group's kernels starting when the current group's are half way, its orderings drawn and uploaded before the
         current group's statistics are read back; a chunk of 64 samples or more per rank goes as two half-chunks (QMC
         samplers only, as for lookahead; same results up to the rounding of the half-chunk grouping of the statistics;
-        a stop wastes at most one group of GPU work).  'auto': 2 for the QMC methods when p > 126 (the fused small-p
+        a stop wastes at most one group of GPU work).  'auto': 2 for the QMC methods when p > 127 (the fused small-p
         kernel gains nothing from it), else 1.
     comm:  several GPUs, one process each: the communicator every rank passes -- ``NativeComm.from_env()``
         (RCCL through the C ABI, no PyTorch) or ``TorchComm()`` (torch.distributed: RCCL, or gloo on CPU in
@@ -740,7 +755,7 @@ def ls_spa(X_train, X_test, y_train, y_test, reg=0., max_samples=2 ** 13, batch_
         if lookahead != "auto" and int(lookahead) < 1:
             raise ValueError("lookahead must be >= 1 or 'auto'")
         if lanes == "auto":
-            lanes = 2 if (perms is None and method in ("argsort", "permutohedron") and p > 126) else 1
+            lanes = 2 if (perms is None and method in ("argsort", "permutohedron") and p > SMALL_P_MAX) else 1
         if int(lanes) not in (1, 2):
             raise ValueError("lanes must be 1, 2 or 'auto'")
         if hasattr(engine, "set_lanes") and getattr(engine, "lanes", 1) != int(lanes):

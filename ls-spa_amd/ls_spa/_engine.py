@@ -336,6 +336,7 @@ class HipEngine:
 
     # ---- running form of the device-side estimator (include/lsspa.h) ---------------------
     RESULT_SLOTS = 64
+    SMALL_P_MAX = 127      # csrc/k_small.hip small_p_eligible: p + 1 <= 128 takes the one-workgroup-per-ordering kernels
 
     def error_running_enable(self, seed: int):
         """D = Xi L and s = Xi 1 stay in HBM; Xi is a function of (seed, sample id, draw)."""
