@@ -388,8 +388,14 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
     # wastes up to k chunks of GPU work, which only the final read-back waits for).  With the device-side estimator the
     # checks are enqueued behind the chunks' statistics and read late (below): the next group is launched when the
     # current one has been taken up, whatever its checks will say.
+    ramp = None
     if lookahead == "auto":
         lookahead = auto_lookahead(p, -(-int(batch_size) // comm.world))
+        # the automatic groups grow: 1, 2, 4, ... chunks up to the size above.  A run that stops at one of its first checks
+        # -- the usual run to a tolerance -- then has its answer after about as many chunks as it needed, not after a
+        # whole group (its kernels are one launch: none of its checks is known before all of its chunks have run); a long
+        # run is at the full size after log2 of it groups.  An explicit lookahead = k is k from the first group on.
+        ramp = [1]
     group = max(1, int(lookahead)) if (hasattr(engine, "launch_batch") and source.independent and not chunk_cap) else 1
     # The device estimator's checks are ENQUEUED, not waited for: x = (D - s mean^T) / sqrt(n (n - 1)), the all-reduce of
     # the per-rank x, the quantile kernels and a copy of (errors, running mean, n) into a pinned slot run on the context's
@@ -456,11 +462,21 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
     if prefetch and group == 1 and -(-(int(batch_size) + 1) // 2 // comm.world) >= 32:
         sub_cap = (int(batch_size) + 1) // 2
     queue = []
+    group_of = {}      # id(ticket) -> chunks launched with it: as many checks may be outstanding behind one of them
+
+    def allowed(ticket):
+        """Checks that may stay unread once a check of this ticket's group has been enqueued: the group's own (their
+        kernels were one launch), `defer` at most."""
+        return defer if (ramp is None or ticket is None) else max(min(defer, group_of.get(id(ticket), defer)), 1 if defer else 0)
 
     def refill(i_now):
         nonlocal t_sampler
         entries, cursor = [], i_now
-        for _ in range(group):
+        size = group
+        if ramp is not None:
+            size = min(group, ramp[0])
+            ramp[0] *= 2
+        for _ in range(size):
             if cursor >= max_samples:
                 break
             target = _next_check(cursor, batch_size, max_samples)
@@ -489,6 +505,8 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
         for e in entries:
             e += [ticket, first]
             first += len(e[1])
+        if ticket is not None:
+            group_of[id(ticket)] = len(entries)
         queue.extend(entries)
 
     # the whole group in one library call: device estimator with its checks deferred by a group at least, nothing that
@@ -550,7 +568,7 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
                 engine.group_collect(ticket, firsts, counts, ids, comm.world, n_after, slots)
                 outstanding.extend((n_a, sl) for n_a, sl in zip(n_after, slots) if n_a)
                 i, pending = cursor, n_after[-1] == 0
-                halt = resolve_due(defer)
+                halt = resolve_due(allowed(ticket))
                 if timings is not None and "check_s" in timings:
                     k = max(1, sum(1 for v in n_after if v))
                     timings["check_s"].extend([(_time.perf_counter() - t_g0) / k] * k)
@@ -600,7 +618,7 @@ def _run_estimator(engine, p, comm, rng, source, batch_size, antithetical, max_s
             enqueue_check(i)
             t_estimator += _time.perf_counter() - t_e0
             pending = False
-            halt = resolve_due(defer)
+            halt = resolve_due(allowed(ticket))
             if timings is not None and "check_s" in timings:
                 timings["check_s"].append(_time.perf_counter() - t_e0)
             if halt:

@@ -181,16 +181,18 @@ def test_deferred_checks_give_the_stopping_checks_results(golden):
         extra = 0 if k in (0, 6) else (15 if k == 4 else 16)
         assert sum(e0.calls) == min(16 * (k + 1), 96 if k == 6 else 95 if k == 5 else 10 ** 9)
         assert sum(e1.calls) == sum(e0.calls) + (1 if k == 5 else extra)
-    # the default look-ahead of this method and estimator ('auto': chunks of 16 samples at p = 12 go eight to a launch,
-    # and as many checks may be outstanding): the same numbers again
+    # the default look-ahead of this method and estimator ('auto': chunks of 16 samples at p = 12 go up to sixteen to a
+    # launch, in groups that grow -- 1, 2, 4, ... chunks -- and as many checks as the group has may be outstanding): the
+    # same numbers again; the stop at check 4 falls into the third group
     tol = float(full.error_history[3]) * 1.0000001
     e8 = OracleEngine()
     c = ls_spa(*d, tolerance=tol, _engine=e8, **dict(base, lookahead=None))
     a = ls_spa(*d, tolerance=tol, _engine=OracleEngine(), _defer=0, **base)
     np.testing.assert_array_equal(c.error_history, a.error_history)
     np.testing.assert_array_equal(c.attribution, a.attribution)
-    assert e8.launched == 1 and len(c.error_history) == 4
-    assert e8.group_calls == 1            # ... and the group's chunks went through ONE library call (lsspa_group_collect)
+    assert e8.launched == 3 and len(c.error_history) == 4
+    assert e8.group_calls == 3            # ... and every group's chunks went through ONE library call (lsspa_group_collect)
+    assert e8.calls == [16, 16, 16, 16, 16, 15, 1]       # groups of 1, 2 and 4 chunks (the check at max_samples - 1 cuts one)
     e3 = OracleEngine()
     c3 = ls_spa(*d, tolerance=0.0, _engine=e3, **dict(base, lookahead=3))
     np.testing.assert_array_equal(c3.error_history, full.error_history)
@@ -625,12 +627,12 @@ def test_lookahead_keeps_the_reference_order(golden):
         assert e4.launched == 0 and e4.discarded == 0
     with pytest.raises(ValueError):
         ls_spa(*d, lookahead=0, _engine=OracleEngine())
-    # 'auto': small problems (p <= 126, one workgroup per ordering) go up to sixteen chunks to a launch up to 2048
-    # samples, chunks of 1024 samples and more one at a time
+    # 'auto': small problems (p <= 127, one workgroup per ordering) go up to sixteen chunks to a launch up to 2048
+    # samples -- in groups of 1, 2, 4, ... chunks --, chunks of 1024 samples and more one at a time
     ea, eb = OracleEngine(), OracleEngine()
     auto = ls_spa(*d, method="argsort", seed=5, max_samples=96, batch_size=16, tolerance=0.0, lookahead="auto", _engine=ea)
     np.testing.assert_array_equal(auto.attribution, first.attribution)
-    assert ea.launched == 1                       # 7 chunks in one group of (up to) 16
+    assert ea.launched == 3                       # 7 chunks in groups of 1, 2 and 4: the automatic groups grow
     ls_spa(*d, method="argsort", seed=5, max_samples=2048, batch_size=1024, tolerance=0.0, lookahead="auto", _engine=eb)
     assert eb.launched == 0
 
