@@ -2075,18 +2075,14 @@ static int quantiles_enqueue(lsspa_ctx* ctx, int32_t slot, bool record) {
   return finish_check(ctx, slot, record);
 }
 
-static int check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot, bool record, const double* mean_at = nullptr,
-                         const double* n_at = nullptr);
+static int check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot, bool record);
 int lsspa_error_check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot) try {
   return check_enqueue(ctx, n_total, slot, true);
 } catch (...) {
   return abi_caught(ctx);
 }
 
-// mean_at / n_at: the running mean and n the check belongs to, when they are not the context's current ones (a group of
-// chunks folded in one launch: the snapshots after the check's own chunk)
-static int check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot, bool record, const double* mean_at,
-                         const double* n_at) {
+static int check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot, bool record) {
   if (!ctx || n_total < 0 || slot < 0 || slot >= lsspa_ctx::RES_SLOTS) return LSSPA_ERR_ARG;
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   if (!ctx->run_on) return ctx->fail(LSSPA_ERR_STATE, "the running estimator is not enabled");
@@ -2098,10 +2094,9 @@ static int check_enqueue(lsspa_ctx* ctx, int64_t n_total, int32_t slot, bool rec
   const double scale = 1.0 / sqrt(nt * (nt - 1.0));
   {
     ProfScope ps(ctx, LSSPA_K_ERROR);
-    HIPCHK(launch_error_quantiles_running(ctx->Dacc.ptr, ctx->sacc.ptr, mean_at ? mean_at : ctx->mean.ptr, scale,
-                                          ctx->ldh(), (int)p, ctx->err_out.ptr + 2 * p + 2,
-                                          ctx->res_hd + (size_t)slot * (2 * p + 2), n_at ? n_at : ctx->state_n.ptr,
-                                          ctx->stream));
+    HIPCHK(launch_error_quantiles_running(ctx->Dacc.ptr, ctx->sacc.ptr, ctx->mean.ptr, scale, ctx->ldh(), (int)p,
+                                          ctx->err_out.ptr + 2 * p + 2, ctx->res_hd + (size_t)slot * (2 * p + 2),
+                                          ctx->state_n.ptr, ctx->stream));
   }
   return finish_check(ctx, slot, record);
 }
