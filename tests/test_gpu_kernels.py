@@ -819,8 +819,9 @@ def test_chunks_of_a_batch_folded_in_one_call(p, chunk, n_chunks):
         whole.close()
 
 
-@pytest.mark.parametrize("p,bs", [(24, 16), (100, 16), (126, 10), (12, 3), (13, 5), (61, 40)])
-def test_a_group_of_checks_from_one_statistics_launch(p, bs):
+@pytest.mark.parametrize("p,bs,anti", [(24, 16, True), (100, 16, True), (126, 10, True), (12, 3, True), (13, 5, True),
+                                       (61, 40, True), (40, 16, False), (127, 7, False)])
+def test_a_group_of_checks_from_one_statistics_launch(p, bs, anti):
     """The public call on a small problem with the device estimator: a look-ahead group's chunks are folded by ONE
     statistics launch inside lsspa_group_collect and every chunk's check reads the mean and n as they stood after ITS
     chunk -- the error history, the attribution and its errors are those of the run that folds, merges and checks
@@ -828,7 +829,8 @@ def test_a_group_of_checks_from_one_statistics_launch(p, bs):
     from ls_spa import ls_spa
     Xa, Xe, ya, ye = problem(5, p, 4 * p + 30, 3 * p + 20)
     # (chunks of 10, 3, 5 and 40 samples: the normals' blocks are padded to 16 columns; 21 chunks in groups of 8, 8, 5)
-    kw = dict(reg=1e-3, method="argsort", seed=3, batch_size=bs, max_samples=bs * 21, error_estimator="device")
+    kw = dict(reg=1e-3, method="argsort", seed=3, batch_size=bs, max_samples=bs * 21, error_estimator="device",
+              antithetical=anti)
     ref = ls_spa(Xa, Xe, ya, ye, tolerance=0.0, lookahead=1, _defer=0, **kw)
     grp = ls_spa(Xa, Xe, ya, ye, tolerance=0.0, lookahead=8, **kw)
     assert len(ref.error_history) == len(grp.error_history) == 22          # 21 chunks and the check at max - 1
