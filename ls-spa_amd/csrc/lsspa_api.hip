@@ -1698,6 +1698,11 @@ int lsspa_lift_collect_chunks(lsspa_ctx* ctx, int32_t ticket, int32_t first, int
   if (!ctx->have_problem) return ctx->fail(LSSPA_ERR_STATE, "no problem loaded");
   HIPCHK(hipSetDevice(ctx->device));
   Lane& L = ctx->lanes[ticket];
+  // everything a part could be refused for, before the first part is taken: a refused call leaves the lane as it was
+  if (!L.in_flight) return ctx->fail(LSSPA_ERR_STATE, "no launched batch on this lane");
+  if (first != L.taken || (int64_t)first + (int64_t)n_chunks * chunk > L.B)
+    return ctx->fail(LSSPA_ERR_ARG, "parts of a launched batch are collected front to back, without gaps, inside the batch");
+  TRY(check_accumulate(ctx, accumulate));
   if (accumulate == 2 && n_chunks <= StatsChunks::MAX) {
     int32_t f[StatsChunks::MAX], k[StatsChunks::MAX];
     for (int c = 0; c < n_chunks; ++c) {
@@ -2186,6 +2191,17 @@ int lsspa_group_collect(lsspa_ctx* ctx, int32_t ticket, int32_t n_chunks, const 
     if (first_id[c] < 0 || n_after[c] < 0 || slot[c] < 0 || slot[c] >= lsspa_ctx::RES_SLOTS)
       return ctx->fail(LSSPA_ERR_ARG, "sample ids and counts must be non-negative, slots within range");
   HIPCHK(hipSetDevice(ctx->device));
+  {   // the chunks follow each other from the lane's next sample on, inside the batch: checked before the first is taken
+    const Lane& Lc = ctx->lanes[ticket];
+    if (!Lc.in_flight) return ctx->fail(LSSPA_ERR_STATE, "no launched batch on this lane");
+    int64_t next = Lc.taken;
+    for (int c = 0; c < n_chunks; ++c) {
+      if (count[c] < 0 || (count[c] > 0 && first[c] != next))
+        return ctx->fail(LSSPA_ERR_ARG, "parts of a launched batch are collected front to back, without gaps");
+      next += count[c];
+    }
+    if (next > Lc.B) return ctx->fail(LSSPA_ERR_ARG, "the chunks reach beyond the launched batch");
+  }
   // a communicator on the context (of one rank or of many): the moments and the draws go through it, as in the
   // separate calls; none: the chunk is folded and merged at once
   const bool several = ctx->comm != nullptr;

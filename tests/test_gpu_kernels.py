@@ -881,3 +881,40 @@ def test_every_batch_checks_its_sums(p):
         assert eng.info() == 0
     finally:
         eng.close()
+
+
+def test_collect_chunks_refuses_what_collect_refuses():
+    """lsspa_lift_collect_chunks is lsspa_lift_collect part after part: parts out of turn, beyond the batch or of no
+    samples are refused with the lane left as it was (the batch can still be collected), and the R^2 test hook needs a
+    full fit first."""
+    from ls_spa._engine import HipEngine
+    Xa, Xe, ya, ye = problem(3, 30, 200, 150)
+    rng = np.random.default_rng(0)
+    eng = HipEngine(0)
+    try:
+        eng.load_data(Xa, Xe, ya, ye, 1e-3)
+        with pytest.raises(Exception, match="full_fit"):
+            eng._check(eng._lib.lsspa_debug_set_r2(eng._h, 0.5))
+        perms = np.array([rng.permutation(30) for _ in range(40)])
+        tk = eng.launch_batch(perms, True)
+        with pytest.raises(Exception):
+            eng.collect_chunks(tk, 8, 8, 2)            # not from the front
+        with pytest.raises(Exception):
+            eng.collect_chunks(tk, 0, 16, 3)           # 48 > 40 samples
+        with pytest.raises(Exception):
+            eng.collect_chunks(tk, 0, 0, 2)            # empty parts
+        with pytest.raises(Exception):
+            eng.collect_chunks(tk, 0, 8, 2, accumulate=3)
+        eng.collect_chunks(tk, 0, 8, 5)                # the whole batch, five parts in one launch
+        ref = HipEngine(0)
+        try:
+            ref.load_data(Xa, Xe, ya, ye, 1e-3)
+            ref.run_batch(perms[:8], True, accumulate=2)
+            for k in range(1, 5):
+                ref.run_batch(perms[8 * k:8 * k + 8], True, accumulate=2)
+            np.testing.assert_array_equal(eng.stats()[2], ref.stats()[2])
+            np.testing.assert_array_equal(eng.stats()[1], ref.stats()[1])
+        finally:
+            ref.close()
+    finally:
+        eng.close()
