@@ -314,6 +314,31 @@ def test_sources_hand_out_a_ranks_share():
         S.PrefetchedSource(S.ArgsortSource(9, 1, 50), rank=0, world=2).take_share(4, 3, 0, 2)
 
 
+def test_prefetched_source_in_one_process():
+    """One process: the helper thread draws the orderings in blocks of its own ahead of the loop (PrefetchedSource);
+    what comes out is the plain source's sequence, whatever the block size, the look-ahead limit and the sizes asked
+    for -- also when the source ends inside a block, when it is asked for more than it has, and when it is closed with
+    thousands of orderings never asked for."""
+    for cls, p in ((S.ArgsortSource, 23), (S.PermutohedronSource, 23), (S.ArgsortSource, 140)):
+        full = cls(p, 5, 1000).take(333)
+        assert full.dtype == np.int32
+        for block, ahead in ((7, 20), (64, 128), (100, 100), (400, 800)):
+            src = S.PrefetchedSource(cls(p, 5, 333), block=block, ahead=ahead)
+            rows, pos = [], 0
+            for cnt in (1, 10, 100, 7, 120, 50, 80):
+                n, own = src.take_share(cnt, pos, 0, 1)
+                assert n == len(own) == min(cnt, 333 - pos)
+                rows.append(own)
+                pos += n
+            assert pos == 333 and src.take_share(5, pos, 0, 1)[0] == 0
+            np.testing.assert_array_equal(np.concatenate(rows), full)
+            src.close()
+        early = S.PrefetchedSource(cls(p, 5, 10 ** 6), block=256, ahead=4096)
+        np.testing.assert_array_equal(early.take(20), full[:20])
+        early.close()                      # thousands of orderings drawn ahead and never asked for
+        assert not early._thread.is_alive() or early._thread.join(5) is None
+
+
 def test_iterable_source_is_lazy():
     pulled = []
 
