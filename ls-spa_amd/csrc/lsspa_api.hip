@@ -2212,8 +2212,7 @@ int lsspa_group_collect(lsspa_ctx* ctx, int32_t ticket, int32_t n_chunks, const 
   if (chunks_fusable(ctx, Lg, n_chunks, first, count)) {
     // small problem, one rank: the group's statistics in one launch; every check reads the mean and n after ITS chunk
     // ... and the estimator likewise: the chunks' products side by side, summed in order with a snapshot per chunk, all
-    // the checks' quantiles in one launch (launch_error_group) -- 6 launches a group instead of 5 a chunk
-    TRY(collect_chunks_small(ctx, Lg, n_chunks, first, count, true));
+    // the checks' quantiles in one launch (launch_error_group) -- five launches a group instead of five a chunk
     EstChunks ch;
     EstChecks ck;
     ch.n = n_chunks;
@@ -2243,6 +2242,8 @@ int lsspa_group_collect(lsspa_ctx* ctx, int32_t ticket, int32_t n_chunks, const 
     TRY(dev_alloc(ctx, ctx->grp_S, (size_t)n_chunks * ERR_DRAWS));
     TRY(dev_alloc(ctx, ctx->grp_s, (size_t)n_chunks * ERR_DRAWS));
     TRY(dev_alloc(ctx, ctx->grp_norms, (size_t)n_chunks * ERR_DRAWS));
+    // (every buffer is there before the first launch: a refused allocation leaves statistics and estimator in step)
+    TRY(collect_chunks_small(ctx, Lg, n_chunks, first, count, true));
     {
       ProfScope ps(ctx, LSSPA_K_ERROR);
       HIPCHK(launch_error_group(ctx->run_seed, stride, ch, ck, ctx->xi_d.ptr, Lg.lifts.ptr, ctx->p, (int)ld,
