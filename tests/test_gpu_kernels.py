@@ -918,3 +918,40 @@ def test_collect_chunks_refuses_what_collect_refuses():
             ref.close()
     finally:
         eng.close()
+
+
+def test_grouped_collect_survives_a_refused_allocation():
+    """The grouped form of lsspa_group_collect makes its buffers before its first launch: with the next device allocation
+    refused (test hook) the call fails, the lane still holds its batch and statistics and estimator have not moved --
+    the same call again goes through and gives what chunk-by-chunk calls give."""
+    from ls_spa._engine import HipEngine
+    Xa, Xe, ya, ye = problem(4, 30, 220, 160)
+    rng = np.random.default_rng(1)
+    perms = np.array([rng.permutation(30) for _ in range(48)])
+    args = ([0, 16, 32], [16, 16, 16], [0, 16, 32], 1, [16, 32, 48], [0, 1, 2])
+    eng, ref = HipEngine(0), HipEngine(0)
+    try:
+        for e in (eng, ref):
+            e.load_data(Xa, Xe, ya, ye, 1e-3)
+            e.full_fit()
+            e.error_running_enable(7)
+        tk = eng.launch_batch(perms, True)
+        eng.debug_fail_alloc(1)
+        with pytest.raises(MemoryError):
+            eng.group_collect(tk, *args)
+        eng.debug_fail_alloc(0)
+        assert eng.stats(want_cov=False)[0] == 0
+        eng.group_collect(tk, *args)
+        tr = ref.launch_batch(perms, True)
+        for c in range(3):
+            ref.collect_batch(tr, accumulate=2, first=16 * c, count=16)
+            ref.error_advance(16 * c, 1)
+            ref.error_check_enqueue(16 * (c + 1), c)
+        for c in range(3):
+            a, b = eng.error_result(c, wait=True), ref.error_result(c, wait=True)
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+        np.testing.assert_array_equal(eng.stats()[2], ref.stats()[2])
+    finally:
+        eng.close()
+        ref.close()
