@@ -307,6 +307,13 @@ int lsspa_set_flags(lsspa_ctx* ctx, int32_t flags);
 int lsspa_debug_fail_alloc(lsspa_ctx* ctx, int32_t nth);
 /* use the packed (upper-triangle) form of lsspa_stats_allreduce from this p on (default 2048) */
 int lsspa_debug_pack_from(lsspa_ctx* ctx, int32_t p_min);
+/* Host helper of the QMC ordering sources (the reference: np.argsort of Sobol' points / projected normals,
+ * experiments/ground_truth_medium.py:56-71): out [B][p] = the argsort of every row of keys [B][p], on up to `threads`
+ * threads of this library (no interpreter lock between them and the caller's other threads).  A row with all keys
+ * different has one argsort; redo[s] = 1 marks the rows with equal keys or a NaN, whose order is numpy's own business:
+ * the caller sorts those with numpy (*n_redo of them).  No context, no GPU. */
+int lsspa_host_argsort_rows(const double* keys, int64_t B, int32_t p, int32_t* out, uint8_t* redo, int32_t threads,
+                            int64_t* n_redo);
 /* overwrite the R^2 the batches' sums are checked against (LSSPA_INFO_SUM; set by lsspa_full_fit): a test makes the
  * check fire on a healthy engine with it */
 int lsspa_debug_set_r2(lsspa_ctx* ctx, double r2);

@@ -78,3 +78,86 @@ bool all_permutations_plain(const int32_t* perms, int B, int p, std::vector<int3
 
 }  // namespace lsspa
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The row argsort of the QMC samplers (ls_spa/ls_spa.py:375-397 argsort of Sobol' points, :400-456 of projected normals;
+// here ls_spa/_samplers.py) on a few native threads.  numpy.argsort(points, axis=1) is 0.8 us a row of 100 on one thread
+// and three quarters of what the sampler's helper thread does for a small problem, whose public call waits for
+// orderings half of its time -- and a second PYTHON thread for the sorts costs the driver's thread more waits for the
+// interpreter lock than it saves (measured twice, DESIGN_HISTORY.md).  Threads of this library hold no such lock.
+// A row whose keys are all different has ONE argsort, so any correct sort reproduces numpy's; rows with equal keys
+// (numpy's order among them is its sort's own business, and the reference's results inherit it) or a NaN are reported
+// and left to numpy by the caller.  Keys spread over their range (uniform points, projected normals): one counting pass
+// into 4 p buckets between the row's minimum and maximum leaves them almost in order, an insertion pass finishes --
+// correct whatever the buckets did, since the last pass is a full sort.
+#include <algorithm>
+#include <cmath>
+#include <thread>
+
+namespace lsspa {
+
+// false: the row has equal keys or a NaN (out is then unspecified)
+static bool argsort_row(const double* key, int p, int32_t* out, std::vector<int32_t>& cnt, std::vector<int32_t>& tmp) {
+  if (p == 1) {
+    out[0] = 0;
+    return key[0] == key[0];
+  }
+  double mn = key[0], mx = key[0];
+  bool nan = false;
+  for (int j = 0; j < p; ++j) {
+    const double v = key[j];
+    nan |= !(v == v);
+    mn = v < mn ? v : mn;
+    mx = v > mx ? v : mx;
+  }
+  if (nan || !(mx > mn) || !std::isfinite(mx - mn)) return false;
+  const int nb = 4 * p;
+  const double inv = (double)(nb - 1) / (mx - mn);
+  cnt.assign((size_t)nb + 1, 0);
+  tmp.resize((size_t)p);
+  for (int j = 0; j < p; ++j) {
+    int b = (int)((key[j] - mn) * inv);
+    b = b < 0 ? 0 : (b > nb - 1 ? nb - 1 : b);
+    tmp[j] = b;
+    ++cnt[b + 1];
+  }
+  for (int b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
+  for (int j = 0; j < p; ++j) out[cnt[tmp[j]]++] = j;
+  for (int i = 1; i < p; ++i) {       // the insertion pass over the bucket order
+    const int32_t x = out[i];
+    const double kx = key[x];
+    int j = i - 1;
+    while (j >= 0 && key[out[j]] > kx) {
+      out[j + 1] = out[j];
+      --j;
+    }
+    out[j + 1] = x;
+  }
+  for (int i = 1; i < p; ++i)
+    if (key[out[i]] == key[out[i - 1]]) return false;
+  return true;
+}
+
+// out [B][p] = argsort of every row of keys [B][p]; redo [B] = 1 where the row is left to the caller (equal keys, NaN).
+// Returns the number of such rows.  Rows are independent: the block is cut over up to `threads` threads.
+int64_t argsort_rows_host(const double* keys, int64_t B, int p, int32_t* out, uint8_t* redo, int threads) {
+  auto range = [&](int64_t lo, int64_t hi) {
+    std::vector<int32_t> cnt, tmp;
+    for (int64_t s = lo; s < hi; ++s) redo[s] = argsort_row(keys + s * p, p, out + s * p, cnt, tmp) ? 0 : 1;
+  };
+  int nt = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
+  nt = (int)std::min<int64_t>(nt, std::max<int64_t>(1, B / 64));
+  if (nt == 1) {
+    range(0, B);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(range, B * t / nt, B * (t + 1) / nt);
+    range(0, B / nt);                  // the caller's thread takes the first share
+    for (auto& t : th) t.join();
+  }
+  int64_t n = 0;
+  for (int64_t s = 0; s < B; ++s) n += redo[s];
+  return n;
+}
+
+}  // namespace lsspa

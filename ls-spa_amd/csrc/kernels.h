@@ -80,6 +80,9 @@ bool small_p_checks_sum(const SmallArgs& a);
 // _plain: the stamp loop alone, the test's comparison)
 bool all_permutations(const int32_t* perms, int B, int p, std::vector<int32_t>& mark);
 bool all_permutations_plain(const int32_t* perms, int B, int p, std::vector<int32_t>& mark);
+// host_perms.cpp: out [B][p] = argsort of the rows of keys [B][p] on up to `threads` native threads; redo [B] = 1 for the
+// rows left to the caller (equal keys or a NaN: numpy's order there is its own); returns their number
+int64_t argsort_rows_host(const double* keys, int64_t B, int p, int32_t* out, uint8_t* redo, int threads);
 bool small_p_eligible(int p);
 size_t small_p_lds_bytes(int nb);
 hipError_t launch_small_p(const SmallArgs& a, hipStream_t st);

@@ -2468,6 +2468,15 @@ int lsspa_debug_set_r2(lsspa_ctx* ctx, double r2) try {
   return abi_caught(ctx);
 }
 
+int lsspa_host_argsort_rows(const double* keys, int64_t B, int32_t p, int32_t* out, uint8_t* redo, int32_t threads,
+                            int64_t* n_redo) try {
+  if (!keys || !out || !redo || B < 1 || p < 1 || !n_redo) return LSSPA_ERR_ARG;
+  *n_redo = argsort_rows_host(keys, B, p, out, redo, threads);
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(nullptr);
+}
+
 int lsspa_debug_check_perms(const int32_t* perms, int32_t B, int32_t p, int32_t plain) try {
   if (!perms || B < 1 || p < 1) return 0;
   std::vector<int32_t> mark;

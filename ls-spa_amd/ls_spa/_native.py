@@ -86,6 +86,7 @@ SIGNATURES = {
     "lsspa_set_precision": (C.c_int, [_vp, _i32]),
     "lsspa_debug_fail_alloc": (C.c_int, [_vp, _i32]),
     "lsspa_debug_pack_from": (C.c_int, [_vp, _i32]),
+    "lsspa_host_argsort_rows": (C.c_int, [_pd, _i64, _i32, _pi32, C.POINTER(C.c_uint8), _i32, _pi64]),
     "lsspa_debug_set_r2": (C.c_int, [_vp, _dbl]),
     "lsspa_debug_check_perms": (C.c_int, [_pi32, _i32, _i32, _i32]),
     "lsspa_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),

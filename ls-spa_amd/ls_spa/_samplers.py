@@ -135,11 +135,51 @@ def _pool():
     return _sort_pool
 
 
+_native_sort = False      # False: not looked for yet; None: not there; else the library's lsspa_host_argsort_rows
+
+
+def _native_argsort(a):
+    """np.argsort(a, axis=1) by the library's own threads (include/lsspa.h, lsspa_host_argsort_rows), or None if the
+    library is not there.  A row whose keys are all different has one argsort; the rows the library marks -- equal keys,
+    NaN: numpy's order among those is its sort's own business and the reference's results inherit it -- are sorted by
+    numpy here, so the result is numpy's for every row."""
+    global _native_sort
+    if _native_sort is False:
+        try:
+            from . import _native
+            _native_sort = (_native.load().lsspa_host_argsort_rows, _native)
+        except Exception:
+            _native_sort = None
+    if _native_sort is None:
+        return None
+    fn, N = _native_sort
+    import ctypes as C
+    import os
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.empty(a.shape, dtype=np.int32)
+    redo = np.empty(len(a), dtype=np.uint8)
+    n_redo = C.c_int64()
+    threads = max(1, min(3, (os.cpu_count() or 2) // 4))
+    rc = fn(N.dptr(a), len(a), a.shape[1], N.iptr(out), redo.ctypes.data_as(C.POINTER(C.c_uint8)), threads,
+            C.byref(n_redo))
+    if rc != 0:
+        return None
+    if n_redo.value:
+        rows = np.nonzero(redo)[0]
+        out[rows] = np.argsort(a[rows], axis=1)
+    return out
+
+
 def _argsort_rows(a):
-    """np.argsort(a, axis=1) as int32 (what the engine uploads); large blocks are cut into row ranges sorted on a few
-    threads (the sort releases the GIL) -- same result, row by row.  (Not the 1024 x 100 blocks of a small problem:
-    threads there took the driver's own thread 1.6 ms of a 4 ms run -- measured, round 5.)"""
+    """np.argsort(a, axis=1) as int32 (what the engine uploads).  Blocks of 64 rows and more by the library's native
+    threads (_native_argsort: the same result, row by row); without the library numpy, large blocks cut into row ranges
+    sorted on a few threads (the sort releases the GIL).  (Python threads for the 1024 x 100 blocks of a small problem
+    took the driver's own thread 1.6 ms of a 4 ms run -- measured, round 5.)"""
     n = len(a)
+    if n >= 64 and a.ndim == 2 and a.shape[1] >= 2:
+        got = _native_argsort(a)
+        if got is not None:
+            return got
     if a.size < (1 << 17) or n < 64:
         return np.argsort(a, axis=1).astype(np.int32)
     pool = _pool()

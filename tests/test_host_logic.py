@@ -527,6 +527,41 @@ def test_batch_validation_fast_form_agrees_with_the_stamp_loop():
             assert verdicts(q) == (0, 0), (p, t, s, j)
 
 
+def test_native_row_argsort_is_numpys():
+    """The QMC sources' row argsort goes through the library's native threads (lsspa_host_argsort_rows; the reference:
+    np.argsort of Sobol' points / projected normals, experiments/ground_truth_medium.py:56-71).  A row with all keys
+    different has one argsort; rows with equal keys or a NaN are marked and sorted by numpy -- so every row is numpy's,
+    whatever numpy does with ties."""
+    import warnings
+    from scipy.stats.qmc import Sobol
+    from ls_spa import _native
+    lib = _native.load()
+    rng = np.random.default_rng(8)
+    for p, n in ((2, 70), (12, 64), (100, 1024), (101, 333), (1000, 130)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            keys = Sobol(p, seed=p).random(n) if p % 2 == 0 else rng.standard_normal((n, p))
+        np.testing.assert_array_equal(S._argsort_rows(keys), np.argsort(keys, axis=1))
+        spoilt = keys.copy()
+        spoilt[3, 0] = spoilt[3, p - 1]          # equal keys at the two ends of a row
+        spoilt[9, :] = 0.5                       # a constant row
+        spoilt[17, p // 2] = np.nan
+        spoilt[21, 0] = np.inf
+        got = S._argsort_rows(spoilt)
+        assert got.dtype == np.int32
+        np.testing.assert_array_equal(got, np.argsort(spoilt, axis=1))
+        out, redo, n_redo = np.empty((n, p), np.int32), np.empty(n, np.uint8), ctypes.c_int64()
+        assert lib.lsspa_host_argsort_rows(_native.dptr(spoilt), n, p, _native.iptr(out),
+                                           redo.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), 3, ctypes.byref(n_redo)) == 0
+        marked = set(np.nonzero(redo)[0])
+        assert {3, 9, 17} <= marked and n_redo.value == len(marked)          # (the row with +inf may sort or be left)
+        for r in marked - {3, 9, 17, 21}:          # Sobol' points carry 30 bits: a row of 1000 has equal keys now and then
+            assert len(np.unique(spoilt[r])) < p
+    # below 64 rows the blocks stay with numpy
+    few = rng.random((10, 30))
+    np.testing.assert_array_equal(S._argsort_rows(few), np.argsort(few, axis=1))
+
+
 def test_product_never_imports_oracle():
     pkg_dir = os.path.join(ROOT, "ls-spa_amd")
     for base, _, files in os.walk(pkg_dir):
