@@ -1044,7 +1044,7 @@ def main():
                             "max": max(per_check) if per_check else None},
                         "sum_attribution": sum_attr, "r_squared": r2,
                         "note": f"ls_spa(method='argsort', batch_size={B}, num_batches={nb}, tolerance=0.0): the public call "
-                                "through sampler (SciPy Sobol + argsort on a helper thread), driver, device estimator "
+                                "through sampler (SciPy's Sobol' stream and its argsort, drawn ahead by threads of the library), driver, device estimator "
                                 "(running form, checks deferred by one) and statistics; orderings_per_s is over the "
                                 "sampling loop (host_seconds sampler + estimator + sampling), seconds the whole call "
                                 "(one GPU: engine, reduction over PCIe, final fit included); loop_ms_per_check = host "

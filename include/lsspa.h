@@ -314,6 +314,21 @@ int lsspa_debug_pack_from(lsspa_ctx* ctx, int32_t p_min);
  * the caller sorts those with numpy (*n_redo of them).  No context, no GPU. */
 int lsspa_host_argsort_rows(const double* keys, int64_t B, int32_t p, int32_t* out, uint8_t* redo, int32_t threads,
                             int64_t* n_redo);
+/* The 'argsort' ordering source as a thread of this library (the reference: np.argsort(qmc.Sobol(p, seed).random(n), axis=1),
+ * experiments/ground_truth_medium.py:56-60): Sobol' points by SciPy's own recurrence -- the caller reads direction numbers
+ * sv [p][bits], the state before the first step q0 [p] and the scale off a SciPy engine it built, having checked them
+ * against that engine's output -- and their row argsort, drawn `block` orderings at a time up to `ahead` ahead of the
+ * consumer (`ahead_unasked` until the first lsspa_sampler_take) on `threads` sort threads; ordering number g of the run
+ * belongs to rank g mod world, only those rows are sorted and handed out.  lsspa_sampler_take: the next `count`
+ * orderings of the run -- *n_taken of them exist --, this rank's rows of them into out [cap][p] (*n_own rows); rows with
+ * equal keys (numpy's order among them is its own) are listed by position in `out` and number in the run: the caller
+ * sorts those with numpy.  Errors of these three calls are read with lsspa_last_error(NULL).  No context, no GPU. */
+int lsspa_sampler_create(int32_t p, int32_t bits, const uint64_t* sv, const uint64_t* q0, double scale, int64_t limit,
+                         int32_t block, int64_t ahead, int64_t ahead_unasked, int32_t threads, int32_t rank,
+                         int32_t world, void** out);
+int lsspa_sampler_take(void* sampler, int64_t count, int32_t* out, int64_t cap, int64_t* n_taken, int64_t* n_own,
+                       int64_t* redo_pos, int64_t* redo_id, int64_t* n_redo);
+int lsspa_sampler_destroy(void* sampler);
 /* overwrite the R^2 the batches' sums are checked against (LSSPA_INFO_SUM; set by lsspa_full_fit): a test makes the
  * check fire on a healthy engine with it */
 int lsspa_debug_set_r2(lsspa_ctx* ctx, double r2);

@@ -83,6 +83,13 @@ bool all_permutations_plain(const int32_t* perms, int B, int p, std::vector<int3
 // host_perms.cpp: out [B][p] = argsort of the rows of keys [B][p] on up to `threads` native threads; redo [B] = 1 for the
 // rows left to the caller (equal keys or a NaN: numpy's order there is its own); returns their number
 int64_t argsort_rows_host(const double* keys, int64_t B, int p, int32_t* out, uint8_t* redo, int threads);
+// host_perms.cpp: the 'argsort' ordering source as a native thread (Sobol' points by SciPy's recurrence + row argsort)
+struct SobolSampler;
+SobolSampler* sobol_sampler_create(int p, int bits, const uint64_t* sv_pb, const uint64_t* q0, double scale, int64_t limit,
+                                   int block, int64_t ahead, int64_t ahead_unasked, int threads, int rank, int world);
+void sobol_sampler_destroy(SobolSampler* s);
+int sobol_sampler_take(SobolSampler* s, int64_t count, int32_t* out, int64_t cap, int64_t* n_taken, int64_t* n_own,
+                       int64_t* redo_pos, int64_t* redo_id, int64_t* n_redo, const char** err);
 bool small_p_eligible(int p);
 size_t small_p_lds_bytes(int nb);
 hipError_t launch_small_p(const SmallArgs& a, hipStream_t st);

@@ -2477,6 +2477,49 @@ int lsspa_host_argsort_rows(const double* keys, int64_t B, int32_t p, int32_t* o
   return abi_caught(nullptr);
 }
 
+int lsspa_sampler_create(int32_t p, int32_t bits, const uint64_t* sv, const uint64_t* q0, double scale, int64_t limit,
+                         int32_t block, int64_t ahead, int64_t ahead_unasked, int32_t threads, int32_t rank,
+                         int32_t world, void** out) try {
+  if (!out) return LSSPA_ERR_ARG;
+  *out = nullptr;
+  if (p < 1 || bits < 1 || bits > 64 || !sv || !q0 || !(scale > 0.0) || limit < 0 || block < 1 || ahead < 1 ||
+      ahead_unasked < 1 || threads < 1 || world < 1 || rank < 0 || rank >= world) {
+    g_create_error = "lsspa_sampler_create: bad argument";
+    return LSSPA_ERR_ARG;
+  }
+  *out = sobol_sampler_create(p, bits, sv, q0, scale, limit, block, ahead, ahead_unasked, threads, rank, world);
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(nullptr);
+}
+
+int lsspa_sampler_take(void* sampler, int64_t count, int32_t* out, int64_t cap, int64_t* n_taken, int64_t* n_own,
+                       int64_t* redo_pos, int64_t* redo_id, int64_t* n_redo) try {
+  if (!sampler || count < 0 || !out || cap < 0 || !n_taken || !n_own || !redo_pos || !redo_id || !n_redo)
+    return LSSPA_ERR_ARG;
+  const char* err = nullptr;
+  const int rc = sobol_sampler_take(static_cast<SobolSampler*>(sampler), count, out, cap, n_taken, n_own, redo_pos,
+                                    redo_id, n_redo, &err);
+  if (rc == 1) {
+    g_create_error = "lsspa_sampler_take: the output buffer is too small for this rank's share";
+    return LSSPA_ERR_ARG;
+  }
+  if (rc == 2) {
+    g_create_error = std::string("lsspa_sampler: ") + (err ? err : "the producer failed");
+    return LSSPA_ERR_STATE;
+  }
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(nullptr);
+}
+
+int lsspa_sampler_destroy(void* sampler) try {
+  sobol_sampler_destroy(static_cast<SobolSampler*>(sampler));
+  return LSSPA_OK;
+} catch (...) {
+  return abi_caught(nullptr);
+}
+
 int lsspa_debug_check_perms(const int32_t* perms, int32_t B, int32_t p, int32_t plain) try {
   if (!perms || B < 1 || p < 1) return 0;
   std::vector<int32_t> mark;

@@ -272,7 +272,11 @@ def prepare_sampling(p, *, max_samples, batch_size, seed, perms, antithetical, m
     elif method == "random":
         source = S.RandomSource(rng, p, max_samples)
     elif method == "argsort":
-        source = S.ArgsortSource(p, seed, max_samples)
+        # a thread of the library draws the orderings ahead (no interpreter lock between it and this thread; SciPy's
+        # engine still defines the stream); the Python source and its helper thread if that cannot be had
+        source = (S.NativeArgsortSource.make(p, seed, max_samples, block=1024 if p <= SMALL_P_MAX else 256, rank=rank,
+                                             world=world)
+                  or S.ArgsortSource(p, seed, max_samples))
     elif method == "permutohedron":
         source = S.PermutohedronSource(p, seed, max_samples)
     else:
@@ -280,7 +284,8 @@ def prepare_sampling(p, *, max_samples, batch_size, seed, perms, antithetical, m
     if source.independent:
         # the QMC samplers draw ahead of the loop on a helper thread (their stream is nobody else's), from now on --
         # in ls_spa() that is under the data reduction
-        source = S.PrefetchedSource(source, block=1024 if p <= SMALL_P_MAX else 256, rank=rank, world=world)
+        if not isinstance(source, S.NativeArgsortSource):
+            source = S.PrefetchedSource(source, block=1024 if p <= SMALL_P_MAX else 256, rank=rank, world=world)
     return rng, source, batch_size, antithetical, max_samples, never_stop
 
 

@@ -87,6 +87,10 @@ SIGNATURES = {
     "lsspa_debug_fail_alloc": (C.c_int, [_vp, _i32]),
     "lsspa_debug_pack_from": (C.c_int, [_vp, _i32]),
     "lsspa_host_argsort_rows": (C.c_int, [_pd, _i64, _i32, _pi32, C.POINTER(C.c_uint8), _i32, _pi64]),
+    "lsspa_sampler_create": (C.c_int, [_i32, _i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _dbl, _i64, _i32, _i64,
+                                      _i64, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "lsspa_sampler_take": (C.c_int, [_vp, _i64, _pi32, _i64, _pi64, _pi64, _pi64, _pi64, _pi64]),
+    "lsspa_sampler_destroy": (C.c_int, [_vp]),
     "lsspa_debug_set_r2": (C.c_int, [_vp, _dbl]),
     "lsspa_debug_check_perms": (C.c_int, [_pi32, _i32, _i32, _i32]),
     "lsspa_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),

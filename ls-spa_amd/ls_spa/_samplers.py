@@ -532,5 +532,163 @@ class PrefetchedSource(OrderingSource):
         self._thread.join(timeout=5)
 
 
+_sobol_numbers = {}       # (p, seed) -> _DirectSobol of SciPy's engine for them (checked against the engine when made)
+
+
+class NativeArgsortSource(OrderingSource):
+    """The 'argsort' source drawn ahead of the loop by a thread of the library (include/lsspa.h, lsspa_sampler_*):
+    Sobol' points by SciPy's own recurrence and their row argsort with no interpreter in the way -- the Python helper of
+    PrefetchedSource shares the interpreter lock with the driver's thread, and the public call of a small problem waited
+    for orderings a third of its time.  SciPy's engine still defines the stream: it is built here (on a helper thread,
+    under the caller's engine creation), its direction numbers, first state and scale are read off it (_DirectSobol)
+    and checked against its own output before they are used; rows with equal keys come back marked and are sorted by
+    numpy from their points, so every row is what ArgsortSource hands out
+    (tests/test_host_logic.py::test_native_argsort_source_is_the_python_one).  ``make`` returns None -- the caller
+    then takes PrefetchedSource(ArgsortSource) -- if the library or the engine's private attributes are not there."""
+    independent = True
+
+    def __init__(self, p, seed, limit, block, ahead, rank, world):
+        self._p, self._rank, self._world, self._taken = int(p), int(rank), int(world), 0
+        self._h = self._lib = self._N = self._direct = self._fallback = None
+        self._args = (p, seed, limit, block, ahead)
+        limit = int(min(limit, 2 ** 62))
+
+        def build():
+            import ctypes as C
+            from . import _native as N
+            lib = N.load()
+            # SciPy's constructor (the scramble) takes 3-8 ms at p = 100 and tens at p = 1000; its numbers are a function
+            # of (p, seed): a process that calls again with the same ones -- an experiment's runs, a benchmark's
+            # repetitions -- reads them off the first call's engine
+            key = (int(p), int(seed)) if isinstance(seed, (int, np.integer)) and not isinstance(seed, bool) else None
+            direct = _sobol_numbers.get(key) if key is not None else None
+            if direct is None:
+                from scipy.stats.qmc import Sobol
+                direct = _DirectSobol.make(Sobol(p, seed=seed))
+                if direct is None:
+                    raise RuntimeError("SciPy's Sobol engine does not match its direct form")
+                if key is not None:
+                    if len(_sobol_numbers) >= 8:
+                        _sobol_numbers.pop(next(iter(_sobol_numbers)))
+                    _sobol_numbers[key] = direct
+            sv = np.ascontiguousarray(direct.sv, dtype=np.uint64)
+            q0 = np.ascontiguousarray(direct.q0, dtype=np.uint64)
+            import os
+            threads = max(1, min(4, (os.cpu_count() or 2) // 4))      # producers: each draws and sorts whole blocks
+            small = (8 * p * block) <= (1 << 20)          # as PrefetchedSource: one block until first asked, unless small
+            h = C.c_void_p()
+            rc = lib.lsspa_sampler_create(int(p), direct.bits, sv.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                          q0.ctypes.data_as(C.POINTER(C.c_uint64)), direct.scale, limit, int(block),
+                                          int(ahead), int(ahead if small else block), threads, int(rank), int(world),
+                                          C.byref(h))
+            if rc != 0:
+                raise RuntimeError("lsspa_sampler_create failed: " + (lib.lsspa_last_error(None) or b"").decode())
+            return lib, N, direct, h
+
+        self._build = _BackgroundBuild(build)
+
+    @classmethod
+    def make(cls, p, seed, limit, block=256, ahead=None, rank=0, world=1):
+        try:
+            from . import _native
+            if not hasattr(_native.load(), "lsspa_sampler_create"):
+                return None
+        except Exception:
+            return None
+        if ahead is None:
+            ahead = max(2 * block, min(8192, (64 << 20) // (8 * max(1, p))))
+        return cls(p, seed, limit, block, ahead, rank, world)
+
+    def _ready(self):
+        if self._h is None:
+            if self._build is None:
+                raise ValueError("the source has been closed")
+            self._lib, self._N, self._direct, self._h = self._build.get()
+        return self._lib
+
+    def usable(self):
+        """False if the background build failed (the caller falls back to the Python source)."""
+        try:
+            self._ready()
+            return True
+        except Exception:
+            return False
+
+    def _python_source(self):
+        """The Python source instead (SciPy's engine no longer matches its direct form, or the sampler could not be made):
+        only ever chosen before the first ordering has been handed out."""
+        if self._fallback is None:
+            p, seed, limit, block, ahead = self._args
+            self._fallback = PrefetchedSource(ArgsortSource(p, seed, limit), block=block, ahead=ahead, rank=self._rank,
+                                              world=self._world)
+        return self._fallback
+
+    def take_share(self, count, first, rank, world):
+        if (rank, world) != (self._rank, self._world) or first != self._taken:
+            raise ValueError("the native source was made for another rank, or orderings were taken out of turn")
+        import ctypes as C
+        if self._fallback is None and self._h is None:
+            try:
+                self._ready()
+            except ValueError:
+                raise
+            except Exception:
+                self._python_source()
+        if self._fallback is not None:
+            n, own = self._fallback.take_share(count, first, rank, world)
+            self._taken += n
+            return n, own
+        lib = self._lib
+        count = int(count)
+        cap = count // self._world + 2
+        out = np.empty((cap, self._p), dtype=np.int32)
+        pos, ids = np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int64)
+        n_taken, n_own, n_redo = C.c_int64(), C.c_int64(), C.c_int64()
+        N = self._N
+        rc = lib.lsspa_sampler_take(self._h, count, N.iptr(out), cap, C.byref(n_taken), C.byref(n_own),
+                                    pos.ctypes.data_as(N._pi64), ids.ctypes.data_as(N._pi64), C.byref(n_redo))
+        if rc != 0:
+            raise RuntimeError("lsspa_sampler_take failed: " + (lib.lsspa_last_error(None) or b"").decode())
+        k = n_redo.value
+        if k:       # equal keys in a row: numpy's order among them is its own -- its argsort of the row's points
+            out[pos[:k]] = np.argsort(self._direct.points(ids[:k]), axis=1)
+        self._taken += n_taken.value
+        return n_taken.value, out[:n_own.value]
+
+    def take(self, count):
+        if self._world != 1:
+            raise ValueError("a rank's source hands out shares: use take_share")
+        return self.take_share(count, self._taken, 0, 1)[1]
+
+    def skip(self, count):
+        left = int(count)
+        while left > 0:
+            got = self.take_share(min(left, 4096), self._taken, self._rank, self._world)[0]
+            if got == 0:
+                break
+            left -= got
+
+    def close(self):
+        build, self._build = self._build, None
+        if self._fallback is not None:
+            self._fallback.close()
+        if build is None:
+            return                 # closed before
+        try:
+            if self._h is None:
+                self._lib, self._N, self._direct, self._h = build.get()
+        except Exception:
+            return
+        h, self._h = self._h, None
+        if h is not None:
+            self._lib.lsspa_sampler_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def exact_source(p):
     return IterableSource(itertools.permutations(range(p)), p)

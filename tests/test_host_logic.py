@@ -562,6 +562,62 @@ def test_native_row_argsort_is_numpys():
     np.testing.assert_array_equal(S._argsort_rows(few), np.argsort(few, axis=1))
 
 
+def test_native_argsort_source_is_the_python_one():
+    """method='argsort' draws its orderings on a thread of the library (lsspa_sampler_*: Sobol' points by SciPy's
+    recurrence, read off a SciPy engine and checked against it, and their row argsort).  What it hands out is what the
+    Python source hands out -- the reference's np.argsort(Sobol(p, seed).random(n), axis=1),
+    experiments/ground_truth_medium.py:56-60 -- for one process and for every rank of several, whatever the sizes asked
+    for, past the end of the source, after a skip, and in rows whose points have equal coordinates (30-bit points: a few
+    in a thousand rows at p = 1000), which come back marked and are sorted by numpy."""
+    for p, n, block in ((12, 300, 64), (100, 3000, 1024), (1000, 2500, 256)):
+        full = S.ArgsortSource(p, 5, 10 ** 6).take(n)
+        ties = sum(len(np.unique(r)) < p for r in S._DirectSobol.make(__import__("scipy.stats").stats.qmc.Sobol(p, seed=5))
+                   .points(np.arange(n)))
+        if p == 1000:
+            assert ties > 0          # the marked-row path is exercised
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                src = S.NativeArgsortSource.make(p, 5, n, block=block, rank=rank, world=world)
+                assert src is not None and src.usable()
+                pos, rows, idx = 0, [], []
+                for cnt in (1, 10, 100, 7, 120, 50, 10 ** 4):
+                    m, own = src.take_share(cnt, pos, rank, world)
+                    idx.append(np.arange(pos + (rank - pos) % world, pos + m, world))
+                    rows.append(own)
+                    pos += m
+                assert pos == n and src.take_share(5, pos, rank, world)[0] == 0
+                np.testing.assert_array_equal(np.concatenate(rows), full[np.concatenate(idx)])
+                src.close()
+                src.close()          # twice is once
+    src = S.NativeArgsortSource.make(23, 7, 500, block=64)
+    src.skip(123)
+    np.testing.assert_array_equal(src.take(77), S.ArgsortSource(23, 7, 500).take(200)[123:])
+    with pytest.raises(ValueError, match="out of turn"):
+        src.take_share(4, 3, 0, 1)
+    src.close()
+    # the public call takes it for method='argsort' and gives the Python source's run to the last bit
+    g = np.load(os.path.join(ROOT, "tests", "golden", "p12.npz"))
+    d = [g[k] for k in ("X_train", "X_test", "y_train", "y_test")]
+    kw = dict(method="argsort", seed=5, max_samples=96, batch_size=16, tolerance=0.0)
+    from ls_spa import _driver
+    made = []
+    real = S.NativeArgsortSource.make.__func__
+
+    def spy(cls, *a, **k):
+        made.append(real(cls, *a, **k))
+        return made[-1]
+    S.NativeArgsortSource.make = classmethod(spy)
+    try:
+        nat = ls_spa(*d, _engine=OracleEngine(), **kw)
+        assert len(made) == 1 and made[0] is not None and made[0]._fallback is None
+        S.NativeArgsortSource.make = classmethod(lambda cls, *a, **k: None)
+        py = ls_spa(*d, _engine=OracleEngine(), **kw)
+    finally:
+        S.NativeArgsortSource.make = classmethod(real)
+    np.testing.assert_array_equal(nat.attribution, py.attribution)
+    np.testing.assert_array_equal(nat.error_history, py.error_history)
+
+
 def test_product_never_imports_oracle():
     pkg_dir = os.path.join(ROOT, "ls-spa_amd")
     for base, _, files in os.walk(pkg_dir):
