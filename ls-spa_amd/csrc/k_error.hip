@@ -379,33 +379,55 @@ __global__ __launch_bounds__(256) void prefix_norms_kernel(EstChunks ch, const d
   const int a0 = lane, a1 = lane + 64;
   double r0 = a0 < p ? D[(int64_t)d * ld + a0] : 0.0, r1 = a1 < p ? D[(int64_t)d * ld + a1] : 0.0;
   double sr = s[d];
-  for (int c = 0; c < ch.n; ++c) {
-    const int64_t o = ((int64_t)c * ND + d) * ld;
-    if (a0 < p) {
-      r0 = r0 + P[o + a0];
-      Dsnap[o + a0] = r0;
-    }
-    if (a1 < p) {
-      r1 = r1 + P[o + a1];
-      Dsnap[o + a1] = r1;
-    }
-    sr = sr + S[(int64_t)c * ND + d];
-    if (lane == 0) ssnap[(int64_t)c * ND + d] = sr;
-    const double scale = ch.scale[c];
-    if (scale != 0.0) {
-      const double* mean = mean_snap + (int64_t)c * p;
-      double v = 0.0;
-      if (a0 < p) {
-        const double x = draw_value(r0, sr, mean[a0], scale);
-        v = __builtin_fma(x, x, v);
-      }
-      if (a1 < p) {
-        const double x = draw_value(r1, sr, mean[a1], scale);
-        v = __builtin_fma(x, x, v);
-      }
+  // eight chunks a turn, all their loads issued before the first sum (a chain of dependent memory round trips otherwise:
+  // 30 us for sixteen chunks)
+  constexpr int CB = 8;
+  for (int c0 = 0; c0 < ch.n; c0 += CB) {
+    double p0[CB], p1[CB], sc[CB], m0[CB], m1[CB], scl[CB];
 #pragma unroll
-      for (int o2 = 1; o2 < 64; o2 <<= 1) v += __shfl_xor(v, o2, 64);
-      if (lane == 0) norms[(int64_t)c * ND + d] = sqrt(v);
+    for (int u = 0; u < CB; ++u) {
+      const int c = c0 + u;
+      const bool live = c < ch.n;
+      const int64_t o = ((int64_t)(live ? c : c0) * ND + d) * ld;
+      p0[u] = (live && a0 < p) ? P[o + a0] : 0.0;
+      p1[u] = (live && a1 < p) ? P[o + a1] : 0.0;
+      sc[u] = live ? S[(int64_t)c * ND + d] : 0.0;
+      scl[u] = live ? ch.scale[c] : 0.0;
+      const double* mean = mean_snap + (int64_t)(live ? c : c0) * p;
+      m0[u] = (live && a0 < p) ? mean[a0] : 0.0;
+      m1[u] = (live && a1 < p) ? mean[a1] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < CB; ++u) {
+      const int c = c0 + u;
+      if (c < ch.n) {
+        const int64_t o = ((int64_t)c * ND + d) * ld;
+        if (a0 < p) {
+          r0 = r0 + p0[u];
+          Dsnap[o + a0] = r0;
+        }
+        if (a1 < p) {
+          r1 = r1 + p1[u];
+          Dsnap[o + a1] = r1;
+        }
+        sr = sr + sc[u];
+        if (lane == 0) ssnap[(int64_t)c * ND + d] = sr;
+        const double scale = scl[u];
+        if (scale != 0.0) {
+          double v = 0.0;
+          if (a0 < p) {
+            const double x = draw_value(r0, sr, m0[u], scale);
+            v = __builtin_fma(x, x, v);
+          }
+          if (a1 < p) {
+            const double x = draw_value(r1, sr, m1[u], scale);
+            v = __builtin_fma(x, x, v);
+          }
+#pragma unroll
+          for (int o2 = 1; o2 < 64; o2 <<= 1) v += __shfl_xor(v, o2, 64);
+          if (lane == 0) norms[(int64_t)c * ND + d] = sqrt(v);
+        }
+      }
     }
   }
   if (a0 < p) D[(int64_t)d * ld + a0] = r0;
